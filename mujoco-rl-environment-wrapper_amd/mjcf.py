@@ -1,0 +1,714 @@
+"""MJCF subset compiler: level XML -> flat constant tables for the batched stepper.
+
+The reference hands its XML to ``mujoco.MjModel.from_xml_path`` (mujoco_parent.py:126).  That
+package is not part of the reference tree; this module re-implements the compile semantics
+the 19 shipped levels rely on from MuJoCo's published XML reference:
+default classes, degrees, intrinsic xyz euler, ``fromto`` capsules, inertia inferred from geoms,
+depth-first body numbering with static bodies kept, weld-based collision filtering, motor
+actuators, and the constants derived at ``qpos0`` (``body_invweight0``, ``dof_invweight0``,
+``meaninertia``).
+
+Everything here is host-side, run once per level.  Output is a :class:`Model` of numpy arrays
+that ``blob.pack`` serialises for the C-ABI (include/mjrl.h) and for the oracle.
+"""
+from __future__ import annotations
+
+import math
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# enums (values follow MuJoCo's public mjtGeom / mjtJoint / mjtSensor ordering where it matters:
+# collision functions are indexed with the lower geom type first)
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX = range(7)
+GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = range(4)
+JNT_TYPES = {"free": JNT_FREE, "hinge": JNT_HINGE, "slide": JNT_SLIDE}
+SENS_TOUCH, SENS_ACCELEROMETER, SENS_RANGEFINDER, SENS_FRAMEXAXIS, SENS_FRAMEYAXIS, SENS_FRAMEZAXIS = range(6)
+SENSOR_TYPES = {
+    "touch": (SENS_TOUCH, 1), "accelerometer": (SENS_ACCELEROMETER, 3),
+    "rangefinder": (SENS_RANGEFINDER, 1), "framexaxis": (SENS_FRAMEXAXIS, 3),
+    "frameyaxis": (SENS_FRAMEYAXIS, 3), "framezaxis": (SENS_FRAMEZAXIS, 3),
+}
+INT_EULER, INT_RK4 = 0, 1
+
+MINVAL = 1e-15
+
+
+# ----------------------------------------------------------------------------- small math
+def _vec(text, n=None, default=None):
+    if text is None:
+        return None if default is None else np.array(default, dtype=np.float64)
+    v = np.array([float(t) for t in text.split()], dtype=np.float64)
+    if n is not None and v.size < n and default is not None:
+        full = np.array(default, dtype=np.float64)
+        full[: v.size] = v
+        v = full
+    return v
+
+
+def quat_mul(a, b):
+    return np.array([
+        a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+        a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+        a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+        a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def quat_to_mat(q):
+    w, x, y, z = q
+    return np.array([
+        [w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
+def mat_to_quat(m):
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        q = np.array([0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s])
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = math.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+        q = np.array([(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s])
+    elif m[1, 1] > m[2, 2]:
+        s = math.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+        q = np.array([(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s])
+    else:
+        s = math.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+        q = np.array([(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s])
+    return q / np.linalg.norm(q)
+
+
+def axis_angle_quat(axis, ang):
+    axis = np.asarray(axis, dtype=np.float64)
+    n = np.linalg.norm(axis)
+    if n < MINVAL:
+        return np.array([1.0, 0, 0, 0])
+    s = math.sin(ang / 2) / n
+    return np.array([math.cos(ang / 2), axis[0] * s, axis[1] * s, axis[2] * s])
+
+
+def z_to_quat(vec):
+    """Quaternion turning the z axis onto ``vec`` (unit)."""
+    axis = np.cross([0.0, 0.0, 1.0], vec)
+    s = np.linalg.norm(axis)
+    if s < 1e-10:
+        axis = np.array([1.0, 0.0, 0.0])
+    else:
+        axis = axis / s
+    ang = math.atan2(s, vec[2])
+    return np.array([math.cos(ang / 2), *(axis * math.sin(ang / 2))])
+
+
+# ----------------------------------------------------------------------------- model container
+@dataclass
+class Model:
+    # sizes
+    nq: int = 0
+    nv: int = 0
+    nu: int = 0
+    nbody: int = 0
+    njnt: int = 0
+    ngeom: int = 0
+    nsite: int = 0
+    ncam: int = 0
+    nsensor: int = 0
+    nsensordata: int = 0
+    npair: int = 0
+    nM: int = 0
+    ntree: int = 0
+    # options
+    timestep: float = 0.002
+    gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
+    integrator: int = INT_EULER
+    iterations: int = 100
+    tolerance: float = 1e-8
+    impratio: float = 1.0
+    meaninertia: float = 1.0
+    nconmax: int = 24        # contact cap per env copy (MuJoCo's <size nconmax>)
+    njmax: int = 112         # constraint-row cap per env copy (MuJoCo's <size njmax>)
+    # everything else is set by the compiler as numpy arrays
+    arrays: dict = field(default_factory=dict)
+    names: dict = field(default_factory=dict)
+    xml_path: str = ""
+
+    def __getattr__(self, key):
+        arrays = self.__dict__.get("arrays", {})
+        if key in arrays:
+            return arrays[key]
+        raise AttributeError(key)
+
+    def name2id(self, kind: str, name: str) -> int:
+        try:
+            return self.names[kind].index(name)
+        except ValueError:
+            raise KeyError(f"Invalid name '{name}'. No {kind} with that name.")
+
+
+# ----------------------------------------------------------------------------- defaults handling
+class _Defaults:
+    """``<default>`` tree: class name -> {tag: attrib dict}; child classes inherit."""
+
+    def __init__(self, root: ET.Element):
+        self.classes = {"main": {}}
+        top = root.find("default")
+        if top is not None:
+            self._walk(top, "main", {})
+
+    def _walk(self, elem, cls_name, inherited):
+        own = {tag: dict(attrs) for tag, attrs in inherited.items()}
+        for child in elem:
+            if child.tag == "default":
+                continue
+            own.setdefault(child.tag, {}).update(child.attrib)
+        self.classes[cls_name] = own
+        for child in elem:
+            if child.tag == "default":
+                self._walk(child, child.attrib.get("class", "main"), own)
+
+    def apply(self, elem: ET.Element, childclass):
+        cls = elem.attrib.get("class", childclass or "main")
+        merged = dict(self.classes.get(cls, {}).get(elem.tag, {}))
+        merged.update(elem.attrib)
+        return merged
+
+
+# ----------------------------------------------------------------------------- compiler
+class _Compiler:
+    def __init__(self, xml_text: str):
+        self.root = ET.fromstring(xml_text)
+        comp = self.root.find("compiler")
+        comp = comp.attrib if comp is not None else {}
+        self.degree = comp.get("angle", "degree") == "degree"
+        self.eulerseq = comp.get("eulerseq", "xyz")
+        self.defaults = _Defaults(self.root)
+        self.bodies, self.joints, self.geoms, self.sites, self.cams = [], [], [], [], []
+
+    # -- orientation attributes -------------------------------------------------
+    def _angle(self, a):
+        return math.radians(a) if self.degree else a
+
+    def orientation(self, attrs):
+        if "quat" in attrs:
+            q = _vec(attrs["quat"])
+            return q / np.linalg.norm(q)
+        if "euler" in attrs:
+            e = _vec(attrs["euler"])
+            q = np.array([1.0, 0, 0, 0])
+            for ax_char, ang in zip(self.eulerseq, e):
+                axis = np.zeros(3)
+                axis["xyz".index(ax_char.lower())] = 1.0
+                rot = axis_angle_quat(axis, self._angle(ang))
+                q = quat_mul(q, rot) if ax_char.islower() else quat_mul(rot, q)
+            return q / np.linalg.norm(q)
+        if "axisangle" in attrs:
+            aa = _vec(attrs["axisangle"])
+            return axis_angle_quat(aa[:3], self._angle(aa[3]))
+        if "xyaxes" in attrs:
+            xy = _vec(attrs["xyaxes"])
+            x = xy[:3] / np.linalg.norm(xy[:3])
+            y = xy[3:] - np.dot(xy[3:], x) * x
+            y /= np.linalg.norm(y)
+            z = np.cross(x, y)
+            return mat_to_quat(np.stack([x, y, z], axis=1))
+        if "zaxis" in attrs:
+            z = _vec(attrs["zaxis"])
+            return z_to_quat(z / np.linalg.norm(z))
+        return np.array([1.0, 0, 0, 0])
+
+    # -- tree walk ---------------------------------------------------------------
+    def walk(self):
+        world = self.root.find("worldbody")
+        self.bodies.append(dict(name="world", parent=0, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]),
+                                jnts=[], geoms=[]))
+        self._body_children(world, 0, None)
+
+    def _body_children(self, elem, body_id, childclass):
+        # MuJoCo numbers bodies depth-first in document order; joints, geoms, sites and cameras are
+        # numbered in the order their owning bodies are numbered.
+        for child in elem:
+            if child.tag == "joint" or child.tag == "freejoint":
+                self._add_joint(child, body_id, childclass)
+            elif child.tag == "geom":
+                self._add_geom(child, body_id, childclass)
+            elif child.tag == "site":
+                a = self.defaults.apply(child, childclass)
+                self.sites.append(dict(name=a.get("name", ""), body=body_id,
+                                       pos=_vec(a.get("pos"), 3, [0, 0, 0]), quat=self.orientation(a),
+                                       size=_vec(a.get("size"), 3, [0.005, 0.005, 0.005])))
+            elif child.tag == "camera":
+                a = self.defaults.apply(child, childclass)
+                self.cams.append(dict(name=a.get("name", ""), body=body_id,
+                                      pos=_vec(a.get("pos"), 3, [0, 0, 0]), quat=self.orientation(a),
+                                      fovy=float(a.get("fovy", 45.0))))
+        for child in elem:
+            if child.tag == "body":
+                a = child.attrib
+                new_id = len(self.bodies)
+                self.bodies.append(dict(name=a.get("name", ""), parent=body_id,
+                                        pos=_vec(a.get("pos"), 3, [0, 0, 0]), quat=self.orientation(a),
+                                        jnts=[], geoms=[]))
+                self._body_children(child, new_id, a.get("childclass", childclass))
+
+    def _add_joint(self, elem, body_id, childclass):
+        if elem.tag == "freejoint":
+            a = dict(elem.attrib)
+            a["type"] = "free"
+            a.setdefault("limited", "false")
+            a.setdefault("armature", "0")
+            a.setdefault("damping", "0")
+        else:
+            a = self.defaults.apply(elem, childclass)
+        jtype = JNT_TYPES[a.get("type", "hinge")]
+        limited = a.get("limited", "false") == "true"
+        rng = _vec(a.get("range"), 2, [0, 0])
+        if jtype in (JNT_HINGE,) and self.degree:
+            rng = np.radians(rng)
+        axis = _vec(a.get("axis"), 3, [0, 0, 1])
+        n = np.linalg.norm(axis)
+        axis = axis / n if n > MINVAL else np.array([0.0, 0, 1])
+        j = dict(name=a.get("name", ""), type=jtype, body=body_id, pos=_vec(a.get("pos"), 3, [0, 0, 0]),
+                 axis=axis, limited=limited and jtype != JNT_FREE, range=rng,
+                 margin=float(a.get("margin", 0.0)), armature=float(a.get("armature", 0.0)),
+                 damping=float(a.get("damping", 0.0)), stiffness=float(a.get("stiffness", 0.0)),
+                 ref=float(a.get("ref", 0.0)),
+                 solref=_vec(a.get("solreflimit"), 2, [0.02, 1.0]),
+                 solimp=_vec(a.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]))
+        self.bodies[body_id]["jnts"].append(len(self.joints))
+        self.joints.append(j)
+
+    def _add_geom(self, elem, body_id, childclass):
+        a = self.defaults.apply(elem, childclass)
+        gtype = GEOM_TYPES[a.get("type", "sphere")]
+        size = _vec(a.get("size"), 3, [0, 0, 0])
+        pos = _vec(a.get("pos"), 3, [0, 0, 0])
+        quat = self.orientation(a)
+        if "fromto" in a:
+            ft = _vec(a["fromto"])
+            vec = ft[:3] - ft[3:]
+            length = np.linalg.norm(vec)
+            pos = 0.5 * (ft[:3] + ft[3:])
+            quat = z_to_quat(vec / length)
+            size = np.array([size[0], 0.5 * length, 0.0])
+        g = dict(name=a.get("name", ""), type=gtype, body=body_id, size=size, pos=pos, quat=quat,
+                 friction=_vec(a.get("friction"), 3, [1.0, 0.005, 0.0001]),
+                 density=float(a.get("density", 1000.0)), margin=float(a.get("margin", 0.0)),
+                 gap=float(a.get("gap", 0.0)), condim=int(a.get("condim", 3)),
+                 contype=int(a.get("contype", 1)), conaffinity=int(a.get("conaffinity", 1)),
+                 solref=_vec(a.get("solref"), 2, [0.02, 1.0]),
+                 solimp=_vec(a.get("solimp"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
+                 solmix=float(a.get("solmix", 1.0)),
+                 rgba=_vec(a.get("rgba"), 4, [0.5, 0.5, 0.5, 1.0]),
+                 mass=float(a["mass"]) if "mass" in a else None)
+        self.bodies[body_id]["geoms"].append(len(self.geoms))
+        self.geoms.append(g)
+
+
+def _geom_mass_inertia(g):
+    """Mass and principal inertia (geom frame) of a solid primitive of uniform density."""
+    t, s, rho = g["type"], g["size"], g["density"]
+    if t == GEOM_SPHERE:
+        r = s[0]
+        vol = 4.0 / 3.0 * math.pi * r ** 3
+        unit = np.array([0.4 * r * r] * 3)
+        mass = rho * vol
+        inertia = mass * unit
+    elif t == GEOM_CAPSULE:
+        r, h = s[0], 2.0 * s[1]
+        m_cyl = rho * math.pi * r * r * h
+        m_sph = rho * 4.0 / 3.0 * math.pi * r ** 3
+        mass = m_cyl + m_sph
+        lateral = m_cyl * (3 * r * r + h * h) / 12.0 + m_sph * (0.4 * r * r + 0.25 * h * h + 0.375 * h * r)
+        axial = m_cyl * r * r / 2.0 + m_sph * 0.4 * r * r
+        inertia = np.array([lateral, lateral, axial])
+    elif t == GEOM_BOX:
+        mass = rho * 8.0 * s[0] * s[1] * s[2]
+        inertia = mass / 3.0 * np.array([s[1] ** 2 + s[2] ** 2, s[0] ** 2 + s[2] ** 2, s[0] ** 2 + s[1] ** 2])
+    else:  # plane: no volume
+        return 0.0, np.zeros(3)
+    if g["mass"] is not None and mass > 0:
+        inertia = inertia * (g["mass"] / mass)
+        mass = g["mass"]
+    return mass, inertia
+
+
+def _geom_rbound(g):
+    t, s = g["type"], g["size"]
+    if t == GEOM_SPHERE:
+        return s[0]
+    if t == GEOM_CAPSULE:
+        return s[0] + s[1]
+    if t == GEOM_BOX:
+        return float(np.linalg.norm(s))
+    return 0.0
+
+
+SUPPORTED_PAIRS = {
+    (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_BOX),
+    (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_SPHERE, GEOM_BOX),
+    (GEOM_CAPSULE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX), (GEOM_BOX, GEOM_BOX),
+}
+
+
+def compile_mjcf(xml_path: str, nconmax: int | None = None, njmax: int | None = None) -> Model:
+    with open(xml_path, "r") as fh:
+        text = fh.read()
+    return compile_mjcf_string(text, xml_path=xml_path, nconmax=nconmax, njmax=njmax)
+
+
+def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None) -> Model:
+    c = _Compiler(text)
+    c.walk()
+    m = Model(xml_path=xml_path)
+    A = m.arrays
+    opt = c.root.find("option")
+    opt = opt.attrib if opt is not None else {}
+    m.timestep = float(opt.get("timestep", 0.002))
+    m.gravity = _vec(opt.get("gravity"), 3, [0, 0, -9.81])
+    m.integrator = INT_RK4 if opt.get("integrator", "Euler") == "RK4" else INT_EULER
+    m.iterations = int(opt.get("iterations", 100))
+    m.tolerance = float(opt.get("tolerance", 1e-8))
+    m.impratio = float(opt.get("impratio", 1.0))
+
+    nbody, njnt, ngeom = len(c.bodies), len(c.joints), len(c.geoms)
+    m.nbody, m.njnt, m.ngeom, m.nsite, m.ncam = nbody, njnt, ngeom, len(c.sites), len(c.cams)
+
+    # ---- joints / dofs
+    jnt_qposadr, jnt_dofadr = np.zeros(njnt, np.int32), np.zeros(njnt, np.int32)
+    nq = nv = 0
+    for j, jn in enumerate(c.joints):
+        jnt_qposadr[j], jnt_dofadr[j] = nq, nv
+        nq += 7 if jn["type"] == JNT_FREE else 1
+        nv += 6 if jn["type"] == JNT_FREE else 1
+    m.nq, m.nv = nq, nv
+    A["jnt_type"] = np.array([j["type"] for j in c.joints], np.int32)
+    A["jnt_qposadr"], A["jnt_dofadr"] = jnt_qposadr, jnt_dofadr
+    A["jnt_bodyid"] = np.array([j["body"] for j in c.joints], np.int32)
+    A["jnt_pos"] = np.array([j["pos"] for j in c.joints], np.float64).reshape(njnt, 3)
+    A["jnt_axis"] = np.array([j["axis"] for j in c.joints], np.float64).reshape(njnt, 3)
+    A["jnt_limited"] = np.array([int(j["limited"]) for j in c.joints], np.int32)
+    A["jnt_range"] = np.array([j["range"] for j in c.joints], np.float64).reshape(njnt, 2)
+    A["jnt_margin"] = np.array([j["margin"] for j in c.joints], np.float64)
+    A["jnt_solref"] = np.array([j["solref"] for j in c.joints], np.float64).reshape(njnt, 2)
+    A["jnt_solimp"] = np.array([j["solimp"] for j in c.joints], np.float64).reshape(njnt, 5)
+
+    qpos0 = np.zeros(nq)
+    dof_bodyid, dof_jntid = np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+    dof_armature, dof_damping = np.zeros(nv), np.zeros(nv)
+
+    # ---- bodies
+    body_parentid = np.array([b["parent"] for b in c.bodies], np.int32)
+    body_jntnum = np.array([len(b["jnts"]) for b in c.bodies], np.int32)
+    body_jntadr = np.array([b["jnts"][0] if b["jnts"] else -1 for b in c.bodies], np.int32)
+    body_geomnum = np.array([len(b["geoms"]) for b in c.bodies], np.int32)
+    body_geomadr = np.array([b["geoms"][0] if b["geoms"] else -1 for b in c.bodies], np.int32)
+    body_dofnum, body_dofadr = np.zeros(nbody, np.int32), np.full(nbody, -1, np.int32)
+    body_pos = np.array([b["pos"] for b in c.bodies], np.float64).reshape(nbody, 3)
+    body_quat = np.array([b["quat"] for b in c.bodies], np.float64).reshape(nbody, 4)
+    body_rootid, body_weldid = np.zeros(nbody, np.int32), np.zeros(nbody, np.int32)
+    body_depth = np.zeros(nbody, np.int32)
+    body_lastdof = np.full(nbody, -1, np.int32)   # last dof on the path from the world to this body
+    dof_parentid = np.full(nv, -1, np.int32)
+    for b in range(1, nbody):
+        p = body_parentid[b]
+        body_rootid[b] = b if p == 0 else body_rootid[p]
+        body_depth[b] = body_depth[p] + 1
+        body_weldid[b] = b if body_jntnum[b] > 0 else body_weldid[p]
+        last = body_lastdof[p]
+        for j in c.bodies[b]["jnts"]:
+            jn = c.joints[j]
+            nd = 6 if jn["type"] == JNT_FREE else 1
+            if body_dofadr[b] < 0:
+                body_dofadr[b] = jnt_dofadr[j]
+            body_dofnum[b] += nd
+            for k in range(nd):
+                d = jnt_dofadr[j] + k
+                dof_bodyid[d], dof_jntid[d] = b, j
+                dof_parentid[d] = last
+                dof_armature[d], dof_damping[d] = jn["armature"], jn["damping"]
+                last = d
+            if jn["type"] == JNT_FREE:
+                qa = jnt_qposadr[j]
+                # a free joint's reference pose is the body's frame in its parent (the parent is the world)
+                qpos0[qa:qa + 3] = body_pos[b]
+                qpos0[qa + 3:qa + 7] = body_quat[b]
+            else:
+                qpos0[jnt_qposadr[j]] = jn["ref"]
+        body_lastdof[b] = last
+    A.update(body_parentid=body_parentid, body_rootid=body_rootid, body_weldid=body_weldid,
+             body_jntnum=body_jntnum, body_jntadr=body_jntadr, body_dofnum=body_dofnum,
+             body_dofadr=body_dofadr, body_geomnum=body_geomnum, body_geomadr=body_geomadr,
+             body_pos=body_pos, body_quat=body_quat, body_depth=body_depth, body_lastdof=body_lastdof,
+             dof_bodyid=dof_bodyid, dof_jntid=dof_jntid, dof_parentid=dof_parentid,
+             dof_armature=dof_armature, dof_damping=dof_damping, qpos0=qpos0)
+
+    # kinematic trees: one per child of the world that carries (or whose subtree carries) dofs
+    dof_treeid = np.zeros(nv, np.int32)
+    roots = sorted({int(body_rootid[dof_bodyid[d]]) for d in range(nv)})
+    for d in range(nv):
+        dof_treeid[d] = roots.index(int(body_rootid[dof_bodyid[d]]))
+    m.ntree = len(roots)
+    A["dof_treeid"] = dof_treeid
+    body_treeid = np.full(nbody, -1, np.int32)
+    for b in range(1, nbody):
+        if int(body_rootid[b]) in roots:
+            body_treeid[b] = roots.index(int(body_rootid[b]))
+    A["body_treeid"] = body_treeid
+
+    # sparse inertia addressing: row d holds the diagonal followed by its ancestors, walking up
+    dof_Madr = np.zeros(nv, np.int32)
+    dof_depth = np.zeros(nv, np.int32)
+    nM = 0
+    for d in range(nv):
+        dof_Madr[d] = nM
+        k, n = d, 0
+        while k >= 0:
+            n += 1
+            k = dof_parentid[k]
+        dof_depth[d] = n - 1
+        nM += n
+    m.nM = nM
+    A["dof_Madr"], A["dof_depth"] = dof_Madr, dof_depth
+
+    # ---- geoms
+    A["geom_type"] = np.array([g["type"] for g in c.geoms], np.int32)
+    A["geom_bodyid"] = np.array([g["body"] for g in c.geoms], np.int32)
+    A["geom_size"] = np.array([g["size"] for g in c.geoms], np.float64).reshape(ngeom, 3)
+    A["geom_pos"] = np.array([g["pos"] for g in c.geoms], np.float64).reshape(ngeom, 3)
+    A["geom_quat"] = np.array([g["quat"] for g in c.geoms], np.float64).reshape(ngeom, 4)
+    A["geom_friction"] = np.array([g["friction"] for g in c.geoms], np.float64).reshape(ngeom, 3)
+    A["geom_margin"] = np.array([g["margin"] for g in c.geoms], np.float64)
+    A["geom_gap"] = np.array([g["gap"] for g in c.geoms], np.float64)
+    A["geom_condim"] = np.array([g["condim"] for g in c.geoms], np.int32)
+    A["geom_solref"] = np.array([g["solref"] for g in c.geoms], np.float64).reshape(ngeom, 2)
+    A["geom_solimp"] = np.array([g["solimp"] for g in c.geoms], np.float64).reshape(ngeom, 5)
+    A["geom_solmix"] = np.array([g["solmix"] for g in c.geoms], np.float64)
+    A["geom_rbound"] = np.array([_geom_rbound(g) for g in c.geoms], np.float64)
+    A["geom_rgba"] = np.array([g["rgba"] for g in c.geoms], np.float64).reshape(ngeom, 4)
+
+    # ---- body inertial frames from geoms
+    body_mass, body_ipos = np.zeros(nbody), np.zeros((nbody, 3))
+    body_iquat, body_inertia = np.tile([1.0, 0, 0, 0], (nbody, 1)), np.zeros((nbody, 3))
+    for b in range(1, nbody):
+        parts = []
+        for gi in c.bodies[b]["geoms"]:
+            mass, inertia = _geom_mass_inertia(c.geoms[gi])
+            if mass > 0:
+                parts.append((mass, inertia, c.geoms[gi]["pos"], c.geoms[gi]["quat"]))
+        if not parts:
+            continue
+        if len(parts) == 1:
+            body_mass[b], body_inertia[b], body_ipos[b], body_iquat[b] = parts[0]
+            continue
+        total = sum(p[0] for p in parts)
+        com = sum(p[0] * p[2] for p in parts) / total
+        tensor = np.zeros((3, 3))
+        for mass, inertia, pos, quat in parts:
+            rot = quat_to_mat(quat)
+            d = pos - com
+            tensor += rot @ np.diag(inertia) @ rot.T + mass * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        evals, evecs = np.linalg.eigh(tensor)
+        order = np.argsort(-evals)
+        evals, evecs = evals[order], evecs[:, order]
+        if np.linalg.det(evecs) < 0:
+            evecs[:, 2] = -evecs[:, 2]
+        body_mass[b], body_ipos[b], body_inertia[b], body_iquat[b] = total, com, evals, mat_to_quat(evecs)
+    body_subtreemass = body_mass.copy()
+    for b in range(nbody - 1, 0, -1):
+        body_subtreemass[body_parentid[b]] += body_subtreemass[b]
+    A.update(body_mass=body_mass, body_ipos=body_ipos, body_iquat=body_iquat, body_inertia=body_inertia,
+             body_subtreemass=body_subtreemass)
+
+    # ---- sites, cameras
+    ns, nc = m.nsite, m.ncam
+    A["site_bodyid"] = np.array([s["body"] for s in c.sites], np.int32)
+    A["site_pos"] = np.array([s["pos"] for s in c.sites], np.float64).reshape(ns, 3)
+    A["site_quat"] = np.array([s["quat"] for s in c.sites], np.float64).reshape(ns, 4)
+    A["site_size"] = np.array([s["size"] for s in c.sites], np.float64).reshape(ns, 3)
+    A["cam_bodyid"] = np.array([s["body"] for s in c.cams], np.int32)
+    A["cam_pos"] = np.array([s["pos"] for s in c.cams], np.float64).reshape(nc, 3)
+    A["cam_quat"] = np.array([s["quat"] for s in c.cams], np.float64).reshape(nc, 4)
+    A["cam_fovy"] = np.array([s["fovy"] for s in c.cams], np.float64)
+
+    m.names = dict(body=[b["name"] for b in c.bodies], joint=[j["name"] for j in c.joints],
+                   geom=[g["name"] for g in c.geoms], site=[s["name"] for s in c.sites],
+                   camera=[s["name"] for s in c.cams], actuator=[], sensor=[])
+
+    # ---- actuators (motors)
+    act = c.root.find("actuator")
+    motors = []
+    if act is not None:
+        for el in act:
+            a = c.defaults.apply(el, None)
+            if el.tag not in ("motor", "general"):
+                raise ValueError(f"actuator <{el.tag}> is outside the supported MJCF subset")
+            jid = m.names["joint"].index(a["joint"])
+            gear = _vec(a.get("gear"), 6, [1, 0, 0, 0, 0, 0])
+            motors.append(dict(name=a.get("name", ""), dof=int(jnt_dofadr[jid]), jnt=jid, gear=gear[0],
+                               limited=a.get("ctrllimited", "false") == "true",
+                               range=_vec(a.get("ctrlrange"), 2, [0, 0])))
+    m.nu = len(motors)
+    A["act_dofid"] = np.array([a["dof"] for a in motors], np.int32)
+    A["act_jntid"] = np.array([a["jnt"] for a in motors], np.int32)
+    A["act_gear"] = np.array([a["gear"] for a in motors], np.float64)
+    A["act_ctrllimited"] = np.array([int(a["limited"]) for a in motors], np.int32)
+    A["act_ctrlrange"] = np.array([a["range"] for a in motors], np.float64).reshape(m.nu, 2)
+    m.names["actuator"] = [a["name"] for a in motors]
+
+    # ---- sensors (the subset the levels use; all are attached to a site)
+    sens = c.root.find("sensor")
+    s_type, s_objid, s_dim, s_adr, s_cutoff = [], [], [], [], []
+    adr = 0
+    if sens is not None:
+        for el in sens:
+            if el.tag not in SENSOR_TYPES:
+                raise ValueError(f"sensor <{el.tag}> is outside the supported MJCF subset")
+            stype, dim = SENSOR_TYPES[el.tag]
+            site_name = el.attrib.get("site", el.attrib.get("objname"))
+            if el.tag.startswith("frame") and el.attrib.get("objtype", "site") != "site":
+                raise ValueError("frame sensors are supported on sites only")
+            s_type.append(stype)
+            s_objid.append(m.names["site"].index(site_name))
+            s_dim.append(dim)
+            s_adr.append(adr)
+            s_cutoff.append(float(el.attrib.get("cutoff", 0.0)))
+            m.names["sensor"].append(el.attrib.get("name", ""))
+            adr += dim
+    m.nsensor, m.nsensordata = len(s_type), adr
+    A["sensor_type"] = np.array(s_type, np.int32)
+    A["sensor_objid"] = np.array(s_objid, np.int32)
+    A["sensor_dim"] = np.array(s_dim, np.int32)
+    A["sensor_adr"] = np.array(s_adr, np.int32)
+    A["sensor_cutoff"] = np.array(s_cutoff, np.float64)
+
+    # ---- candidate collision pairs (static filter), ordered by (geom1, geom2) before type swap
+    pairs = []
+    gt, gb = A["geom_type"], A["geom_bodyid"]
+    for g1 in range(ngeom):
+        for g2 in range(g1 + 1, ngeom):
+            b1, b2 = gb[g1], gb[g2]
+            if b1 == b2:
+                continue
+            g_a, g_b = c.geoms[g1], c.geoms[g2]
+            if not ((g_a["contype"] & g_b["conaffinity"]) or (g_b["contype"] & g_a["conaffinity"])):
+                continue
+            w1, w2 = body_weldid[b1], body_weldid[b2]
+            if w1 == w2:
+                continue
+            wp1, wp2 = body_weldid[body_parentid[w1]], body_weldid[body_parentid[w2]]
+            if w1 != 0 and w2 != 0 and (w1 == wp2 or w2 == wp1):
+                continue
+            a, b = (g1, g2) if gt[g1] <= gt[g2] else (g2, g1)
+            if (int(gt[a]), int(gt[b])) not in SUPPORTED_PAIRS:
+                raise ValueError(f"collision pair types {gt[a]},{gt[b]} are outside the supported subset")
+            pairs.append((a, b))
+    m.npair = len(pairs)
+    A["pair_geom"] = np.array(pairs, np.int32).reshape(m.npair, 2)
+
+    if nconmax is not None:
+        m.nconmax = int(nconmax)
+    if njmax is not None:
+        m.njmax = int(njmax)
+
+    _set_const(m)
+    return m
+
+
+# ----------------------------------------------------------------------------- constants at qpos0
+def kinematics_numpy(m: Model, qpos):
+    """Body frames (xpos, xquat) for ``qpos`` -- plain numpy, used for the qpos0 constants only."""
+    nb = m.nbody
+    xpos, xquat = np.zeros((nb, 3)), np.tile([1.0, 0, 0, 0], (nb, 1))
+    for b in range(1, nb):
+        p = m.body_parentid[b]
+        rot_p = quat_to_mat(xquat[p])
+        pos = xpos[p] + rot_p @ m.body_pos[b]
+        quat = quat_mul(xquat[p], m.body_quat[b])
+        for k in range(m.body_jntnum[b]):
+            j = m.body_jntadr[b] + k
+            qa = m.jnt_qposadr[j]
+            if m.jnt_type[j] == JNT_FREE:
+                pos = np.array(qpos[qa:qa + 3])
+                quat = np.array(qpos[qa + 3:qa + 7])
+                quat = quat / np.linalg.norm(quat)
+            else:
+                anchor = pos + quat_to_mat(quat) @ m.jnt_pos[j]
+                if m.jnt_type[j] == JNT_HINGE:
+                    quat = quat_mul(quat, axis_angle_quat(m.jnt_axis[j], qpos[qa] - m.qpos0[qa]))
+                    pos = anchor - quat_to_mat(quat) @ m.jnt_pos[j]
+                else:
+                    pos = pos + quat_to_mat(quat) @ m.jnt_axis[j] * (qpos[qa] - m.qpos0[qa])
+        xpos[b], xquat[b] = pos, quat / np.linalg.norm(quat)
+    return xpos, xquat
+
+
+def body_jacobian_numpy(m: Model, xpos, xquat, body, point):
+    """6 x nv Jacobian (translational rows first) of ``point`` moving with ``body``."""
+    jac = np.zeros((6, m.nv))
+    d = m.body_lastdof[body]
+    while d >= 0:
+        b, j = m.dof_bodyid[d], m.dof_jntid[d]
+        rot = quat_to_mat(xquat[b])
+        if m.jnt_type[j] == JNT_FREE:
+            k = d - m.jnt_dofadr[j]
+            if k < 3:
+                jac[k, d] = 1.0
+            else:
+                axis = rot[:, k - 3]
+                jac[3:, d] = axis
+                jac[:3, d] = np.cross(axis, point - xpos[b])
+        else:
+            axis = rot @ m.jnt_axis[j]
+            if m.jnt_type[j] == JNT_HINGE:
+                anchor = xpos[b] + rot @ m.jnt_pos[j]
+                jac[3:, d] = axis
+                jac[:3, d] = np.cross(axis, point - anchor)
+            else:
+                jac[:3, d] = axis
+        d = m.dof_parentid[d]
+    return jac
+
+
+def mass_matrix_numpy(m: Model, qpos):
+    xpos, xquat = kinematics_numpy(m, qpos)
+    M = np.diag(m.dof_armature.astype(np.float64))
+    for b in range(1, m.nbody):
+        if m.body_mass[b] <= 0 or m.body_lastdof[b] < 0:
+            continue
+        rot = quat_to_mat(xquat[b])
+        com = xpos[b] + rot @ m.body_ipos[b]
+        jac = body_jacobian_numpy(m, xpos, xquat, b, com)
+        irot = rot @ quat_to_mat(m.body_iquat[b])
+        inertia_w = irot @ np.diag(m.body_inertia[b]) @ irot.T
+        M += m.body_mass[b] * jac[:3].T @ jac[:3] + jac[3:].T @ inertia_w @ jac[3:]
+    return M, xpos, xquat
+
+
+def _set_const(m: Model):
+    """``body_invweight0``, ``dof_invweight0``, ``meaninertia`` at ``qpos0``."""
+    A = m.arrays
+    inv_b = np.zeros((m.nbody, 2))
+    inv_d = np.zeros(m.nv)
+    if m.nv:
+        M, xpos, xquat = mass_matrix_numpy(m, m.qpos0)
+        Minv = np.linalg.inv(M)
+        m.meaninertia = float(np.mean(np.diag(M)))
+        for b in range(1, m.nbody):
+            if m.body_lastdof[b] < 0:
+                continue
+            com = xpos[b] + quat_to_mat(xquat[b]) @ m.body_ipos[b]
+            jac = body_jacobian_numpy(m, xpos, xquat, b, com)
+            a = jac @ Minv @ jac.T
+            inv_b[b, 0] = (a[0, 0] + a[1, 1] + a[2, 2]) / 3.0
+            inv_b[b, 1] = (a[3, 3] + a[4, 4] + a[5, 5]) / 3.0
+        for j in range(m.njnt):
+            d = m.jnt_dofadr[j]
+            if m.jnt_type[j] == JNT_FREE:
+                inv_d[d:d + 3] = np.mean(np.diag(Minv)[d:d + 3])
+                inv_d[d + 3:d + 6] = np.mean(np.diag(Minv)[d + 3:d + 6])
+            else:
+                inv_d[d] = Minv[d, d]
+    A["body_invweight0"] = inv_b
+    A["dof_invweight0"] = inv_d
