@@ -1,0 +1,101 @@
+/* C-ABI of the MI355X batched env stepper (libmjrl_hip.so).
+ *
+ * This is the drop-in boundary for the reference's step path.  The reference is pure Python and
+ * crosses into native code through the `mujoco` bindings; the entry points below are what a
+ * ctypes binding for that path needs, each citing the reference call it
+ * replaces.  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Threading: a handle is NOT thread-safe; use one handle per GPU (one process per GPU).
+ * Ownership: the library owns all device buffers and the uploaded model; callers own every buffer
+ * they pass.  Every entry returns 0 on success, non-zero on error; mjrl_last_error() explains.
+ * Pointers named d_* are DEVICE pointers (HBM), h_* are host pointers.
+ */
+#ifndef MJRL_H
+#define MJRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mjrl_env mjrl_env;
+
+/* library / blob-layout version string */
+const char* mjrl_version(void);
+
+/* last error of a handle; pass NULL for the error of a failed mjrl_create */
+const char* mjrl_last_error(const mjrl_env* env);
+
+/* Upload a compiled model (blob.py layout) and allocate state for n_env copies on device_id.
+ * Replaces: mj.MjModel.from_xml_path + mj.MjData (mujoco_parent.py:126-127), once per copy.
+ * All copies start at qpos0 with zero velocity (as after mj_resetData, mujoco_parent.py:349). */
+int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out);
+void mjrl_destroy(mjrl_env* env);
+
+/* Launch on a caller-provided HIP stream (hipStream_t passed as void*); NULL = the handle's own. */
+int mjrl_set_stream(mjrl_env* env, void* hip_stream);
+/* Wait for everything queued on the handle's stream. */
+int mjrl_sync(mjrl_env* env);
+
+/* Observation gather table.  Replaces the table built by get_observation_space_mujoco
+ * (mujoco_parent.py:233-272) and consumed by get_observations (mujoco_parent.py:380-392):
+ * for each agent, sensordata addresses, then qpos indices, then qvel indices; counts are per agent,
+ * index arrays are the per-agent lists concatenated. */
+int mjrl_set_gather_tables(mjrl_env* env, int n_agent, const int32_t* n_sensor, const int32_t* sensor_idx,
+                           const int32_t* n_qpos, const int32_t* qpos_idx, const int32_t* n_qvel,
+                           const int32_t* qvel_idx);
+/* Action scatter table.  Replaces agents_action_index (mujoco_parent.py:274-314) as used by apply_action
+ * (mujoco_parent.py:323-332): mode 0 writes ctrl[idx], mode 1 overwrites qvel[idx] (freeJoint).
+ * Action slots beyond n_idx[agent] are not routed to the physics (dynamics-plugin slots). */
+int mjrl_set_scatter_tables(mjrl_env* env, int n_agent, int mode, const int32_t* n_idx, const int32_t* idx);
+int mjrl_set_max_steps(mjrl_env* env, int max_steps);   /* truncation horizon, mujoco_rl.py:59,412 */
+
+/* Sizes a caller needs to allocate buffers: "nq","nv","nu","nbody","ngeom","nsensordata","obs_dim",
+ * "n_agent","n_env","lds_doubles","ncon_stride", ...; -1 for an unknown name. */
+int mjrl_size(const mjrl_env* env, const char* name);
+
+/* Reset copies to qpos0 / zero velocity / zero ctrl / zero warm start / timestep 0.
+ * Replaces mj_resetData (mujoco_parent.py:349); mask is a host array [n_env] of 0/1, NULL = all.
+ * If d_obs is non-NULL the post-reset observations (mj_forward sensordata | qpos | qvel,
+ * mujoco_parent.py:350 + mujoco_rl.py:314) are written there. */
+int mjrl_reset(mjrl_env* env, const uint8_t* h_mask, double* d_obs);
+
+/* One step() of every copy: scatter actions, skip_frames physics steps, gather observations.
+ * Replaces apply_action + mj_step loop (mujoco_parent.py:316-336) and get_observations (:380-392),
+ * plus the zero-initialised rewards / terminations and the truncation flag of MuJoCoRL.step
+ * (mujoco_rl.py:262-263, 279).  All pointers are device pointers and may be NULL except d_actions
+ * when a scatter table is set.  Asynchronous on the handle's stream.
+ *   d_actions [n_env][n_agent][act_dim]   d_obs   [n_env][n_agent][obs_dim]
+ *   d_reward  [n_env][n_agent]            d_term / d_trunc [n_env][n_agent] (bytes) */
+int mjrl_step_device(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames, double* d_obs,
+                     double* d_reward, uint8_t* d_term, uint8_t* d_trunc);
+/* Same with host buffers (PCIe copies in and out, synchronous). */
+int mjrl_step_host(mjrl_env* env, const double* h_actions, int act_dim, int skip_frames, double* h_obs,
+                   double* h_reward, uint8_t* h_term, uint8_t* h_trunc);
+
+/* State access for parity tests and host-side plugins (synchronous, host buffers [n_env][n]).
+ * Fields: "qpos","qvel","ctrl","qacc_warmstart","sensordata","timestep"(int32). */
+int mjrl_get_field(mjrl_env* env, const char* name, void* h_out, size_t nbytes);
+int mjrl_set_field(mjrl_env* env, const char* name, const void* h_in, size_t nbytes);
+
+/* Derived quantities of the CURRENT state for host-side plugins (get_data / distance / collision,
+ * mujoco_parent.py:394-478): runs the position stage + collision for every copy and returns
+ *   "xpos" [n_env][nbody][3]  "xquat" [n_env][nbody][4]  "xipos" [n_env][nbody][3]
+ *   "geom_xpos" [n_env][ngeom][3]  "geom_xmat" [n_env][ngeom][9]
+ *   "ncon" [n_env] (as double)  "contact_geom" [n_env][nconmax][2] (as double, -1 padded). */
+int mjrl_query(mjrl_env* env, const char* name, double* h_out, size_t nbytes);
+
+/* Debug: step once like mjrl_step_device and also dump every copy's LDS image
+ * ([n_env][lds_doubles] doubles; stage 0 = end of the forward pass, 1 = after the row build).
+ * mjrl_lds_offset gives the offset of a named region inside one image. */
+int mjrl_step_debug(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames, int stage,
+                    double* h_dump, size_t nbytes);
+int mjrl_lds_offset(const mjrl_env* env, const char* region);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

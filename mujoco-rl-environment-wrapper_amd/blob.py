@@ -18,11 +18,11 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 3
+VERSION = 5
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
-               "reserved0", "reserved1"]
+               "ndesc", "nchild", "maxdofdepth", "pair_kmax"]
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
@@ -56,6 +56,8 @@ I32_FIELDS = [
     ("act_dofid", "nu"), ("act_ctrllimited", "nu"),
     ("sensor_type", "nsensor"), ("sensor_objid", "nsensor"), ("sensor_dim", "nsensor"), ("sensor_adr", "nsensor"),
     ("pair_geom", "npair*2"),
+    ("M_rowid", "nM"), ("M_colid", "nM"), ("dof_descadr", "nv"), ("dof_descnum", "nv"), ("desc_Madr", "ndesc"),
+    ("body_childadr", "nbody"), ("body_childnum", "nbody"), ("body_childid", "nchild"), ("tree_rootbody", "ntree"),
 ]
 
 
@@ -63,7 +65,12 @@ def _sizes(model) -> dict:
     s = {k: int(getattr(model, k)) for k in SIZE_FIELDS if hasattr(model, k) and not k.startswith("reserved")
          and k != "maxdepth"}
     s["maxdepth"] = int(model.body_depth.max()) if model.nbody else 0
-    s["reserved0"] = s["reserved1"] = 0
+    # narrow-phase work items one candidate pair can need (plane-box 8, capsule-capsule 4, capsule ends 2)
+    kmax = 1
+    for g1, g2 in model.pair_geom:
+        t = (int(model.geom_type[g1]), int(model.geom_type[g2]))
+        kmax = max(kmax, {(0, 3): 2, (0, 6): 8, (3, 3): 4, (3, 6): 2}.get(t, 1))
+    s["pair_kmax"] = kmax
     return s
 
 

@@ -1,0 +1,429 @@
+// libmjrl_hip.so: kernels + the C-ABI declared in include/mjrl.h.
+// One workgroup = one 64-lane wavefront = one env copy; the env's working set lives in dynamic LDS.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mjrl.h"
+#include "mjrl_step.h"
+
+namespace {
+
+__global__ __launch_bounds__(64) void mjrl_step_kernel(DevModel m, mj::StepArgs a) {
+  extern __shared__ double lds[];
+  mj::env_step(m, a, lds);
+}
+
+// masked reset of the HBM state (mj_resetData for the selected copies)
+__global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double* ctrl, double* warm, int* timestep,
+                                  const unsigned char* mask, int n_env) {
+  int env = blockIdx.x;
+  if (env >= n_env || (mask && !mask[env])) return;
+  for (int i = threadIdx.x; i < m.nq; i += blockDim.x) qpos[(size_t)env * m.nq + i] = m.qpos0[i];
+  for (int i = threadIdx.x; i < m.nv; i += blockDim.x) { qvel[(size_t)env * m.nv + i] = 0; warm[(size_t)env * m.nv + i] = 0; }
+  for (int i = threadIdx.x; i < m.nu; i += blockDim.x) ctrl[(size_t)env * m.nu + i] = 0;
+  if (threadIdx.x == 0) timestep[env] = 0;
+}
+
+std::string g_create_error;
+
+}  // namespace
+
+struct mjrl_env {
+  std::vector<char> h_blob;
+  DevModel hm{}, dm{};
+  mj::Lay lay{};
+  void* d_blob = nullptr;
+  int n_env = 0, device = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
+  int* timestep = nullptr;
+  unsigned char* d_mask = nullptr;
+  // tables
+  int n_agent = 0, obs_dim = 0, scatter_mode = 0, max_steps = 1024;
+  std::vector<int32_t> h_gather;                 // [n_agent][obs_dim]
+  std::vector<std::vector<int32_t>> h_scatter;   // per agent
+  int32_t *d_gather = nullptr, *d_scatter = nullptr;
+  int scatter_act_dim = -1;
+  // staging for the host-buffer entry points
+  double *s_act = nullptr, *s_obs = nullptr, *s_rew = nullptr;
+  unsigned char *s_term = nullptr, *s_trunc = nullptr;
+  size_t s_act_n = 0, s_obs_n = 0;
+  std::string err;
+};
+
+#define MJRL_FAIL(env, code, ...)                              \
+  do {                                                         \
+    char buf_[512];                                            \
+    snprintf(buf_, sizeof(buf_), __VA_ARGS__);                 \
+    (env)->err = buf_;                                         \
+    return (code);                                             \
+  } while (0)
+
+#define MJRL_HIP(env, call)                                                                    \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) MJRL_FAIL(env, 100 + (int)e_, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" {
+
+const char* mjrl_version(void) { return "mjrl-hip 0.1 (blob layout 5, gfx950)"; }
+
+const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
+
+void mjrl_destroy(mjrl_env* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  void* ptrs[] = {e->d_blob, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+                  e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+static int launch_reset(mjrl_env* e, const unsigned char* d_mask) {
+  hipLaunchKernelGGL(mjrl_reset_kernel, dim3(e->n_env), dim3(64), 0, e->stream, e->dm, e->qpos, e->qvel, e->ctrl, e->warm,
+                     e->timestep, d_mask, e->n_env);
+  MJRL_HIP(e, hipGetLastError());
+  return 0;
+}
+
+int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out) {
+  (void)flags;
+  if (!blob || !out || n_env <= 0) { g_create_error = "mjrl_create: bad arguments"; return 1; }
+  mjrl_env* e = new mjrl_env();
+  auto fail = [&](int code, const std::string& msg) { g_create_error = msg; mjrl_destroy(e); return code; };
+  e->h_blob.assign((const char*)blob, (const char*)blob + nbytes);
+  int rc = mjrl_model_from_blob(&e->hm, e->h_blob.data(), nbytes, e->h_blob.data());
+  if (rc) return fail(2, "mjrl_create: model blob rejected (magic/version/size), code " + std::to_string(rc));
+  const DevModel& m = e->hm;
+  if (m.nbody > 64 * 4 || m.nv > 64 || m.nv < 1) return fail(3, "mjrl_create: needs 1 <= nv <= 64 (one dof per lane)");
+  if (m.maxdofdepth + 1 > mj::MAX_DOF_DEPTH) return fail(3, "mjrl_create: kinematic chains deeper than 8 dofs are not supported");
+  if (m.nconmax > 64 || m.nconmax < 1) return fail(3, "mjrl_create: nconmax must be in 1..64");
+  if (m.pair_kmax != 1 && m.pair_kmax != 2 && m.pair_kmax != 4 && m.pair_kmax != 8) return fail(3, "mjrl_create: bad pair_kmax");
+  if (m.integrator != 0) return fail(3, "mjrl_create: only the Euler integrator is implemented");
+  mj::make_layout(m, e->lay);
+  size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
+  if (lds_bytes > 160 * 1024) return fail(3, "mjrl_create: env working set exceeds the 160 KiB LDS of a CU");
+  e->n_env = n_env;
+  e->device = device_id;
+  hipError_t he = hipSetDevice(device_id);
+  if (he != hipSuccess) return fail(4, std::string("hipSetDevice: ") + hipGetErrorString(he));
+#define CK(call) do { he = (call); if (he != hipSuccess) return fail(5, std::string(#call ": ") + hipGetErrorString(he)); } while (0)
+  CK(hipStreamCreate(&e->own_stream));
+  e->stream = e->own_stream;
+  CK(hipMalloc(&e->d_blob, nbytes));
+  CK(hipMemcpy(e->d_blob, blob, nbytes, hipMemcpyHostToDevice));
+  mjrl_model_from_blob(&e->dm, e->h_blob.data(), nbytes, e->d_blob);
+  CK(hipMalloc(&e->qpos, sizeof(double) * n_env * m.nq));
+  CK(hipMalloc(&e->qvel, sizeof(double) * n_env * m.nv));
+  CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
+  CK(hipMalloc(&e->warm, sizeof(double) * n_env * m.nv));
+  CK(hipMalloc(&e->sens, sizeof(double) * n_env * (m.nsensordata > 0 ? m.nsensordata : 1)));
+  CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
+  CK(hipMalloc(&e->d_mask, n_env));
+  CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+#undef CK
+  if (launch_reset(e, nullptr)) return fail(6, e->err);
+  he = hipStreamSynchronize(e->stream);
+  if (he != hipSuccess) return fail(6, std::string("reset: ") + hipGetErrorString(he));
+  *out = e;
+  return 0;
+}
+
+int mjrl_set_stream(mjrl_env* e, void* hip_stream) {
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return 0;
+}
+
+int mjrl_sync(mjrl_env* e) {
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int mjrl_set_max_steps(mjrl_env* e, int max_steps) { e->max_steps = max_steps; return 0; }
+
+int mjrl_set_gather_tables(mjrl_env* e, int n_agent, const int32_t* n_sensor, const int32_t* sensor_idx,
+                           const int32_t* n_qpos, const int32_t* qpos_idx, const int32_t* n_qvel,
+                           const int32_t* qvel_idx) {
+  if (n_agent <= 0) MJRL_FAIL(e, 1, "set_gather_tables: n_agent must be positive");
+  if (e->n_agent && e->n_agent != n_agent) MJRL_FAIL(e, 1, "set_gather_tables: agent count differs from the scatter table's");
+  const DevModel& m = e->hm;
+  int dim = 0;
+  for (int a = 0; a < n_agent; a++) dim = std::max(dim, n_sensor[a] + n_qpos[a] + n_qvel[a]);
+  std::vector<int32_t> table((size_t)n_agent * dim, -1);
+  int so = 0, po = 0, vo = 0;
+  for (int a = 0; a < n_agent; a++) {
+    int k = 0;
+    for (int i = 0; i < n_sensor[a]; i++) {
+      int idx = sensor_idx[so++];
+      if (idx < 0 || idx >= m.nsensordata) MJRL_FAIL(e, 2, "set_gather_tables: sensordata index %d out of range", idx);
+      table[(size_t)a * dim + k++] = (0 << 24) | idx;
+    }
+    for (int i = 0; i < n_qpos[a]; i++) {
+      int idx = qpos_idx[po++];
+      if (idx < 0 || idx >= m.nq) MJRL_FAIL(e, 2, "set_gather_tables: qpos index %d out of range", idx);
+      table[(size_t)a * dim + k++] = (1 << 24) | idx;
+    }
+    for (int i = 0; i < n_qvel[a]; i++) {
+      int idx = qvel_idx[vo++];
+      if (idx < 0 || idx >= m.nv) MJRL_FAIL(e, 2, "set_gather_tables: qvel index %d out of range", idx);
+      table[(size_t)a * dim + k++] = (2 << 24) | idx;
+    }
+  }
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->d_gather) { hipFree(e->d_gather); e->d_gather = nullptr; }
+  MJRL_HIP(e, hipMalloc(&e->d_gather, sizeof(int32_t) * std::max<size_t>(table.size(), 1)));
+  MJRL_HIP(e, hipMemcpy(e->d_gather, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice));
+  e->h_gather = table;
+  e->n_agent = n_agent;
+  e->obs_dim = dim;
+  return 0;
+}
+
+int mjrl_set_scatter_tables(mjrl_env* e, int n_agent, int mode, const int32_t* n_idx, const int32_t* idx) {
+  if (n_agent <= 0) MJRL_FAIL(e, 1, "set_scatter_tables: n_agent must be positive");
+  if (e->n_agent && e->n_agent != n_agent) MJRL_FAIL(e, 1, "set_scatter_tables: agent count differs from the gather table's");
+  const DevModel& m = e->hm;
+  int limit = mode == 0 ? m.nu : m.nv;
+  std::vector<std::vector<int32_t>> lists(n_agent);
+  int o = 0;
+  for (int a = 0; a < n_agent; a++)
+    for (int i = 0; i < n_idx[a]; i++) {
+      int v = idx[o++];
+      if (v < 0 || v >= limit) MJRL_FAIL(e, 2, "set_scatter_tables: index %d out of range for mode %d", v, mode);
+      lists[a].push_back(v);
+    }
+  e->h_scatter = lists;
+  e->scatter_mode = mode;
+  e->scatter_act_dim = -1;
+  e->n_agent = n_agent;
+  return 0;
+}
+
+int mjrl_size(const mjrl_env* e, const char* name) {
+#define X(field) if (strcmp(name, #field) == 0) return e->hm.field;
+  MJRL_SIZE_FIELDS(X)
+#undef X
+  if (!strcmp(name, "obs_dim")) return e->obs_dim;
+  if (!strcmp(name, "n_agent")) return e->n_agent;
+  if (!strcmp(name, "n_env")) return e->n_env;
+  if (!strcmp(name, "lds_doubles")) return e->lay.total;
+  if (!strcmp(name, "con_stride")) return mj::CON_STRIDE;
+  if (!strcmp(name, "row_stride")) return mj::ROW_STRIDE;
+  if (!strcmp(name, "ldj")) return e->lay.ldj;
+  return -1;
+}
+
+int mjrl_lds_offset(const mjrl_env* e, const char* region) {
+  const mj::Lay& l = e->lay;
+#define R(name) if (!strcmp(region, #name)) return l.name;
+  R(qpos) R(qvel) R(ctrl) R(warm) R(xpos) R(xquat) R(xanchor) R(xaxis) R(com) R(cinert) R(crb) R(cdof) R(cdofdot)
+  R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gmat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
+  R(sens) R(ints) R(total) R(i_cand) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid)
+#undef R
+  return -1;
+}
+
+static int ensure_scatter(mjrl_env* e, int act_dim) {
+  if (e->h_scatter.empty() || e->scatter_act_dim == act_dim) return 0;
+  std::vector<int32_t> table((size_t)e->n_agent * act_dim, -1);
+  for (int a = 0; a < e->n_agent; a++) {
+    if ((int)e->h_scatter[a].size() > act_dim)
+      MJRL_FAIL(e, 3, "step: agent %d routes %d action slots to the physics but act_dim is %d", a,
+                (int)e->h_scatter[a].size(), act_dim);
+    for (size_t k = 0; k < e->h_scatter[a].size(); k++) table[(size_t)a * act_dim + k] = e->h_scatter[a][k];
+  }
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->d_scatter) { hipFree(e->d_scatter); e->d_scatter = nullptr; }
+  MJRL_HIP(e, hipMalloc(&e->d_scatter, sizeof(int32_t) * std::max<size_t>(table.size(), 1)));
+  MJRL_HIP(e, hipMemcpy(e->d_scatter, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice));
+  e->scatter_act_dim = act_dim;
+  return 0;
+}
+
+// mode: 0 = full step; 1 = forward pass only (no integration, no counters): reset observations and queries
+static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
+                       uint8_t* d_term, uint8_t* d_trunc, double* d_dbg, int dbg_stage, int forward_only) {
+  if (skip_frames < 0) MJRL_FAIL(e, 3, "step: skip_frames must be >= 0");
+  if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "step: observations requested but no gather table is set");
+  mj::StepArgs a{};
+  a.qpos = e->qpos; a.qvel = e->qvel; a.ctrl = e->ctrl; a.warm = e->warm; a.sensordata = e->sens;
+  a.timestep = e->timestep;
+  a.actions = nullptr; a.scatter = nullptr;
+  a.n_agent = e->n_agent; a.act_dim = act_dim; a.scatter_mode = e->scatter_mode;
+  if (d_actions && !e->h_scatter.empty()) {
+    if (int rc = ensure_scatter(e, act_dim)) return rc;
+    a.actions = d_actions;
+    a.scatter = e->d_scatter;
+  }
+  a.gather = e->d_gather; a.obs_dim = e->obs_dim; a.obs = d_obs;
+  a.reward = d_reward; a.term = d_term; a.trunc = d_trunc;
+  a.max_steps = e->max_steps; a.skip_frames = skip_frames; a.n_env = e->n_env;
+  a.dbg = d_dbg; a.dbg_stage = dbg_stage;
+  a.forward_only = forward_only;
+  size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
+  hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, a);
+  MJRL_HIP(e, hipGetLastError());
+  return 0;
+}
+
+int mjrl_step_device(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
+                     uint8_t* d_term, uint8_t* d_trunc) {
+  return launch_step(e, d_actions, act_dim, skip_frames, d_obs, d_reward, d_term, d_trunc, nullptr, 0, 0);
+}
+
+static int ensure_staging(mjrl_env* e, int act_dim) {
+  size_t act_n = (size_t)e->n_env * std::max(e->n_agent, 1) * std::max(act_dim, 1);
+  size_t obs_n = (size_t)e->n_env * std::max(e->n_agent, 1) * std::max(e->obs_dim, 1);
+  if (act_n > e->s_act_n) {
+    if (e->s_act) hipFree(e->s_act);
+    MJRL_HIP(e, hipMalloc(&e->s_act, sizeof(double) * act_n));
+    e->s_act_n = act_n;
+  }
+  if (obs_n > e->s_obs_n) {
+    if (e->s_obs) hipFree(e->s_obs);
+    MJRL_HIP(e, hipMalloc(&e->s_obs, sizeof(double) * obs_n));
+    e->s_obs_n = obs_n;
+  }
+  size_t na = (size_t)e->n_env * std::max(e->n_agent, 1);
+  if (!e->s_rew) {
+    MJRL_HIP(e, hipMalloc(&e->s_rew, sizeof(double) * na));
+    MJRL_HIP(e, hipMalloc(&e->s_term, na));
+    MJRL_HIP(e, hipMalloc(&e->s_trunc, na));
+  }
+  return 0;
+}
+
+int mjrl_step_host(mjrl_env* e, const double* h_actions, int act_dim, int skip_frames, double* h_obs, double* h_reward,
+                   uint8_t* h_term, uint8_t* h_trunc) {
+  if (int rc = ensure_staging(e, act_dim)) return rc;
+  size_t na = (size_t)e->n_env * std::max(e->n_agent, 1);
+  if (h_actions)
+    MJRL_HIP(e, hipMemcpyAsync(e->s_act, h_actions, sizeof(double) * na * act_dim, hipMemcpyHostToDevice, e->stream));
+  int rc = launch_step(e, h_actions ? e->s_act : nullptr, act_dim, skip_frames, (h_obs && e->d_gather) ? e->s_obs : nullptr,
+                       e->s_rew, e->s_term, e->s_trunc, nullptr, 0, 0);
+  if (rc) return rc;
+  if (h_obs && e->d_gather)
+    MJRL_HIP(e, hipMemcpyAsync(h_obs, e->s_obs, sizeof(double) * na * e->obs_dim, hipMemcpyDeviceToHost, e->stream));
+  if (h_reward) MJRL_HIP(e, hipMemcpyAsync(h_reward, e->s_rew, sizeof(double) * na, hipMemcpyDeviceToHost, e->stream));
+  if (h_term) MJRL_HIP(e, hipMemcpyAsync(h_term, e->s_term, na, hipMemcpyDeviceToHost, e->stream));
+  if (h_trunc) MJRL_HIP(e, hipMemcpyAsync(h_trunc, e->s_trunc, na, hipMemcpyDeviceToHost, e->stream));
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int mjrl_reset(mjrl_env* e, const uint8_t* h_mask, double* d_obs) {
+  const unsigned char* d_mask = nullptr;
+  if (h_mask) {
+    MJRL_HIP(e, hipMemcpyAsync(e->d_mask, h_mask, e->n_env, hipMemcpyHostToDevice, e->stream));
+    d_mask = e->d_mask;
+  }
+  if (int rc = launch_reset(e, d_mask)) return rc;
+  // mj_forward after the reset (mujoco_parent.py:350): refreshes sensordata and the warm start of every copy
+  // (a forward pass on an un-reset copy recomputes the same values it already holds)
+  return launch_step(e, nullptr, 0, 1, d_obs, nullptr, nullptr, nullptr, nullptr, 0, 1);
+}
+
+struct field_ref { void* ptr; size_t bytes; };
+static int find_field(mjrl_env* e, const char* name, field_ref* f) {
+  const DevModel& m = e->hm;
+  size_t n = e->n_env;
+  if (!strcmp(name, "qpos")) *f = {e->qpos, sizeof(double) * n * m.nq};
+  else if (!strcmp(name, "qvel")) *f = {e->qvel, sizeof(double) * n * m.nv};
+  else if (!strcmp(name, "ctrl")) *f = {e->ctrl, sizeof(double) * n * m.nu};
+  else if (!strcmp(name, "qacc_warmstart")) *f = {e->warm, sizeof(double) * n * m.nv};
+  else if (!strcmp(name, "sensordata")) *f = {e->sens, sizeof(double) * n * m.nsensordata};
+  else if (!strcmp(name, "timestep")) *f = {e->timestep, sizeof(int) * n};
+  else MJRL_FAIL(e, 4, "unknown field '%s'", name);
+  return 0;
+}
+
+int mjrl_get_field(mjrl_env* e, const char* name, void* h_out, size_t nbytes) {
+  field_ref f;
+  if (int rc = find_field(e, name, &f)) return rc;
+  if (nbytes != f.bytes) MJRL_FAIL(e, 4, "get_field(%s): buffer holds %zu bytes, field has %zu", name, nbytes, f.bytes);
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (f.bytes) MJRL_HIP(e, hipMemcpy(h_out, f.ptr, f.bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mjrl_set_field(mjrl_env* e, const char* name, const void* h_in, size_t nbytes) {
+  field_ref f;
+  if (int rc = find_field(e, name, &f)) return rc;
+  if (nbytes != f.bytes) MJRL_FAIL(e, 4, "set_field(%s): buffer holds %zu bytes, field has %zu", name, nbytes, f.bytes);
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (f.bytes) MJRL_HIP(e, hipMemcpy(f.ptr, h_in, f.bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int ensure_dbg(mjrl_env* e) {
+  if (!e->dbg) MJRL_HIP(e, hipMalloc(&e->dbg, sizeof(double) * (size_t)e->n_env * e->lay.total));
+  return 0;
+}
+
+int mjrl_step_debug(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, int stage, double* h_dump,
+                    size_t nbytes) {
+  size_t need = sizeof(double) * (size_t)e->n_env * e->lay.total;
+  if (nbytes != need) MJRL_FAIL(e, 4, "step_debug: dump buffer holds %zu bytes, need %zu", nbytes, need);
+  if (int rc = ensure_dbg(e)) return rc;
+  if (int rc = launch_step(e, d_actions, act_dim, skip_frames, nullptr, nullptr, nullptr, nullptr, e->dbg, stage, 0)) return rc;
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  MJRL_HIP(e, hipMemcpy(h_dump, e->dbg, need, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
+  const DevModel& m = e->hm;
+  const mj::Lay& l = e->lay;
+  if (int rc = ensure_dbg(e)) return rc;
+  if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, e->dbg, 0, 1)) return rc;
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  std::vector<double> img((size_t)e->n_env * l.total);
+  MJRL_HIP(e, hipMemcpy(img.data(), e->dbg, sizeof(double) * img.size(), hipMemcpyDeviceToHost));
+  size_t per = 0;
+  int off = 0;
+  enum { PLAIN, XIPOS, NCON, CONGEOM } kind = PLAIN;
+  if (!strcmp(name, "xpos")) { per = 3 * m.nbody; off = l.xpos; }
+  else if (!strcmp(name, "xquat")) { per = 4 * m.nbody; off = l.xquat; }
+  else if (!strcmp(name, "geom_xpos")) { per = 3 * m.ngeom; off = l.gpos; }
+  else if (!strcmp(name, "geom_xmat")) { per = 9 * m.ngeom; off = l.gmat; }
+  else if (!strcmp(name, "xipos")) { per = 3 * m.nbody; kind = XIPOS; }
+  else if (!strcmp(name, "ncon")) { per = 1; kind = NCON; }
+  else if (!strcmp(name, "contact_geom")) { per = 2 * m.nconmax; kind = CONGEOM; }
+  else MJRL_FAIL(e, 4, "query: unknown quantity '%s'", name);
+  if (nbytes != sizeof(double) * per * e->n_env) MJRL_FAIL(e, 4, "query(%s): buffer holds %zu bytes, need %zu", name, nbytes, sizeof(double) * per * e->n_env);
+  for (int env = 0; env < e->n_env; env++) {
+    const double* S = img.data() + (size_t)env * l.total;
+    const int* I = (const int*)(S + l.ints);
+    double* o = h_out + (size_t)env * per;
+    if (kind == PLAIN) memcpy(o, S + off, sizeof(double) * per);
+    else if (kind == NCON) o[0] = I[mj::I_NCON];
+    else if (kind == CONGEOM) {
+      for (int c = 0; c < m.nconmax; c++) {
+        bool live = c < I[mj::I_NCON];
+        o[2 * c] = live ? I[l.i_cong1 + c] : -1;
+        o[2 * c + 1] = live ? I[l.i_cong2 + c] : -1;
+      }
+    } else {
+      for (int b = 0; b < m.nbody; b++) {
+        const double* q = S + l.xquat + 4 * b;
+        const double* ip = m.body_ipos + 3 * b;
+        double w = q[0], x = q[1], y = q[2], z = q[3];
+        double r[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+                       2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                       2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
+        for (int k = 0; k < 3; k++)
+          o[3 * b + k] = S[l.xpos + 3 * b + k] + r[3 * k] * ip[0] + r[3 * k + 1] * ip[1] + r[3 * k + 2] * ip[2];
+      }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Device-side view of the compiled model: sizes, options and one pointer per blob section
+// (blob.py is the single source of the section order; mjrl_layout.h is generated from it).
+// The same struct describes a host-resident blob (pointers into the blob) and, after
+// mjrl_create has uploaded the sections, the copy the kernels read from HBM.
+#ifndef MJRL_MODEL_H
+#define MJRL_MODEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mjrl_layout.h"
+
+struct DevModel {
+#define X(name) int name;
+  MJRL_SIZE_FIELDS(X)
+#undef X
+#define X(name) double name;
+  MJRL_OPT_FIELDS(X)
+#undef X
+#define X(name, count) const double* name;
+  MJRL_F64_FIELDS(X)
+#undef X
+#define X(name, count) const int32_t* name;
+  MJRL_I32_FIELDS(X)
+#undef X
+};
+
+// Point a DevModel at the sections of a blob held at `base` (host or device address; only the
+// header words are dereferenced, and those come from `host_blob`).  Returns 0 on success.
+static inline int mjrl_model_from_blob(DevModel* m, const void* host_blob, size_t nbytes, const void* base) {
+  const char* h = (const char*)host_blob;
+  if (nbytes < 8 + 4 * MJRL_NSIZES + 8 * MJRL_NOPTS) return 1;
+  const int32_t* head = (const int32_t*)h;
+  if (head[0] != (int32_t)MJRL_BLOB_MAGIC) return 2;
+  if (head[1] != MJRL_BLOB_VERSION) return 3;
+  const int32_t* sz = (const int32_t*)(h + 8);
+  int k = 0;
+#define X(name) m->name = sz[k++];
+  MJRL_SIZE_FIELDS(X)
+#undef X
+  const double* op = (const double*)(h + 8 + 4 * MJRL_NSIZES);
+  k = 0;
+#define X(name) m->name = op[k++];
+  MJRL_OPT_FIELDS(X)
+#undef X
+  size_t off = 8 + 4 * MJRL_NSIZES + 8 * MJRL_NOPTS;
+  const char* b = (const char*)base;
+  int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom, nsite = m->nsite,
+      ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nM = m->nM, ndesc = m->ndesc, nchild = m->nchild,
+      ntree = m->ntree;
+  (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
+  (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
+#define X(name, count) m->name = (const double*)(b + off); off += 8 * (size_t)(count);
+  MJRL_F64_FIELDS(X)
+#undef X
+#define X(name, count) m->name = (const int32_t*)(b + off); off += 4 * (size_t)(((count) + 1) & ~1);
+  MJRL_I32_FIELDS(X)
+#undef X
+  return off == nbytes ? 0 : 4;
+}
+
+#endif

@@ -119,6 +119,9 @@ class Model:
     npair: int = 0
     nM: int = 0
     ntree: int = 0
+    ndesc: int = 0
+    nchild: int = 0
+    maxdofdepth: int = 0
     # options
     timestep: float = 0.002
     gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
@@ -471,6 +474,32 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
         nM += n
     m.nM = nM
     A["dof_Madr"], A["dof_depth"] = dof_Madr, dof_depth
+    # per sparse entry: its row and column dof; per dof: the entries L[k][d] of its descendants k (ascending k)
+    M_rowid, M_colid = np.zeros(nM, np.int32), np.zeros(nM, np.int32)
+    desc = [[] for _ in range(nv)]
+    for d in range(nv):
+        k, adr = d, dof_Madr[d]
+        while k >= 0:
+            M_rowid[adr], M_colid[adr] = d, k
+            if k != d:
+                desc[k].append(adr)
+            adr += 1
+            k = dof_parentid[k]
+    A["M_rowid"], A["M_colid"] = M_rowid, M_colid
+    A["dof_descadr"] = np.cumsum([0] + [len(x) for x in desc[:-1]]).astype(np.int32) if nv else np.zeros(0, np.int32)
+    A["dof_descnum"] = np.array([len(x) for x in desc], np.int32)
+    A["desc_Madr"] = np.array([a for x in desc for a in x], np.int32)
+    m.ndesc = int(A["desc_Madr"].size)
+    m.maxdofdepth = int(dof_depth.max()) if nv else 0
+    # children of every body (descending id, the order in which a backward pass over bodies meets them)
+    kids = [[] for _ in range(nbody)]
+    for b in range(nbody - 1, 0, -1):
+        kids[body_parentid[b]].append(b)
+    A["body_childadr"] = np.cumsum([0] + [len(x) for x in kids[:-1]]).astype(np.int32)
+    A["body_childnum"] = np.array([len(x) for x in kids], np.int32)
+    A["body_childid"] = np.array([c for x in kids for c in x], np.int32)
+    m.nchild = int(A["body_childid"].size)
+    A["tree_rootbody"] = np.array(roots, np.int32)
 
     # ---- geoms
     A["geom_type"] = np.array([g["type"] for g in c.geoms], np.int32)

@@ -80,7 +80,7 @@ static inline int ora_plane_box(ora_rawcon* c, const double* ppos, const double*
   v3_sub(dif, bpos, ppos);
   double cdist = v3_dot(dif, n);
   int cnt = 0;
-  for (int i = 0; i < 8 && cnt < 4; i++) {
+  for (int i = 0; i < 8; i++) {   /* every corner inside the margin makes a contact (nconmax is the only cap) */
     double loc[3] = {(i & 1 ? bsize[0] : -bsize[0]), (i & 2 ? bsize[1] : -bsize[1]), (i & 4 ? bsize[2] : -bsize[2])};
     double off[3];
     m3_mulv(off, bmat, loc);
@@ -131,9 +131,10 @@ static inline int ora_capsule_capsule(ora_rawcon* c, const double* p1, const dou
     v3_addscl(e2, p2, a2, x2);
     return ora_sphere_sphere_raw(c, e1, s1[0], e2, s2[0], margin);
   }
-  /* parallel axes: pair each end of one segment with its projection on the other; at most two contacts */
+  /* parallel axes: pair each end of one segment with its projection on the other (four independent
+   * candidates; generically two of them are valid) */
   int n = 0;
-  for (int k = 0; k < 4 && n < 2; k++) {
+  for (int k = 0; k < 4; k++) {
     double x1, x2;
     if (k < 2) {
       x1 = (k == 0) ? len1 : -len1;

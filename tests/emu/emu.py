@@ -1,0 +1,100 @@
+"""ctypes front end of the CPU lane-emulation build of the device step code.  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libmjrl_emu.so")
+_lib = None
+
+REGION_SHAPES = {
+    "qpos": ("nq",), "qvel": ("nv",), "ctrl": ("nu",), "warm": ("nv",), "xpos": ("nbody", 3), "xquat": ("nbody", 4),
+    "xanchor": ("njnt", 3), "xaxis": ("njnt", 3), "cinert": ("nbody", 10), "crb": ("nbody", 10), "cdof": ("nv", 6),
+    "cdofdot": ("nv", 6), "cvel": ("nbody", 6), "cacc": ("nbody", 6), "M": ("nM",), "LD": ("nM",), "Dinv": ("nv",),
+    "gpos": ("ngeom", 3), "gmat": ("ngeom", 9), "bias": ("nv",), "smooth": ("nv",), "qaccs": ("nv",), "x": ("nv",),
+    "qfc": ("nv",), "qacc": ("nv",), "con": ("nconmax", 16), "row": ("njmax", 8), "sens": ("nsensordata",),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        L = ctypes.CDLL(_LIB)
+        L.emu_lds_total.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.emu_lds_offset.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        P = ctypes.c_void_p
+        L.emu_step.argtypes = [ctypes.c_char_p, ctypes.c_size_t, P, P, P, P, P, P, P, P, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P,
+                               ctypes.c_int, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(arr):
+    return None if arr is None else arr.ctypes.data_as(ctypes.c_void_p)
+
+
+class LdsImage:
+    """View of one env copy's LDS image dumped by the step code."""
+
+    def __init__(self, image, model, offset_fn):
+        self.image, self.model, self._off = image, model, offset_fn
+        i0 = self._off("ints")
+        self.ints = image[i0:].view(np.int32)
+
+    def region(self, name):
+        shape = tuple(getattr(self.model, s) if isinstance(s, str) else s for s in REGION_SHAPES[name])
+        n = int(np.prod(shape))
+        o = self._off(name)
+        return self.image[o:o + n].reshape(shape)
+
+    @property
+    def ncon(self): return int(self.ints[0])
+    @property
+    def nefc(self): return int(self.ints[1])
+    @property
+    def niter(self): return int(self.ints[3])
+    @property
+    def warn(self): return int(self.ints[4])
+
+    def J(self):
+        ldj = self._off("ldj") if self._off("ldj") > 0 else (self.model.nv | 1)
+        o = self._off("J")
+        return self.image[o:o + ldj * self.model.njmax].reshape(self.model.njmax, ldj)[:, :self.model.nv]
+
+    def contact_geoms(self):
+        a, b = self._off("i_cong1"), self._off("i_cong2")
+        return np.stack([self.ints[a:a + self.ncon], self.ints[b:b + self.ncon]], axis=1)
+
+
+class EmuEnv:
+    def __init__(self, model, blob: bytes):
+        self.model, self.blob = model, blob
+        self.qpos = model.qpos0.copy()
+        self.qvel = np.zeros(model.nv)
+        self.ctrl = np.zeros(max(model.nu, 1))
+        self.warm = np.zeros(model.nv)
+        self.sens = np.zeros(max(model.nsensordata, 1))
+        self.timestep = np.zeros(1, np.int32)
+        self.total = lib().emu_lds_total(blob, len(blob))
+        self.dump = np.zeros(self.total)
+
+    def offset(self, name):
+        return lib().emu_lds_offset(self.blob, len(self.blob), name.encode())
+
+    def step(self, nsteps=1, skip_frames=1, dbg_stage=0, forward_only=False, actions=None, scatter=None, n_agent=0,
+             scatter_mode=0, gather=None, obs=None):
+        act_dim = 0 if actions is None else actions.shape[-1]
+        obs_dim = 0 if gather is None else gather.shape[-1]
+        rc = lib().emu_step(self.blob, len(self.blob), _p(self.qpos), _p(self.qvel), _p(self.ctrl), _p(self.warm),
+                            _p(self.sens), _p(self.timestep), _p(actions), _p(scatter), n_agent, act_dim, scatter_mode,
+                            _p(gather), obs_dim, _p(obs), skip_frames, nsteps, 1 << 30, _p(self.dump), dbg_stage,
+                            int(forward_only))
+        if rc:
+            raise RuntimeError(f"emu_step failed with code {rc}")
+        return LdsImage(self.dump, self.model, self.offset)

@@ -1,0 +1,122 @@
+// TEST INFRASTRUCTURE: runs the device step code (csrc/mjrl_step.h, unmodified) on the CPU, one env copy,
+// 64 lanes as fibers (see emu_wave.h).  Built into tests/emu/_build/libmjrl_emu.so by tests/emu/Makefile and
+// used by the CPU test-suite to check the kernel logic against the oracle before any GPU time is spent.
+// It is not a product path: the Python package only ever loads libmjrl_hip.so.
+#include "emu_wave.h"
+
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../mujoco-rl-environment-wrapper_amd/csrc/mjrl_step.h"
+
+namespace emu {
+int cur_lane = 0, cur_env = 0;
+long sync_count[64];
+double xd[64];
+long long xi[64];
+static ucontext_t main_ctx, lane_ctx[64];
+static bool done[64];
+static std::vector<char> stacks;
+
+static int next_live(int from) {
+  for (int k = 1; k <= 64; k++) {
+    int i = (from + k) % 64;
+    if (!done[i]) return i;
+  }
+  return -1;
+}
+
+void yield_lane() {
+  int me = cur_lane, nxt = next_live(me);
+  if (nxt < 0 || nxt == me) return;
+  cur_lane = nxt;
+  swapcontext(&lane_ctx[me], &lane_ctx[nxt]);
+}
+
+struct Job { const DevModel* m; const mj::StepArgs* a; double* lds; };
+static Job job;
+
+static void lane_entry() {
+  mj::env_step(*job.m, *job.a, job.lds);
+  int me = cur_lane;
+  done[me] = true;
+  int nxt = next_live(me);
+  if (nxt < 0) { setcontext(&main_ctx); }
+  cur_lane = nxt;
+  setcontext(&lane_ctx[nxt]);
+}
+
+static int run_wave(const DevModel& m, const mj::StepArgs& a, double* lds) {
+  const size_t stack_bytes = 1 << 20;
+  stacks.resize(64 * stack_bytes);
+  job = {&m, &a, lds};
+  for (int i = 0; i < 64; i++) {
+    done[i] = false;
+    sync_count[i] = 0;
+    getcontext(&lane_ctx[i]);
+    lane_ctx[i].uc_stack.ss_sp = stacks.data() + i * stack_bytes;
+    lane_ctx[i].uc_stack.ss_size = stack_bytes;
+    lane_ctx[i].uc_link = &main_ctx;
+    makecontext(&lane_ctx[i], lane_entry, 0);
+  }
+  cur_lane = 0;
+  swapcontext(&main_ctx, &lane_ctx[0]);
+  for (int i = 1; i < 64; i++)
+    if (sync_count[i] != sync_count[0]) {
+      fprintf(stderr, "emu: lane %d passed %ld barriers, lane 0 passed %ld (divergent barrier)\n", i, sync_count[i], sync_count[0]);
+      return 1;
+    }
+  return 0;
+}
+}  // namespace emu
+
+extern "C" {
+
+int emu_lds_total(const void* blob, size_t nbytes) {
+  DevModel m;
+  if (mjrl_model_from_blob(&m, blob, nbytes, blob)) return -1;
+  mj::Lay l;
+  mj::make_layout(m, l);
+  return l.total;
+}
+
+int emu_lds_offset(const void* blob, size_t nbytes, const char* region) {
+  DevModel m;
+  if (mjrl_model_from_blob(&m, blob, nbytes, blob)) return -1;
+  mj::Lay l;
+  mj::make_layout(m, l);
+#define R(name) if (!strcmp(region, #name)) return l.name;
+  R(qpos) R(qvel) R(ctrl) R(warm) R(xpos) R(xquat) R(xanchor) R(xaxis) R(com) R(cinert) R(crb) R(cdof) R(cdofdot)
+  R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gmat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
+  R(sens) R(ints) R(total) R(ldj) R(i_cand) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid)
+#undef R
+  return -1;
+}
+
+// one env copy, `nsteps` step() calls with the same actions; state arrays are updated in place
+int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
+             int* timestep, const double* actions, const int32_t* scatter, int n_agent, int act_dim, int scatter_mode,
+             const int32_t* gather, int obs_dim, double* obs, int skip_frames, int nsteps, int max_steps, double* dbg,
+             int dbg_stage, int forward_only) {
+  DevModel m;
+  if (mjrl_model_from_blob(&m, blob, nbytes, blob)) return -1;
+  mj::Lay l;
+  mj::make_layout(m, l);
+  std::vector<double> lds(l.total, 0.0);
+  mj::StepArgs a{};
+  a.qpos = qpos; a.qvel = qvel; a.ctrl = ctrl; a.warm = warm; a.sensordata = sens; a.timestep = timestep;
+  a.actions = actions; a.scatter = scatter; a.n_agent = n_agent; a.act_dim = act_dim; a.scatter_mode = scatter_mode;
+  a.gather = gather; a.obs_dim = obs_dim; a.obs = obs;
+  a.reward = nullptr; a.term = nullptr; a.trunc = nullptr;
+  a.max_steps = max_steps; a.skip_frames = skip_frames; a.n_env = 1;
+  a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;
+  emu::cur_env = 0;
+  for (int s = 0; s < nsteps; s++)
+    if (emu::run_wave(m, a, lds.data())) return 2;
+  return 0;
+}
+}

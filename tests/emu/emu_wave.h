@@ -1,0 +1,59 @@
+// TEST INFRASTRUCTURE: CPU stand-in for csrc/mjrl_wave.h.
+// The 64 lanes of a wavefront run as 64 cooperative fibers on one thread; wv::sync() hands control to the
+// next lane, so a lane resumes only after every other lane has reached the same barrier.  Cross-lane
+// primitives go through a 64-slot exchange buffer with the same xor-butterfly order as the GPU header, so
+// floating-point sums come out bit-identical to the device's.  The harness also counts barriers per lane:
+// a kernel whose lanes disagree on the number of barriers (a divergent barrier on the GPU) fails the run.
+#ifndef MJRL_WAVE_H
+#define MJRL_WAVE_H
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#define __device__
+#define __host__
+#define __forceinline__ inline
+
+namespace emu {
+extern int cur_lane, cur_env;
+extern long sync_count[64];
+extern double xd[64];
+extern long long xi[64];
+void yield_lane();
+}  // namespace emu
+
+namespace wv {
+inline int lane() { return emu::cur_lane; }
+inline int env_index() { return emu::cur_env; }
+inline void sync() { emu::sync_count[emu::cur_lane]++; emu::yield_lane(); }
+inline double shfl(double v, int src) {
+  emu::xd[lane()] = v; sync();
+  double r = emu::xd[src & 63]; sync();
+  return r;
+}
+inline int shfl(int v, int src) {
+  emu::xi[lane()] = v; sync();
+  int r = (int)emu::xi[src & 63]; sync();
+  return r;
+}
+inline double shfl_xor(double v, int mask) { return shfl(v, lane() ^ mask); }
+inline unsigned long long ballot(bool pred) {
+  emu::xi[lane()] = pred ? 1 : 0; sync();
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; i++) if (emu::xi[i]) m |= (1ull << i);
+  sync();
+  return m;
+}
+inline int popc(unsigned long long x) { return __builtin_popcountll(x); }
+inline double sum(double v) {
+  for (int mask = 1; mask < 64; mask <<= 1) v += shfl_xor(v, mask);
+  return v;
+}
+inline double min_pos(double v) {
+  for (int mask = 1; mask < 64; mask <<= 1) v = std::fmin(v, shfl_xor(v, mask));
+  return v;
+}
+}  // namespace wv
+
+#endif

@@ -1,0 +1,209 @@
+"""Known-answer tests that pin the CPU oracle (physics parity is otherwise unpinned: the reference
+asserts no physics value anywhere and mujoco itself cannot be run here -- SURVEY.md section 8c).
+
+Each case has a closed-form answer: discrete free fall, conservation laws of an unforced system,
+the mass matrix from an independent Jacobian-sum formula, static contact force = weight, the
+rangefinder distance to a known wall.
+"""
+import numpy as np
+import pytest
+
+from mjrl_amd import blob, levels, mjcf
+from oracle.oracle import OracleEnv
+
+
+def make(xml: str, **kw):
+    model = mjcf.compile_mjcf_string(xml, **kw)
+    return model, OracleEnv(blob.pack(model))
+
+
+FREE_SPHERE = """
+<mujoco><option timestep="0.002"/><worldbody>
+  <body name="ball" pos="0 0 5"><joint type="free" name="root"/>
+    <geom type="sphere" size="0.1" density="1000"/></body>
+</worldbody></mujoco>"""
+
+
+def test_free_fall_matches_discrete_closed_form():
+    model, env = make(FREE_SPHERE)
+    h, g, n = model.timestep, 9.81, 500
+    env.step(n)
+    # semi-implicit Euler: v_k = -g h k ; z_n = z_0 - g h^2 n (n+1) / 2
+    assert env.qvel[2] == pytest.approx(-g * h * n, rel=1e-12)
+    assert env.qpos[2] == pytest.approx(5.0 - g * h * h * n * (n + 1) / 2, rel=1e-12)
+    assert env.ncon == 0 and env.nefc == 0
+
+
+TUMBLER = """
+<mujoco><option timestep="0.0005" gravity="0 0 0"/><worldbody>
+  <body name="brick" pos="0 0 1"><joint type="free" name="root"/>
+    <geom type="box" size="0.1 0.2 0.3" density="800" contype="0" conaffinity="0"/></body>
+</worldbody></mujoco>"""
+
+
+def test_torque_free_body_conserves_angular_momentum_and_energy():
+    model, env = make(TUMBLER)
+    env.qvel[:] = [0.3, -0.2, 0.1, 2.0, 0.5, -1.0]
+    inertia = model.body_inertia[1]
+
+    def momentum_energy():
+        env.forward()
+        rot = env.ximat[1].reshape(3, 3)
+        # free-joint angular velocity is expressed in the body frame (iquat is identity for one box)
+        w_local = env.qvel[3:6]
+        l_world = rot @ (inertia * (rot.T @ (env.xmat[1].reshape(3, 3) @ w_local)))
+        kinetic = 0.5 * env.qvel @ env.qMdense @ env.qvel
+        return l_world, kinetic
+
+    l0, e0 = momentum_energy()
+    env.step(2000)
+    l1, e1 = momentum_energy()
+    assert np.allclose(l0, l1, rtol=2e-3, atol=1e-6)
+    assert e1 == pytest.approx(e0, rel=2e-3)
+    # linear motion of the centre of mass is uniform
+    assert np.allclose(env.qpos[:3], np.array([0, 0, 1]) + np.array([0.3, -0.2, 0.1]) * env.time, atol=1e-9)
+
+
+DOUBLE_PENDULUM = """
+<mujoco><option timestep="0.0002"/><worldbody>
+  <body name="upper" pos="0 0 2"><joint type="hinge" axis="0 1 0" name="j1"/>
+    <geom type="capsule" fromto="0 0 0 0 0 -0.5" size="0.05" density="500" contype="0" conaffinity="0"/>
+    <body name="lower" pos="0 0 -0.5"><joint type="hinge" axis="0.3 1 0" name="j2"/>
+      <geom type="capsule" fromto="0 0 0 0.1 0 -0.4" size="0.04" density="700" contype="0" conaffinity="0"/>
+    </body></body>
+</worldbody></mujoco>"""
+
+
+def _energy(model, env):
+    env.forward()
+    kinetic = 0.5 * env.qvel @ env.qMdense @ env.qvel
+    potential = sum(model.body_mass[b] * 9.81 * env.xipos[b, 2] for b in range(1, model.nbody))
+    return kinetic + potential
+
+
+def test_double_pendulum_energy_is_conserved():
+    """Exercises the Coriolis/centrifugal part of the RNE bias and the sparse factorisation."""
+    model, env = make(DOUBLE_PENDULUM)
+    env.qpos[:] = [1.0, -0.7]
+    env.qvel[:] = [0.5, 2.0]
+    e0 = _energy(model, env)
+    env.step(5000)   # one second
+    e1 = _energy(model, env)
+    assert abs(e1 - e0) < 2e-3 * abs(e0)
+    assert abs(env.qpos[0] - 1.0) > 0.1   # it did move
+
+
+def test_mass_matrix_matches_jacobian_sum_on_the_two_agent_level():
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    env = OracleEnv(blob.pack(model))
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        env.qpos[:] = model.qpos0 + 0.4 * rng.normal(size=model.nq)
+        env.forward()
+        expect, _, _ = mjcf.mass_matrix_numpy(model, env.qpos.copy())
+        assert np.allclose(env.qMdense, expect, rtol=0, atol=1e-13)
+
+
+def test_gravity_bias_matches_potential_gradient():
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    env = OracleEnv(blob.pack(model))
+    rng = np.random.default_rng(3)
+    env.qpos[:] = model.qpos0 + 0.3 * rng.normal(size=model.nq)
+    env.qvel[:] = 0
+    env.forward()
+    q = env.qpos.copy()
+    xpos, xquat = mjcf.kinematics_numpy(model, q)
+    expect = np.zeros(model.nv)
+    for b in range(1, model.nbody):
+        if model.body_lastdof[b] < 0:
+            continue
+        com = xpos[b] + mjcf.quat_to_mat(xquat[b]) @ model.body_ipos[b]
+        jac = mjcf.body_jacobian_numpy(model, xpos, xquat, b, com)
+        expect += jac[:3].T @ (model.body_mass[b] * np.array([0, 0, 9.81]))
+    assert np.allclose(env.qfrc_bias, expect, atol=1e-12)
+
+
+RESTING_BALL = """
+<mujoco><option timestep="0.002"/><worldbody>
+  <geom type="plane" size="5 5 0.1"/>
+  <body name="ball" pos="0 0 0.1"><joint type="free" name="root"/>
+    <geom type="sphere" size="0.1" density="1000"/></body>
+</worldbody></mujoco>"""
+
+
+def test_resting_contact_force_equals_weight():
+    model, env = make(RESTING_BALL)
+    env.step(1500)
+    assert env.ncon == 1
+    con = env.contacts()[0]
+    weight = model.body_mass[1] * 9.81
+    assert con["normal_force"] == pytest.approx(weight, rel=1e-4)
+    assert abs(env.qvel[2]) < 1e-6
+    assert con["dist"] < 0            # soft contact: small penetration
+    assert con["dist"] > -0.01
+    assert np.allclose(con["frame"][0], [0, 0, 1])
+
+
+SLIDING_BOX = """
+<mujoco><option timestep="0.002"/><worldbody>
+  <geom type="plane" size="50 50 0.1" friction="0.5 0.005 0.0001"/>
+  <body name="puck" pos="0 0 0.1"><joint type="free" name="root"/>
+    <geom type="sphere" size="0.1" density="1000" friction="0.5 0.005 0.0001"/></body>
+</worldbody></mujoco>"""
+
+
+def test_friction_pyramid_decelerates_a_sliding_ball():
+    """A ball sliding (not yet rolling) on the plane loses linear momentum through friction and picks up spin."""
+    model, env = make(SLIDING_BOX)
+    env.step(300)                      # settle
+    env.qvel[0] = 1.0
+    env.step(50)
+    assert 0.0 < env.qvel[0] < 1.0     # friction acts against sliding
+    assert env.qvel[4] > 0.0           # and spins the ball up about +y (local frame still ~ world)
+
+
+def test_joint_limits_of_the_ant_are_active_at_reset():
+    """ankle ranges exclude qpos0, so eight limit rows exist from the first step."""
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    env = OracleEnv(blob.pack(model))
+    assert env.ncon == 0 and env.nefc == 8
+    assert np.allclose(np.abs(env.efc_pos[:8]), np.radians(30), atol=1e-12)
+    assert np.all(env.efc_pos[:8] < 0)
+    assert np.all(env.efc_force[:8] > 0)
+
+
+def test_rangefinder_measures_the_wall_distance():
+    """Testing/sensor_levels/Model3.xml geometry: box at x=4.595 flipped 180 deg about x; its site looks along
+    the site z axis (world -z after the flip) from 0.474 above the floor."""
+    model = mjcf.compile_mjcf(levels.level_path("sensor_rangefinder.xml"))
+    env = OracleEnv(blob.pack(model))
+    assert np.allclose(env.site_xmat[0].reshape(3, 3)[:, 2], [0, 0, -1], atol=1e-12)
+    assert env.sensordata[0] == pytest.approx(0.4743838, abs=1e-9)
+    # aim it at the +y wall instead: border2's inner face is at y = 4.738263 - 0.25
+    half = np.sqrt(0.5)
+    env.qpos[3:7] = [half, -half, 0, 0]     # rotate -90 deg about x: local z -> world +y, local x unchanged
+    env.qpos[2] = 0.6
+    env.forward()
+    assert np.allclose(env.site_xmat[0].reshape(3, 3)[:, 2], [0, 1, 0], atol=1e-12)
+    assert env.sensordata[0] == pytest.approx(4.738263 - 0.25 - env.site_xpos[0, 1], abs=1e-9)
+
+
+def test_frame_axis_sensor_reports_site_x_axis():
+    model = mjcf.compile_mjcf(levels.level_path("sensor_framexaxis.xml"))
+    env = OracleEnv(blob.pack(model))
+    assert np.allclose(env.sensordata[:3], [1, 0, 0], atol=1e-12)
+
+
+def test_accelerometer_reads_zero_in_free_fall_and_g_at_rest():
+    xml = """
+    <mujoco><worldbody><geom type="plane" size="5 5 0.1"/>
+      <body name="ball" pos="0 0 1"><joint type="free" name="root"/>
+        <geom type="sphere" size="0.1" density="1000"/><site name="s" pos="0 0 0" size="0.01"/></body>
+    </worldbody><sensor><accelerometer name="acc" site="s" cutoff="50"/></sensor></mujoco>"""
+    model, env = make(xml)
+    env.step(10)
+    assert np.allclose(env.sensordata[:3], 0, atol=1e-9)           # free fall: proper acceleration is zero
+    env.qpos[2] = 0.1
+    env.qvel[:] = 0
+    env.step(1500)
+    assert np.allclose(env.sensordata[:3], [0, 0, 9.81], atol=1e-3)  # at rest the floor pushes up with g
