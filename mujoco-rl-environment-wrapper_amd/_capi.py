@@ -1,0 +1,178 @@
+"""ctypes binding of libmjrl_hip.so (include/mjrl.h).
+
+This is the only native library the package loads.  There is no CPU fallback: if the HIP library is
+missing or fails to load, importing this module's ``load()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmjrl_hip.so")
+
+# every symbol include/mjrl.h declares
+SYMBOLS = [
+    "mjrl_version", "mjrl_last_error", "mjrl_create", "mjrl_destroy", "mjrl_set_stream", "mjrl_sync",
+    "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
+    "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
+    "mjrl_lds_offset",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+            "(or __graft_entry__.build()).  The stepper has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(L, s)]
+    if missing:
+        raise RuntimeError(f"libmjrl_hip.so lacks symbols declared in include/mjrl.h: {missing}")
+    vp, ip, sz, ci = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_size_t, ctypes.c_int
+    L.mjrl_version.restype = ctypes.c_char_p
+    L.mjrl_last_error.restype = ctypes.c_char_p
+    L.mjrl_last_error.argtypes = [vp]
+    L.mjrl_create.argtypes = [ctypes.c_char_p, sz, ci, ci, ctypes.c_uint, ctypes.POINTER(vp)]
+    L.mjrl_destroy.argtypes = [vp]
+    L.mjrl_destroy.restype = None
+    L.mjrl_set_stream.argtypes = [vp, vp]
+    L.mjrl_sync.argtypes = [vp]
+    L.mjrl_set_gather_tables.argtypes = [vp, ci, ip, ip, ip, ip, ip, ip]
+    L.mjrl_set_scatter_tables.argtypes = [vp, ci, ci, ip, ip]
+    L.mjrl_set_max_steps.argtypes = [vp, ci]
+    L.mjrl_size.argtypes = [vp, ctypes.c_char_p]
+    L.mjrl_reset.argtypes = [vp, vp, vp]
+    L.mjrl_step_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    L.mjrl_step_host.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
+    L.mjrl_get_field.argtypes = [vp, ctypes.c_char_p, vp, sz]
+    L.mjrl_set_field.argtypes = [vp, ctypes.c_char_p, vp, sz]
+    L.mjrl_query.argtypes = [vp, ctypes.c_char_p, vp, sz]
+    L.mjrl_step_debug.argtypes = [vp, vp, ci, ci, ci, vp, sz]
+    L.mjrl_lds_offset.argtypes = [vp, ctypes.c_char_p]
+    _lib = L
+    return L
+
+
+def _i32(seq):
+    arr = np.ascontiguousarray(np.asarray(seq, dtype=np.int32).reshape(-1))
+    if arr.size == 0:
+        arr = np.zeros(1, np.int32)
+    return arr, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def _host_ptr(arr):
+    return None if arr is None else ctypes.c_void_p(arr.ctypes.data)
+
+
+class Handle:
+    """Owns one ``mjrl_env`` (one GPU, n_env copies of one model)."""
+
+    def __init__(self, blob: bytes, n_env: int, device_id: int = 0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.mjrl_create(blob, len(blob), int(n_env), int(device_id), 0, ctypes.byref(self._h))
+        if rc:
+            raise Exception(f"mjrl_create failed ({rc}): {self._lib.mjrl_last_error(None).decode()}")
+        self.n_env = int(n_env)
+
+    def _check(self, rc):
+        if rc:
+            raise Exception(f"libmjrl_hip error {rc}: {self._lib.mjrl_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mjrl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self, name: str) -> int:
+        return self._lib.mjrl_size(self._h, name.encode())
+
+    def lds_offset(self, region: str) -> int:
+        return self._lib.mjrl_lds_offset(self._h, region.encode())
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self._lib.mjrl_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def sync(self):
+        self._check(self._lib.mjrl_sync(self._h))
+
+    def set_max_steps(self, n: int):
+        self._check(self._lib.mjrl_set_max_steps(self._h, int(n)))
+
+    def set_gather_tables(self, sensor_idx, qpos_idx, qvel_idx):
+        """Each argument: list (one entry per agent) of index lists."""
+        n_agent = len(sensor_idx)
+        keep = []
+        args = []
+        for lists in (sensor_idx, qpos_idx, qvel_idx):
+            counts, cp = _i32([len(x) for x in lists])
+            flat, fp = _i32([i for x in lists for i in x])
+            keep += [counts, flat]
+            args += [cp, fp]
+        self._check(self._lib.mjrl_set_gather_tables(self._h, n_agent, *args))
+
+    def set_scatter_tables(self, idx_lists, mode: int):
+        counts, cp = _i32([len(x) for x in idx_lists])
+        flat, fp = _i32([i for x in idx_lists for i in x])
+        self._check(self._lib.mjrl_set_scatter_tables(self._h, len(idx_lists), int(mode), cp, fp))
+
+    def reset(self, mask=None, d_obs: int | None = None):
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+            if m.size != self.n_env:
+                raise Exception(f"reset mask has {m.size} entries for {self.n_env} env copies")
+        self._check(self._lib.mjrl_reset(self._h, _host_ptr(m), ctypes.c_void_p(d_obs or 0)))
+
+    def step_device(self, d_actions, act_dim, skip_frames, d_obs=None, d_reward=None, d_term=None, d_trunc=None):
+        """All pointers are integer device addresses (e.g. ``tensor.data_ptr()``) or None."""
+        c = lambda p: ctypes.c_void_p(p or 0)
+        self._check(self._lib.mjrl_step_device(self._h, c(d_actions), int(act_dim), int(skip_frames), c(d_obs),
+                                               c(d_reward), c(d_term), c(d_trunc)))
+
+    def step_host(self, actions, skip_frames, obs=None, reward=None, term=None, trunc=None):
+        act_dim = 0 if actions is None else int(actions.shape[-1])
+        self._check(self._lib.mjrl_step_host(self._h, _host_ptr(actions), act_dim, int(skip_frames), _host_ptr(obs),
+                                             _host_ptr(reward), _host_ptr(term), _host_ptr(trunc)))
+
+    def get_field(self, name: str):
+        per = {"qpos": "nq", "qvel": "nv", "ctrl": "nu", "qacc_warmstart": "nv", "sensordata": "nsensordata"}
+        if name == "timestep":
+            out = np.zeros(self.n_env, np.int32)
+        else:
+            out = np.zeros((self.n_env, self.size(per[name])), np.float64)
+        self._check(self._lib.mjrl_get_field(self._h, name.encode(), _host_ptr(out), out.nbytes))
+        return out
+
+    def set_field(self, name: str, value):
+        dtype = np.int32 if name == "timestep" else np.float64
+        arr = np.ascontiguousarray(np.asarray(value, dtype=dtype))
+        self._check(self._lib.mjrl_set_field(self._h, name.encode(), _host_ptr(arr), arr.nbytes))
+
+    def query(self, name: str):
+        shapes = {"xpos": ("nbody", 3), "xquat": ("nbody", 4), "xipos": ("nbody", 3), "geom_xpos": ("ngeom", 3),
+                  "geom_xmat": ("ngeom", 9), "ncon": (1,), "contact_geom": ("nconmax", 2)}
+        shape = tuple(self.size(s) if isinstance(s, str) else s for s in shapes[name])
+        out = np.zeros((self.n_env,) + shape, np.float64)
+        self._check(self._lib.mjrl_query(self._h, name.encode(), _host_ptr(out), out.nbytes))
+        return out
+
+    def step_debug(self, d_actions, act_dim, skip_frames, stage=0):
+        out = np.zeros((self.n_env, self.size("lds_doubles")), np.float64)
+        self._check(self._lib.mjrl_step_debug(self._h, ctypes.c_void_p(d_actions or 0), int(act_dim), int(skip_frames),
+                                              int(stage), _host_ptr(out), out.nbytes))
+        return out

@@ -136,8 +136,10 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
 }
 
 int mjrl_set_stream(mjrl_env* e, void* hip_stream) {
-  MJRL_HIP(e, hipStreamSynchronize(e->stream));
-  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  hipStream_t next = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  if (next == e->stream) return 0;
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));   // work queued on the old stream finishes before the switch
+  e->stream = next;
   return 0;
 }
 

@@ -1,0 +1,396 @@
+"""Sim host of the batched stepper -- the counterpart of the reference's ``MuJoCoParent``
+(MuJoCo_Gym/mujoco_parent.py).
+
+Same constructor arguments, same table builders and query helpers, but ``n_env`` copies of the level live
+in HBM behind the C-ABI of libmjrl_hip.so and one kernel launch advances all of them.  Interactive GLFW
+rendering (mujoco_parent.py:99-105, 577-616) is out of scope; agent cameras are served by the ray-cast
+render entry when it is available.
+
+Index tables are built by walking the xmltodict-shaped level dict exactly like the reference does, so the
+gather / scatter indices are bit-identical (golden values: tests/golden/index_tables.json).
+"""
+from __future__ import annotations
+
+import math
+import random
+
+import numpy as np
+
+from . import _capi, blob, mjcf, xmldict
+from .helper import mat2euler_scipy
+from .sensor import create_sensor_observation_space, process_sensors
+
+_SITE_SENSOR_KEYS = ("rangefinder", "touch", "accelerometer")
+
+
+class _Named:
+    """Attribute bag returned by ``data.body(name)`` / ``model.geom(name)`` style accessors."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class ModelView:
+    """The slice of ``MjModel`` that plugins and the table builders read."""
+
+    def __init__(self, compiled: mjcf.Model):
+        self._m = compiled
+        self.nq, self.nv, self.nu, self.nbody, self.ngeom = compiled.nq, compiled.nv, compiled.nu, compiled.nbody, compiled.ngeom
+        self.jnt_qposadr, self.jnt_dofadr, self.jnt_type = compiled.jnt_qposadr, compiled.jnt_dofadr, compiled.jnt_type
+        self.opt = _Named(timestep=compiled.timestep, gravity=compiled.gravity)
+
+    def joint(self, name):
+        j = self._m.name2id("joint", name)
+        return _Named(id=j, name=name, qposadr=self._m.jnt_qposadr[j:j + 1], dofadr=self._m.jnt_dofadr[j:j + 1],
+                      type=self._m.jnt_type[j:j + 1])
+
+    def body(self, name):
+        b = self._m.name2id("body", name)
+        return _Named(id=b, name=name, mass=self._m.body_mass[b:b + 1])
+
+    def geom(self, name):
+        g = self._m.name2id("geom", name)
+        return _Named(id=g, name=name, rgba=self._m.geom_rgba[g], type=self._m.geom_type[g:g + 1],
+                      size=self._m.geom_size[g])
+
+    def camera(self, name):
+        return _Named(id=self._m.name2id("camera", name), name=name)
+
+    def sensor(self, name):
+        s = self._m.name2id("sensor", name)
+        return _Named(id=s, name=name, dim=int(self._m.sensor_dim[s]), adr=int(self._m.sensor_adr[s]))
+
+
+class DataView:
+    """The slice of ``MjData`` that plugins read.  Values are fetched from HBM on access; with one env copy
+    the leading batch dimension is dropped so reference plugins work unchanged."""
+
+    def __init__(self, parent):
+        self._p = parent
+
+    def _squeeze(self, arr):
+        return arr[0] if self._p.n_env == 1 else arr
+
+    @property
+    def qpos(self): return self._squeeze(self._p._handle.get_field("qpos"))
+    @property
+    def qvel(self): return self._squeeze(self._p._handle.get_field("qvel"))
+    @property
+    def ctrl(self): return self._squeeze(self._p._handle.get_field("ctrl"))
+    @property
+    def sensordata(self): return self._squeeze(self._p._handle.get_field("sensordata"))
+    @property
+    def time(self): return self._squeeze(self._p._handle.get_field("timestep")) * self._p._compiled.timestep * max(self._p._skip_frames_hint, 1)
+
+    def sensor(self, name):
+        view = self._p.model.sensor(name)
+        data = self._p._handle.get_field("sensordata")[:, view.adr:view.adr + view.dim]
+        return _Named(id=view.id, name=name, data=self._squeeze(data))
+
+    def body(self, name):
+        b = self._p._compiled.name2id("body", name)
+        q = self._p._handle.query
+        xquat = q("xquat")[:, b]
+        xmat = np.stack([mjcf.quat_to_mat(qq).reshape(9) for qq in xquat])
+        return _Named(id=b, name=name, xpos=self._squeeze(q("xpos")[:, b]), xipos=self._squeeze(q("xipos")[:, b]),
+                      xquat=self._squeeze(xquat), xmat=self._squeeze(xmat))
+
+    def geom(self, name):
+        g = self._p._compiled.name2id("geom", name)
+        q = self._p._handle.query
+        return _Named(id=g, name=name, xpos=self._squeeze(q("geom_xpos")[:, g]), xmat=self._squeeze(q("geom_xmat")[:, g]))
+
+    @property
+    def ncon(self):
+        n = self._p._handle.query("ncon")[:, 0].astype(int)
+        return int(n[0]) if self._p.n_env == 1 else n
+
+    @property
+    def contact(self):
+        pairs = self._p._handle.query("contact_geom").astype(int)
+        if self._p.n_env == 1:
+            return [_Named(geom1=int(a), geom2=int(b)) for a, b in pairs[0]]
+        return pairs
+
+
+class MuJoCoParent:
+    def __init__(self, xml_paths, export_path: str = None, render: bool = False, free_joint: bool = False,
+                 agent_cameras: bool = False, sensor_resolution=(64, 64), n_env: int = 1, device_id: int = 0,
+                 nconmax: int = None, njmax: int = None):
+        self.xml_paths = xml_paths
+        self.export_path = export_path
+        self.render = render
+        self.free_joint = free_joint
+        self.agent_cameras = agent_cameras
+        self.sensor_resolution = sensor_resolution
+        self.n_env = int(n_env)
+        self.device_id = int(device_id)
+        self._nconmax, self._njmax = nconmax, njmax
+        self.rgb_sensors = {}
+        self.frame = 0
+        self._skip_frames_hint = 1
+        if render:
+            raise Exception("renderMode needs an interactive GLFW window, which the batched stepper does not provide")
+        if isinstance(xml_paths, str):
+            self.xml_path = xml_paths
+        elif isinstance(xml_paths, list):
+            self.xml_path = random.choice(xml_paths)
+        else:
+            raise Exception("xmlPath must be a path or a list of paths")
+        with open(self.xml_path, "r") as fh:
+            self.xml_dict = xmldict.parse(fh.read())
+        self._handle = None
+        self._init_environment()
+        self.agents_action_index = {}
+        self.agents_observation_index = {}
+        self.agent_observations_id = []
+        self._obs_cache = None
+
+    # ------------------------------------------------------------------ model / device state
+    def _init_environment(self):
+        """Counterpart of mujoco_parent.py:119-137: compile the level and create the device copies."""
+        self._compiled = mjcf.compile_mjcf(self.xml_path, nconmax=self._nconmax, njmax=self._njmax)
+        self._blob = blob.pack(self._compiled)
+        if self._handle is not None:
+            self._handle.close()
+        self._handle = _capi.Handle(self._blob, self.n_env, self.device_id)
+        self.model = ModelView(self._compiled)
+        self.data = DataView(self)
+
+    @classmethod
+    def tables_only(cls, xml_path: str, free_joint: bool = False, agent_cameras: bool = False):
+        """Instance that can build index tables and spaces but owns no device state (no stepping): used to
+        check the gather / scatter tables on a machine without a GPU."""
+        self = object.__new__(cls)
+        self.xml_paths = self.xml_path = xml_path
+        self.free_joint, self.agent_cameras, self.render = free_joint, agent_cameras, False
+        self.n_env, self.rgb_sensors, self._handle = 1, {}, None
+        with open(xml_path, "r") as fh:
+            self.xml_dict = xmldict.parse(fh.read())
+        self._compiled = mjcf.compile_mjcf(xml_path)
+        self.model = ModelView(self._compiled)
+        self.agents_action_index, self.agents_observation_index = {}, {}
+        return self
+
+    def close(self):
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None
+
+    # ------------------------------------------------------------------ table builders (init time)
+    def _process_sensor(self, sensor, indices, key):
+        current = self.model.sensor(sensor["@name"])
+        indices[current.id] = {"name": sensor["@name"], "data": [0.0] * current.dim}
+        if key in _SITE_SENSOR_KEYS:
+            indices[current.id].update(site=sensor["@site"], type=key, cutoff=sensor["@cutoff"])
+        if key == "framexaxis":
+            # the reference files these under the type name "frameyaxis" (mujoco_parent.py:158-160)
+            indices[current.id].update(site=sensor["@objname"], type="frameyaxis")
+
+    def _create_sensor_index_dict(self, sensor_dict):
+        indices = {}
+        for block in sensor_dict:
+            if block is None:
+                continue
+            for key, entry in block.items():
+                if isinstance(entry, list):
+                    for sensor in entry:
+                        self._process_sensor(sensor, indices, key)
+                elif isinstance(entry, dict):
+                    self._process_sensor(entry, indices, key)
+        return indices
+
+    def retrieve_mujoco_all_indices(self, joint_dicts):
+        """qpos / qvel index lists of the named joints: free -> 7 / 6, anything else -> 1 / 1
+        (mujoco_parent.py:185-231)."""
+        qpos_indices, qvel_indices = [], []
+        for joint in joint_dicts:
+            name = joint.get("@name")
+            if not name:
+                continue
+            jid = self._compiled.name2id("joint", name)
+            free = self._compiled.jnt_type[jid] == mjcf.JNT_FREE
+            qa, da = int(self._compiled.jnt_qposadr[jid]), int(self._compiled.jnt_dofadr[jid])
+            qpos_indices.extend(range(qa, qa + (7 if free else 1)))
+            qvel_indices.extend(range(da, da + (6 if free else 1)))
+        return qpos_indices, qvel_indices
+
+    def get_observation_space_mujoco(self, agent: str) -> dict:
+        find = xmldict.find_in_nested_dict
+        agent_dict = find(self.xml_dict, name=agent, filter_key="@name")
+        agent_sites = find(agent_dict, parent="site")
+        sensor_dict = find(self.xml_dict, parent="sensor")
+        world_dict = find(self.xml_dict, parent="worldbody")
+        joint_dict = find(world_dict, parent="joint")
+        if self.agent_cameras:
+            self.rgb_sensors[agent] = [cam["@name"] for cam in find(agent_dict, parent="camera")]
+        indices = self._create_sensor_index_dict(sensor_dict)
+        qpos_indices, qvel_indices = self.retrieve_mujoco_all_indices(joint_dict)
+        agent_indices, agent_sensors = process_sensors(indices, agent_sites)
+        self.agents_observation_index[agent] = {"sensors": agent_indices, "qpos": qpos_indices, "qvel": qvel_indices}
+        space = create_sensor_observation_space(agent_sensors)
+        for _ in range(len(qpos_indices) + len(qvel_indices)):
+            space["low"].append(-np.inf)
+            space["high"].append(np.inf)
+        return space
+
+    def get_action_space_mujoco(self, agent: str) -> dict:
+        find = xmldict.find_in_nested_dict
+        space = {"low": [], "high": []}
+        agent_dict = find(self.xml_dict, name=agent, filter_key="@name")
+        if self.free_joint:
+            try:
+                free_joint = agent_dict[0]["joint"]
+            except (ValueError, KeyError, IndexError):
+                raise Exception(f"The agent {agent} has to have a free joint")
+            if free_joint["@type"] != "free":
+                raise Exception(f"The joint of agent {agent} has to be of type free")
+            dof = int(self._compiled.jnt_dofadr[self._compiled.name2id("joint", free_joint["@name"])])
+            space["low"] = [-1, -1, -1]
+            space["high"] = [1, 1, 1]
+            self.agents_action_index[agent] = [dof, dof + 1, dof + 5]
+            return space
+        actuator_dict = find(self.xml_dict, parent="actuator")
+        indices = []
+        for joint in find(agent_dict, parent="joint"):
+            for motor in find(self.xml_dict, parent="motor", filter_key="@joint", name=joint["@name"]):
+                indices.append(actuator_dict[0]["motor"].index(motor))
+                low, high = motor["@ctrlrange"].split(" ")
+                space["low"].append(float(low))
+                space["high"].append(float(high))
+        self.agents_action_index[agent] = indices
+        return space
+
+    def _upload_tables(self, agents):
+        """Hand the gather / scatter tables to the device (mjrl_set_gather_tables / mjrl_set_scatter_tables)."""
+        obs = [self.agents_observation_index[a] for a in agents]
+        self._handle.set_gather_tables([o["sensors"] for o in obs], [o["qpos"] for o in obs], [o["qvel"] for o in obs])
+        self._handle.set_scatter_tables([self.agents_action_index[a] for a in agents], 1 if self.free_joint else 0)
+        self._table_agents = list(agents)
+        self._obs_len = {a: len(o["sensors"]) + len(o["qpos"]) + len(o["qvel"]) for a, o in zip(agents, obs)}
+
+    # ------------------------------------------------------------------ stepping
+    def _actions_to_array(self, actions: dict) -> np.ndarray:
+        agents = self._table_agents
+        n_phys = max((len(self.agents_action_index[a]) for a in agents), default=0)
+        arr = np.zeros((self.n_env, len(agents), max(n_phys, 1)), np.float64)
+        for k, agent in enumerate(agents):
+            if agent not in actions:
+                raise Exception(f"No action for agent {agent}")
+            act = np.asarray(actions[agent], dtype=np.float64)
+            act = act.reshape(self.n_env, -1) if act.ndim <= 1 or self.n_env > 1 else act
+            need = len(self.agents_action_index[agent])
+            if act.shape[-1] < need:
+                raise Exception(f"The number of actions for agent {agent} is not correct.")
+            arr[:, k, :need] = act[:, :need]
+        return arr
+
+    def apply_action(self, actions: dict, skip_frames: int = 1):
+        """Scatter the actions and advance every copy ``skip_frames`` physics steps (mujoco_parent.py:316-336).
+        The same launch also gathers the post-step observations, which ``get_observations`` then serves."""
+        arr = self._actions_to_array(actions)
+        n_agent, obs_dim = len(self._table_agents), self._handle.size("obs_dim")
+        obs = np.zeros((self.n_env, n_agent, obs_dim), np.float64)
+        trunc = np.zeros((self.n_env, n_agent), np.uint8)
+        self._skip_frames_hint = skip_frames
+        self._handle.step_host(arr, skip_frames, obs=obs, trunc=trunc)
+        self.frame += skip_frames
+        self._obs_cache = obs
+        self._trunc_cache = trunc
+        return obs
+
+    def reset(self):
+        """mj_resetData + mj_forward for every copy (mujoco_parent.py:341-358)."""
+        if isinstance(self.xml_paths, list):
+            chosen = random.choice(self.xml_paths)
+            if chosen != self.xml_path:
+                self.xml_path = chosen
+                self._init_environment()
+                if getattr(self, "_table_agents", None):
+                    self._upload_tables(self._table_agents)
+        self._handle.reset()
+        self._obs_cache = None
+        return self.get_sensor_data()
+
+    def mujoco_step(self):
+        self._handle.step_host(None, 1)
+        self._obs_cache = None
+
+    def _squeeze(self, arr):
+        return arr[0] if self.n_env == 1 else arr
+
+    def get_sensor_data(self, agent: str = None):
+        data = self._handle.get_field("sensordata")
+        if agent is None:
+            return self._squeeze(data)
+        picked = data[:, self.agents_observation_index[agent]["sensors"]]
+        return list(picked[0]) if self.n_env == 1 else picked
+
+    def get_observations(self, agent: str) -> np.ndarray:
+        """sensordata[idx] | qpos[idx] | qvel[idx] of one agent (mujoco_parent.py:380-392)."""
+        k = self._table_agents.index(agent)
+        if self._obs_cache is None:
+            # after a reset / external state change: one forward-only gather launch
+            index = self.agents_observation_index
+            sens, qpos, qvel = (self._handle.get_field(n) for n in ("sensordata", "qpos", "qvel"))
+            self._obs_cache = np.zeros((self.n_env, len(self._table_agents), self._handle.size("obs_dim")))
+            for j, a in enumerate(self._table_agents):
+                row = np.concatenate([sens[:, index[a]["sensors"]], qpos[:, index[a]["qpos"]], qvel[:, index[a]["qvel"]]], axis=1)
+                self._obs_cache[:, j, :row.shape[1]] = row
+        return self._squeeze(self._obs_cache[:, k, :self._obs_len[agent]].copy())
+
+    # ------------------------------------------------------------------ plugin query helpers
+    def get_data(self, name: str) -> dict:
+        """Body (xipos, mass, euler zyx deg) or geom record (mujoco_parent.py:394-426)."""
+        names = self._compiled.names
+        if name in names["body"]:
+            body = self.data.body(name)
+            xmat = np.asarray(body.xmat).reshape(-1, 9)
+            euler = np.stack([mat2euler_scipy(x) for x in xmat])
+            return {"position": body.xipos, "mass": self.model.body(name).mass, "orientation": self._squeeze(euler),
+                    "id": body.id, "name": name, "type": "body"}
+        if name in names["geom"]:
+            geom = self.data.geom(name)
+            xmat = np.asarray(geom.xmat).reshape(-1, 9)
+            euler = np.stack([mat2euler_scipy(x) for x in xmat])
+            mg = self.model.geom(name)
+            return {"position": geom.xpos, "orientation": self._squeeze(euler), "id": geom.id, "name": name,
+                    "type": "geom", "color": mg.rgba, "shape": mg.type}
+        raise KeyError(f"Invalid name '{name}'")
+
+    def distance(self, object_1, object_2):
+        """Euclidean distance between two objects given by name (body xipos, else geom xpos) or by coordinates
+        (mujoco_parent.py:428-449)."""
+        def coordinates(obj):
+            if isinstance(obj, str):
+                if obj in self._compiled.names["body"]:
+                    return np.asarray(self.data.body(obj).xipos)
+                return np.asarray(self.data.geom(obj).xpos)
+            return np.asarray(obj, dtype=np.float64)
+        a, b = coordinates(object_1), coordinates(object_2)
+        if a.ndim == 1 and b.ndim == 1:
+            return math.dist(a, b)
+        return np.linalg.norm(a - b, axis=-1)
+
+    def collision(self, geom_1, geom_2):
+        """True when the two geoms share a contact (mujoco_parent.py:451-478)."""
+        ids = []
+        for g in (geom_1, geom_2):
+            if isinstance(g, str):
+                if g not in self._compiled.names["geom"]:
+                    raise Exception(f"Collision object {g} not found in data")
+                g = self._compiled.names["geom"].index(g)
+            ids.append(int(g))
+        pairs = self._handle.query("contact_geom").astype(int)
+        hit = ((pairs[..., 0] == ids[0]) & (pairs[..., 1] == ids[1])) | ((pairs[..., 0] == ids[1]) & (pairs[..., 1] == ids[0]))
+        hit = hit.any(axis=1)
+        return bool(hit[0]) if self.n_env == 1 else hit
+
+    def get_camera_data(self, cam_object: str):
+        raise Exception("agent cameras need the ray-cast render entry, which this build does not provide yet")
+
+    def start_render(self):
+        raise Exception("interactive rendering is out of scope of the batched stepper")
+
+    def end_render(self):
+        self.render = False

@@ -1,0 +1,298 @@
+"""``MuJoCoRL``: the reference's multi-agent env surface (MuJoCo_Gym/mujoco_rl.py) over the batched stepper.
+
+Same ``config_dict`` keys and defaults (mujoco_rl.py:51-64), same ``reset()`` / ``step()`` return structure,
+same environmentDynamics / rewardFunctions / doneFunctions plugin contract (4-tuple ``dynamic``), same call
+order (dynamic-major, agent-minor; rewards after all dynamics; truncation before the counter moves).
+Extra keys: ``numEnvs`` (default 1), ``deviceId`` (default 0), ``nconmax`` / ``njmax``.
+
+With ``numEnvs == 1`` every value has the reference's shape, so the loops of
+benchmarking/different_env_configs/fps_benchmark.py:33-41 run unchanged.  With more copies each per-agent
+value gains a leading ``[numEnvs]`` axis and plugins are called once per (dynamic, agent) with batched views.
+``step_batched`` is the array-in / array-out path without per-agent dicts; it keeps everything in HBM when
+given torch CUDA tensors.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+import time
+
+import numpy as np
+
+from .helper import update_deep
+from .mujoco_parent import MuJoCoParent
+from .spaces import Box
+
+
+class MuJoCoRL(MuJoCoParent):
+    metadata = {"name": "mjrl_amd_v0"}
+
+    def __init__(self, config_dict: dict):
+        self.agents = config_dict.get("agents", [])
+        self.possible_agents = self.agents
+        self.xml_paths = config_dict.get("xmlPath")
+        self.info_jsons = config_dict.get("infoJson", None)
+        self.render_mode = config_dict.get("renderMode", False)
+        self.export_path = config_dict.get("exportPath")
+        self.free_joint = config_dict.get("freeJoint", False)
+        self.skip_frames = config_dict.get("skipFrames", 1)
+        self.max_steps = config_dict.get("maxSteps", 1024)
+        self.reward_functions = config_dict.get("rewardFunctions", [])
+        self.done_functions = config_dict.get("doneFunctions", [])
+        self.environment_dynamics = config_dict.get("environmentDynamics", [])
+        self.agent_cameras = config_dict.get("agentCameras", False)
+        sensor_resolution = config_dict.get("sensorResolution", (64, 64))
+
+        self.timestep = 0
+        self.start_time = time.time()
+        self.action_routing = {"physical": [], "dynamic": {}}
+        self.data_store = {agent: {} for agent in self.agents}
+
+        MuJoCoParent.__init__(self, xml_paths=self.xml_paths, export_path=self.export_path, render=self.render_mode,
+                              free_joint=self.free_joint, agent_cameras=self.agent_cameras,
+                              sensor_resolution=sensor_resolution, n_env=config_dict.get("numEnvs", 1),
+                              device_id=config_dict.get("deviceId", 0), nconmax=config_dict.get("nconmax"),
+                              njmax=config_dict.get("njmax"))
+        self._handle.set_max_steps(self.max_steps)
+        self._load_info_json()
+
+        self.environment_dynamics = [dynamic(self) for dynamic in self.environment_dynamics]
+        self._check_dynamics(self.environment_dynamics)
+        self._check_reward_functions(self.reward_functions)
+        self._check_done_functions(self.done_functions)
+
+        self._observation_space = self._create_observation_space()
+        self._first_observation_space = self._observation_space[list(self._observation_space.keys())[0]]
+        self._action_space = self._create_action_space()
+        self._first_action_space = self._action_space[list(self._action_space.keys())[0]]
+        self._upload_tables(self.agents)
+
+    # ------------------------------------------------------------------ construction helpers
+    def _load_info_json(self):
+        """mujoco_rl.py:93-112."""
+        path = None
+        if isinstance(self.info_jsons, list):
+            if len(self.info_jsons) != len(self.xml_paths):
+                raise Exception("Length mismatch between info_json list and xml_paths list")
+            stem = os.path.split(self.xml_path)[1].split(".")[0] + ".json"
+            path = [candidate for candidate in self.info_jsons if stem in candidate][0]
+        elif isinstance(self.info_jsons, str):
+            path = self.info_jsons
+        if path is None:
+            self.info_json, self.info_name_list = None, []
+            return
+        with open(path) as fh:
+            self.info_json = json.load(fh)
+        self.info_name_list = list(self.info_json["environment"]["objects"].keys())
+
+    def _check_dynamics(self, dynamics):
+        """Construction-time validation (mujoco_rl.py:114-143): one trial call per class with the lower action
+        bound; its side effects on ``data_store`` are kept, as in the reference."""
+        for instance in dynamics:
+            trial = instance.action_space["low"]
+            reward, observations, done, info = instance.dynamic(self.agents[0], trial)
+            low, high = instance.observation_space["low"], instance.observation_space["high"]
+            obs = np.asarray(observations)
+            width = obs.shape[-1] if obs.ndim else 1
+            if len(low) != width:
+                raise Exception(f"Observation, the second return variable of dynamic function, must match length"
+                                f" of lower bound of observation space of {instance}")
+            if not np.all(np.asarray(low) <= obs):
+                raise Exception(f"Observation, the second return variable of dynamic function, exceeds the lower bound"
+                                f" on at least one axis of the observation space of {instance}")
+            if len(high) != width:
+                raise Exception(f"Observation, the second return variable of dynamic function, must match length of"
+                                f" upper bound of observation space of {instance}")
+            if not np.all(np.asarray(high) >= obs):
+                raise Exception(f"Observation, the second return variable of dynamic function, exceeds the upper bound"
+                                f" on at least one axis of the observation space of {instance}")
+            if not (isinstance(reward, (float, int, np.floating, np.integer)) or
+                    (self.n_env > 1 and isinstance(reward, np.ndarray))):
+                raise Exception(f"Reward, the first return variable of dynamic function of {instance}, must be a float")
+
+    def _check_done_functions(self, done_functions):
+        for fn in done_functions:
+            done = fn(self, self.agents[0])
+            if not (isinstance(done, (int, bool, np.bool_, np.integer)) or (self.n_env > 1 and isinstance(done, np.ndarray))):
+                raise Exception(f"Done, the first return variable of {fn}, must be a boolean")
+
+    def _check_reward_functions(self, reward_functions):
+        for fn in reward_functions:
+            reward = fn(self, self.agents[0])
+            if not (isinstance(reward, (float, int, np.floating, np.integer)) or
+                    (self.n_env > 1 and isinstance(reward, np.ndarray))):
+                raise Exception(f"Reward, the second return variable of {fn}, must be a float")
+
+    def _create_action_space(self) -> dict:
+        """Physical actuators first, then one slice per dynamics class in list order (mujoco_rl.py:171-193)."""
+        spaces = {}
+        for agent in self.agents:
+            space = self.get_action_space_mujoco(agent)
+            self.action_routing["physical"] = [0, len(space["low"])]
+            for dynamic in self.environment_dynamics:
+                extra = dynamic.action_space
+                start = len(space["low"])
+                self.action_routing["dynamic"][dynamic.__class__.__name__] = [start, start + len(extra["low"])]
+                space["low"] += extra["low"]
+                space["high"] += extra["high"]
+            spaces[agent] = Box(low=np.array(space["low"]), high=np.array(space["high"]))
+        return spaces
+
+    def _create_observation_space(self) -> dict:
+        spaces = {}
+        for agent in self.agents:
+            space = self.get_observation_space_mujoco(agent)
+            for dynamic in self.environment_dynamics:
+                space["low"] += dynamic.observation_space["low"]
+                space["high"] += dynamic.observation_space["high"]
+            spaces[agent] = Box(low=np.array(space["low"]), high=np.array(space["high"]))
+        return spaces
+
+    # ------------------------------------------------------------------ plugin loop
+    def _apply_dynamics(self, action, observations, rewards, terminations, infos):
+        """Dynamic-major, agent-minor, strictly sequential: each call sees the data_store writes of the calls
+        before it (mujoco_rl.py:215-241)."""
+        for dynamic in self.environment_dynamics:
+            name = dynamic.__class__.__name__
+            lo, hi = self.action_routing["dynamic"][name]
+            for agent in self.agents:
+                act = np.asarray(action[agent])
+                reward, obs, done, info = dynamic.dynamic(agent, act[..., lo:hi])
+                obs = np.asarray(obs, dtype=np.float64)
+                if self.n_env > 1 and obs.ndim == 1:
+                    obs = np.broadcast_to(obs, (self.n_env, obs.shape[0]))
+                observations[agent] = np.concatenate((observations[agent], obs), axis=-1)
+                rewards[agent] = rewards[agent] + reward
+                terminations[agent] = np.logical_or(terminations[agent], done) if self.n_env > 1 else any([terminations[agent], done])
+                infos[agent][name] = info
+        return observations, rewards, terminations, infos
+
+    def _blank(self, value):
+        return value if self.n_env == 1 else np.full(self.n_env, value)
+
+    def step(self, action: dict):
+        """mujoco_rl.py:243-289."""
+        lo, hi = self.action_routing["physical"]
+        physical = {agent: np.asarray(action[agent])[..., lo:hi] for agent in action.keys()}
+        self.apply_action(physical, skip_frames=self.skip_frames)
+
+        observations = {agent: self.get_observations(agent) for agent in self.agents}
+        rewards = {agent: self._blank(0) for agent in self.agents}
+        terminations = {agent: self._blank(False) for agent in self.agents}
+        infos = {agent: {} for agent in self.agents}
+        observations, rewards, terminations, infos = self._apply_dynamics(action, observations, rewards, terminations, infos)
+
+        for reward_fn in self.reward_functions:
+            rewards = {agent: rewards[agent] + reward_fn(self, agent) for agent in self.agents}
+
+        truncations = self._check_truncations()
+
+        if len(self.done_functions) != 0:
+            for done_fn in self.done_functions:
+                if self.n_env == 1:
+                    terminations = {agent: any([terminations[agent], done_fn(self, agent)]) for agent in self.agents}
+                    terminations["__all__"] = any(terminations.values())
+                    if terminations["__all__"]:
+                        break
+                else:
+                    terminations = {agent: np.logical_or(terminations[agent], done_fn(self, agent)) for agent in self.agents}
+                    terminations["__all__"] = np.logical_or.reduce([terminations[a] for a in self.agents])
+                    if np.all(terminations["__all__"]):
+                        break
+
+        self.timestep += 1
+        return observations, rewards, terminations, truncations, infos
+
+    def reset(self, *, seed: int = None, options=None):
+        """mujoco_rl.py:291-331: reset the physics, clear the data store, run the dynamics once with a random
+        action so the observation has its full width, then discard what that pass wrote to the data store."""
+        MuJoCoParent.reset(self)
+        if isinstance(self.info_jsons, list):
+            self._load_info_json()
+        self.data_store = {agent: {} for agent in self.agents}
+
+        observations = {agent: self.get_observations(agent) for agent in self.agents}
+        sample = self._first_action_space.sample
+        action = {agent: (sample() if self.n_env == 1 else np.stack([sample() for _ in range(self.n_env)]))
+                  for agent in self.agents}
+        rewards = {agent: self._blank(0) for agent in self.agents}
+        terminations = {agent: self._blank(False) for agent in self.agents}
+        infos = {agent: {} for agent in self.agents}
+        copies = [copy.deepcopy(self.data_store) for _ in range(len(self.environment_dynamics))]
+        original = copy.deepcopy(self.data_store)
+        observations, rewards, terminations, infos = self._apply_dynamics(action, observations, rewards, terminations, infos)
+        self.data_store = original
+        for stored in copies:
+            self.data_store = update_deep(self.data_store, stored)
+        self.timestep = 0
+        return observations, infos
+
+    def _check_truncations(self) -> dict:
+        """mujoco_rl.py:406-417 (evaluated before ``timestep`` moves)."""
+        flag = self.timestep >= self.max_steps
+        truncations = {agent: self._blank(flag) for agent in self.agents}
+        truncations["__all__"] = self._blank(flag)
+        return truncations
+
+    # ------------------------------------------------------------------ spaces / info
+    def action_space(self, agent: str):
+        return self._action_space[agent]
+
+    def observation_space(self, agent: str):
+        return self._observation_space[agent]
+
+    def filter_by_tag(self, tag: str) -> list:
+        """mujoco_rl.py:355-378."""
+        found = []
+        groups = [self.info_json["environment"]["objects"]]
+        groups += [self.info_json["areas"][area]["objects"] for area in self.info_json.get("areas", {})]
+        for objects in groups:
+            for name, record in objects.items():
+                tags = record.get("tags") if isinstance(record, dict) else None
+                if tags is not None and tag in tags:
+                    found.append(self.get_data(name))
+        return found
+
+    def get_data(self, name: str) -> dict:
+        """mujoco_rl.py:380-395: physics record merged with the info-JSON attributes."""
+        data = MuJoCoParent.get_data(self, name)
+        if name in self.info_name_list:
+            for key, value in self.info_json["environment"]["objects"][name].items():
+                if key not in ("position", "orientation", "mass"):
+                    data[key] = value
+        return data
+
+    # ------------------------------------------------------------------ array path
+    def step_batched(self, actions, obs=None, reward=None, term=None, trunc=None):
+        """One step of every copy without per-agent dicts and without host plugins.
+
+        ``actions``: ``[numEnvs, n_agent, act_dim]`` float64, numpy array or torch CUDA tensor.  With torch
+        tensors nothing leaves HBM and the launch is asynchronous on the current torch stream; outputs are
+        torch tensors (pass preallocated ones to avoid allocations).  Returns ``(obs, reward, term, trunc)``.
+        """
+        if self.environment_dynamics or self.reward_functions or self.done_functions:
+            raise Exception("step_batched runs no host plugins; use step() or the fused dynamics vocabulary")
+        n_agent, obs_dim = len(self.agents), self._handle.size("obs_dim")
+        if isinstance(actions, np.ndarray):
+            actions = np.ascontiguousarray(actions, dtype=np.float64)
+            obs = np.zeros((self.n_env, n_agent, obs_dim)) if obs is None else obs
+            reward = np.zeros((self.n_env, n_agent)) if reward is None else reward
+            term = np.zeros((self.n_env, n_agent), np.uint8) if term is None else term
+            trunc = np.zeros((self.n_env, n_agent), np.uint8) if trunc is None else trunc
+            self._handle.step_host(actions, self.skip_frames, obs, reward, term, trunc)
+        else:
+            import torch
+            if not (actions.is_cuda and actions.dtype == torch.float64 and actions.is_contiguous()):
+                raise Exception("step_batched needs a contiguous float64 CUDA tensor")
+            dev = actions.device
+            obs = torch.empty((self.n_env, n_agent, obs_dim), dtype=torch.float64, device=dev) if obs is None else obs
+            reward = torch.empty((self.n_env, n_agent), dtype=torch.float64, device=dev) if reward is None else reward
+            term = torch.empty((self.n_env, n_agent), dtype=torch.uint8, device=dev) if term is None else term
+            trunc = torch.empty((self.n_env, n_agent), dtype=torch.uint8, device=dev) if trunc is None else trunc
+            self._handle.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            self._handle.step_device(actions.data_ptr(), actions.shape[-1], self.skip_frames, obs.data_ptr(),
+                                     reward.data_ptr(), term.data_ptr(), trunc.data_ptr())
+        self.timestep += 1
+        self._obs_cache = None
+        return obs, reward, term, trunc

@@ -1,0 +1,36 @@
+"""``__graft_entry__.smoke()``: one small invocation of the hot path on cuda:0, checked against the CPU oracle.
+
+The oracle is used here only as the checker (it is test infrastructure, see oracle/ora_math.h)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def run(n_env: int = 4, n_steps: int = 20):
+    from . import levels
+    from .mujoco_rl import MuJoCoRL
+    from oracle.oracle import OracleEnv
+
+    agents = ["sender", "receiver"]
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": agents, "numEnvs": n_env, "skipFrames": 1})
+    env.reset()
+    oracles = [OracleEnv(env._blob) for _ in range(n_env)]
+    rng = np.random.default_rng(0)
+    idx = env.agents_action_index
+    for _ in range(n_steps):
+        action = {a: rng.uniform(-1, 1, size=(n_env, 8)) for a in agents}
+        obs, rew, term, trunc, info = env.step(action)
+        for e, ora in enumerate(oracles):
+            for a in agents:
+                ora.ctrl[idx[a]] = action[a][e]
+            ora.step()
+    qpos = env._handle.get_field("qpos")
+    ref = np.stack([o.qpos for o in oracles])
+    err = np.abs(qpos - ref).max()
+    if not np.isfinite(err) or err > 1e-9:
+        raise AssertionError(f"HIP step differs from the oracle after {n_steps} steps: max |dqpos| = {err}")
+    expect = np.concatenate([oracles[0].sensordata[[0]], oracles[0].qpos, oracles[0].qvel])
+    if np.abs(obs["sender"][0] - expect).max() > 1e-9:
+        raise AssertionError("observation gather differs from sensordata|qpos|qvel of the oracle")
+    env.close()
+    return err
