@@ -1,0 +1,185 @@
+"""Headline benchmark: env-steps/sec of the batched 2-agent env step on N MI355X of one node.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched under
+``python -m torch.distributed.run`` with one rank per GPU.  A "step" is one step() of every env copy:
+action scatter -> skip_frames=1 physics step -> per-agent observation gather, one kernel launch per rank.
+The env batch shards across ranks (weak scaling: 4096 copies per GPU) with no collective on the step path;
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the timed region.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+ENVS_PER_GPU = 4096
+AGENTS = ["sender", "receiver"]
+LEVEL = "two_agent.xml"          # stand-in for the unshipped MultiEnvs.xml
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, MI355X_MICROARCH.md chip-level table
+
+
+def algorithmic_bytes_per_env_step(nq, nv, n_act_total, obs_total, n_agent, s=8):
+    """state in/out + warm start in/out + actions + observations + per-agent
+    reward/term/trunc.  fp64 state (s = 8): 2-agent level -> 2460 B."""
+    return s * (2 * nq + 2 * nv + 2 * nv + n_act_total + obs_total) + n_agent * (4 + 1 + 1)
+
+
+def action_stream(seed, first_env, n_env, n_steps, n_agent, act_dim):
+    """uniform(-1, 1) keyed on the GLOBAL env id, so a copy's trajectory does not depend on the GPU count."""
+    out = np.empty((n_steps, n_env, n_agent, act_dim), np.float64)
+    for e in range(n_env):
+        rng = np.random.Generator(np.random.Philox(key=seed, counter=[0, 0, 0, first_env + e]))
+        out[:, e] = rng.uniform(-1.0, 1.0, (n_steps, n_agent, act_dim))
+    return out
+
+
+def cpu_baseline(blob_bytes, scatter, seconds=8.0):
+    """The CPU oracle (kind "port": the repo's own fp64 restatement of the step; mujoco is not installed on the
+    box) timed on the host cores on a bounded sample of the same workload: one env copy per worker, the same
+    action distribution, for `seconds` of wall time; once single-threaded, once with one process per core."""
+    import multiprocessing as mp
+    from oracle.oracle import OracleEnv
+
+    def run_one(q, seed, duration):
+        env = OracleEnv(blob_bytes)
+        rng = np.random.default_rng(seed)
+        n = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < duration:
+            for _ in range(64):
+                act = rng.uniform(-1, 1, scatter.shape)
+                env.ctrl[scatter.reshape(-1)] = act.reshape(-1)
+                env.step()
+                # the reference's observation gather: sensordata | qpos | qvel per agent
+                for a in range(scatter.shape[0]):
+                    np.concatenate([env.sensordata[[a]], env.qpos, env.qvel])
+            n += 64
+            if env.time > 2.0:          # episode of 1024 steps ~ 2 s of sim time
+                env.reset()
+        q.put((n, time.perf_counter() - t0))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    run_one(q, 0, seconds)
+    n1, t1 = q.get()
+    cores = os.cpu_count() or 1
+    procs = [ctx.Process(target=run_one, args=(q, 100 + i, seconds)) for i in range(cores)]
+    for p in procs:
+        p.start()
+    results = [q.get() for _ in procs]
+    for p in procs:
+        p.join()
+    total = sum(n / t for n, t in results)
+    return {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (oracle/ora_step.c), {cores} processes x 1 env copy x {seconds:.0f} s of "
+                      f"{LEVEL} with uniform(-1,1) actions, step + numpy obs gather",
+            "single_thread": n1 / t1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    entry.load_package()
+    from mjrl_amd import levels
+    from mjrl_amd.mujoco_rl import MuJoCoRL
+
+    n_env = args.envs_per_gpu
+    env = MuJoCoRL({"xmlPath": levels.level_path(LEVEL), "agents": AGENTS, "numEnvs": n_env, "deviceId": local,
+                    "skipFrames": 1, "maxSteps": 1024})
+    env.reset()
+    n_agent, act_dim, obs_dim = len(AGENTS), 8, env._handle.size("obs_dim")
+    total_steps = args.warmup + args.steps
+    acts_host = action_stream(0, rank * n_env, n_env, total_steps, n_agent, act_dim)
+    acts = torch.from_numpy(acts_host).to(dev)                  # inputs resident in HBM before the timed region
+    obs = torch.empty((n_env, n_agent, obs_dim), dtype=torch.float64, device=dev)
+    rew = torch.empty((n_env, n_agent), dtype=torch.float64, device=dev)
+    term = torch.empty((n_env, n_agent), dtype=torch.uint8, device=dev)
+    trunc = torch.empty((n_env, n_agent), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    env._handle.set_stream(stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        env.step_batched(acts[i], obs, rew, term, trunc)
+    torch.cuda.synchronize(dev)
+    barrier()
+    # HIP events on the stream the step kernel is launched on
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.warmup, total_steps):
+        env.step_batched(acts[i], obs, rew, term, trunc)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if not torch.isfinite(obs).all().item():
+        raise SystemExit("non-finite observations after the timed region")
+
+    if rank == 0:
+        m = env._compiled
+        bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * obs_dim, n_agent)
+        achieved = bytes_per * n_env / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "env-steps/sec", "value": n_env * world * args.steps / wall, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"2-agent ant arena ({LEVEL} = benchmarking/levels/MultiAgentModel.xml, stand-in for the "
+                                   f"unshipped MultiEnvs.xml), {n_env} env copies per GPU, skipFrames=1, PGS solver, "
+                                   f"action scatter + physics step + per-agent obs gather fused in one launch",
+                       "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv, "obs_dim": obs_dim},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mjrl_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            scatter = np.array([env.agents_action_index[a] for a in AGENTS])
+            line["cpu_baseline"] = cpu_baseline(env._blob, scatter)
+        print(json.dumps(line), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

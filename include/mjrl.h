@@ -93,6 +93,11 @@ int mjrl_query(mjrl_env* env, const char* name, double* h_out, size_t nbytes);
 int mjrl_step_debug(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames, int stage,
                     double* h_dump, size_t nbytes);
 int mjrl_lds_offset(const mjrl_env* env, const char* region);
+/* Diagnostic: one step with per-stage wave-clock stamps; h_cycles[n] receives, per stage, the cycles summed
+ * over all env copies (stage order: load kin com crb factor geom collide vel smooth rows project pgs sensors
+ * euler store; n must be 15). */
+int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
+                      unsigned long long* h_cycles, int n);
 
 #ifdef __cplusplus
 }

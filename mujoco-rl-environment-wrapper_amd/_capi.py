@@ -18,7 +18,7 @@ SYMBOLS = [
     "mjrl_version", "mjrl_last_error", "mjrl_create", "mjrl_destroy", "mjrl_set_stream", "mjrl_sync",
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
-    "mjrl_lds_offset",
+    "mjrl_lds_offset", "mjrl_step_profile",
 ]
 
 _lib = None
@@ -57,6 +57,7 @@ def load():
     L.mjrl_query.argtypes = [vp, ctypes.c_char_p, vp, sz]
     L.mjrl_step_debug.argtypes = [vp, vp, ci, ci, ci, vp, sz]
     L.mjrl_lds_offset.argtypes = [vp, ctypes.c_char_p]
+    L.mjrl_step_profile.argtypes = [vp, vp, ci, ci, vp, ci]
     _lib = L
     return L
 
@@ -170,6 +171,14 @@ class Handle:
         out = np.zeros((self.n_env,) + shape, np.float64)
         self._check(self._lib.mjrl_query(self._h, name.encode(), _host_ptr(out), out.nbytes))
         return out
+
+    STAGES = ["load", "kin", "com", "crb", "factor", "geom", "collide", "vel", "smooth", "rows", "project", "pgs",
+              "sensors", "euler", "store"]
+
+    def step_profile(self, skip_frames=1):
+        out = np.zeros(len(self.STAGES), np.uint64)
+        self._check(self._lib.mjrl_step_profile(self._h, None, 0, int(skip_frames), _host_ptr(out), out.size))
+        return dict(zip(self.STAGES, out.tolist()))
 
     def step_debug(self, d_actions, act_dim, skip_frames, stage=0):
         out = np.zeros((self.n_env, self.size("lds_doubles")), np.float64)

@@ -18,11 +18,11 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 5
+VERSION = 7
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
-               "ndesc", "nchild", "maxdofdepth", "pair_kmax"]
+               "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "reserved0"]
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
@@ -42,6 +42,7 @@ F64_FIELDS = [
     ("cam_pos", "ncam*3"), ("cam_quat", "ncam*4"), ("cam_fovy", "ncam"),
     ("act_gear", "nu"), ("act_ctrlrange", "nu*2"),
     ("sensor_cutoff", "nsensor"),
+    ("pair_margin", "npair"), ("pair_bound", "npair"),
 ]
 I32_FIELDS = [
     ("body_parentid", "nbody"), ("body_rootid", "nbody"), ("body_weldid", "nbody"), ("body_jntnum", "nbody"),
@@ -58,6 +59,8 @@ I32_FIELDS = [
     ("pair_geom", "npair*2"),
     ("M_rowid", "nM"), ("M_colid", "nM"), ("dof_descadr", "nv"), ("dof_descnum", "nv"), ("desc_Madr", "ndesc"),
     ("body_childadr", "nbody"), ("body_childnum", "nbody"), ("body_childid", "nchild"), ("tree_rootbody", "ntree"),
+    ("body_subtreenum", "nbody"), ("tree_dofadr", "ntree"), ("tree_dofnum", "ntree"),
+    ("desc_row", "ndesc"), ("M_coldiag", "nM"), ("dof_actid", "nv"),
 ]
 
 
@@ -71,6 +74,7 @@ def _sizes(model) -> dict:
         t = (int(model.geom_type[g1]), int(model.geom_type[g2]))
         kmax = max(kmax, {(0, 3): 2, (0, 6): 8, (3, 3): 4, (3, 6): 2}.get(t, 1))
     s["pair_kmax"] = kmax
+    s["reserved0"] = 0
     return s
 
 

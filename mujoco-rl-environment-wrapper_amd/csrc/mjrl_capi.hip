@@ -71,7 +71,7 @@ struct mjrl_env {
 
 extern "C" {
 
-const char* mjrl_version(void) { return "mjrl-hip 0.1 (blob layout 5, gfx950)"; }
+const char* mjrl_version(void) { return "mjrl-hip 0.2 (blob layout 7, gfx950)"; }
 
 const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 
@@ -101,7 +101,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   int rc = mjrl_model_from_blob(&e->hm, e->h_blob.data(), nbytes, e->h_blob.data());
   if (rc) return fail(2, "mjrl_create: model blob rejected (magic/version/size), code " + std::to_string(rc));
   const DevModel& m = e->hm;
-  if (m.nbody > 64 * 4 || m.nv > 64 || m.nv < 1) return fail(3, "mjrl_create: needs 1 <= nv <= 64 (one dof per lane)");
+  if (m.nv < 1 || m.nv > 64 || m.nbody > 64 || m.njnt > 64 || m.ngeom > 64)
+    return fail(3, "mjrl_create: the model must fit one wavefront (1 <= nv <= 64; nbody, njnt, ngeom <= 64)");
   if (m.maxdofdepth + 1 > mj::MAX_DOF_DEPTH) return fail(3, "mjrl_create: kinematic chains deeper than 8 dofs are not supported");
   if (m.nconmax > 64 || m.nconmax < 1) return fail(3, "mjrl_create: nconmax must be in 1..64");
   if (m.pair_kmax != 1 && m.pair_kmax != 2 && m.pair_kmax != 4 && m.pair_kmax != 8) return fail(3, "mjrl_create: bad pair_kmax");
@@ -226,8 +227,8 @@ int mjrl_lds_offset(const mjrl_env* e, const char* region) {
   const mj::Lay& l = e->lay;
 #define R(name) if (!strcmp(region, #name)) return l.name;
   R(qpos) R(qvel) R(ctrl) R(warm) R(xpos) R(xquat) R(xanchor) R(xaxis) R(com) R(cinert) R(crb) R(cdof) R(cdofdot)
-  R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gmat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
-  R(sens) R(ints) R(total) R(i_cand) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid)
+  R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gquat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
+  R(sens) R(ints) R(total) R(i_item) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid)
 #undef R
   return -1;
 }
@@ -251,7 +252,8 @@ static int ensure_scatter(mjrl_env* e, int act_dim) {
 
 // mode: 0 = full step; 1 = forward pass only (no integration, no counters): reset observations and queries
 static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
-                       uint8_t* d_term, uint8_t* d_trunc, double* d_dbg, int dbg_stage, int forward_only) {
+                       uint8_t* d_term, uint8_t* d_trunc, double* d_dbg, int dbg_stage, int forward_only,
+                       unsigned long long* d_stamps = nullptr) {
   if (skip_frames < 0) MJRL_FAIL(e, 3, "step: skip_frames must be >= 0");
   if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "step: observations requested but no gather table is set");
   mj::StepArgs a{};
@@ -269,6 +271,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.max_steps = e->max_steps; a.skip_frames = skip_frames; a.n_env = e->n_env;
   a.dbg = d_dbg; a.dbg_stage = dbg_stage;
   a.forward_only = forward_only;
+  a.stamps = d_stamps;
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
   hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, a);
   MJRL_HIP(e, hipGetLastError());
@@ -380,6 +383,22 @@ int mjrl_step_debug(mjrl_env* e, const double* d_actions, int act_dim, int skip_
   return 0;
 }
 
+int mjrl_step_profile(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, unsigned long long* h_cycles,
+                      int n) {
+  if (n != mj::N_STAMPS) MJRL_FAIL(e, 4, "step_profile: expected room for %d stage counters, got %d", (int)mj::N_STAMPS, n);
+  unsigned long long* d = nullptr;
+  MJRL_HIP(e, hipMalloc(&d, sizeof(unsigned long long) * n));
+  MJRL_HIP(e, hipMemsetAsync(d, 0, sizeof(unsigned long long) * n, e->stream));
+  int rc = launch_step(e, d_actions, act_dim, skip_frames, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, d);
+  if (!rc) {
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(h_cycles, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { e->err = hipGetErrorString(he); rc = 100 + (int)he; }
+  }
+  hipFree(d);
+  return rc;
+}
+
 int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
   const DevModel& m = e->hm;
   const mj::Lay& l = e->lay;
@@ -390,11 +409,11 @@ int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
   MJRL_HIP(e, hipMemcpy(img.data(), e->dbg, sizeof(double) * img.size(), hipMemcpyDeviceToHost));
   size_t per = 0;
   int off = 0;
-  enum { PLAIN, XIPOS, NCON, CONGEOM } kind = PLAIN;
+  enum { PLAIN, XIPOS, NCON, CONGEOM, GMAT } kind = PLAIN;
   if (!strcmp(name, "xpos")) { per = 3 * m.nbody; off = l.xpos; }
   else if (!strcmp(name, "xquat")) { per = 4 * m.nbody; off = l.xquat; }
   else if (!strcmp(name, "geom_xpos")) { per = 3 * m.ngeom; off = l.gpos; }
-  else if (!strcmp(name, "geom_xmat")) { per = 9 * m.ngeom; off = l.gmat; }
+  else if (!strcmp(name, "geom_xmat")) { per = 9 * m.ngeom; kind = GMAT; }
   else if (!strcmp(name, "xipos")) { per = 3 * m.nbody; kind = XIPOS; }
   else if (!strcmp(name, "ncon")) { per = 1; kind = NCON; }
   else if (!strcmp(name, "contact_geom")) { per = 2 * m.nconmax; kind = CONGEOM; }
@@ -411,6 +430,15 @@ int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
         bool live = c < I[mj::I_NCON];
         o[2 * c] = live ? I[l.i_cong1 + c] : -1;
         o[2 * c + 1] = live ? I[l.i_cong2 + c] : -1;
+      }
+    } else if (kind == GMAT) {
+      for (int g = 0; g < m.ngeom; g++) {
+        const double* q = S + l.gquat + 4 * g;
+        double w = q[0], x = q[1], y = q[2], z = q[3];
+        double r[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
+                       2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
+                       2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
+        memcpy(o + 9 * g, r, sizeof(r));
       }
     } else {
       for (int b = 0; b < m.nbody; b++) {

@@ -7,10 +7,10 @@
 // with all intermediate state (body frames, spatial inertias, mass matrix and its L'DL factor,
 // contacts, constraint rows) held in LDS; HBM sees only state-in / state-out.
 //
-// Lane mappings change from stage to stage (lane = body, joint, dof, geom, candidate pair item,
-// constraint row); stages exchange data through LDS and are separated by wv::sync().
-// Arithmetic follows MuJoCo's documented pipeline; where a sum's order matters for reproducing the
-// CPU oracle bit-for-bit it is noted at the loop.
+// Lane mappings change from stage to stage (lane = body, joint, dof, geom, narrow-phase work item,
+// constraint row); stages exchange data through LDS and are separated by wv::sync().  Per-lane model
+// constants (the lane's body / dof record) are read from HBM once per launch into registers (LaneK).
+// The model must fit one wave: nbody, njnt, nv, ngeom <= 64 (checked by mjrl_create).
 #ifndef MJRL_STEP_H
 #define MJRL_STEP_H
 
@@ -26,40 +26,48 @@ enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_RANGEFINDER = 2, SENS_FRAMEX
 
 // per-contact record in LDS (doubles)
 enum { CON_DIST = 0, CON_POS = 1, CON_FRAME = 4, CON_INCL = 13, CON_MU = 14, CON_STRIDE = 16 };
-// per-row record in LDS (doubles)
-enum { ROW_R = 0, ROW_AREF = 1, ROW_B = 2, ROW_F = 3, ROW_ARII = 4, ROW_POS = 5, ROW_MARGIN = 6, ROW_STRIDE = 8 };
+// per-row record in LDS (doubles); ROW_F doubles as the constraint position until the row is built
+enum { ROW_R = 0, ROW_B = 1, ROW_F = 2, ROW_ARII = 3, ROW_ARINV = 4, ROW_STRIDE = 5 };
 // integer header of the int region
-enum { I_NCON = 0, I_NEFC = 1, I_NLIM = 2, I_NITER = 3, I_WARN = 4, I_NCAND = 5, I_HEAD = 8 };
-enum { CAND_MAX = 256, MAX_DOF_DEPTH = 8 };
+enum { I_NCON = 0, I_NEFC = 1, I_NLIM = 2, I_NITER = 3, I_WARN = 4, I_NITEM = 5, I_HEAD = 8 };
+enum { ITEM_MAX = 256, MAX_DOF_DEPTH = 8 };
 
-// LDS layout of one env copy, offsets in doubles from the env's base
+// LDS layout of one env copy, offsets in doubles from the env's base.  The block `u` is shared by two
+// lifetimes: {xanchor, xaxis, cinert, crb} live from the kinematics to the end of the bias forces,
+// {J, row} from the constraint-row build to the sensors.
 struct Lay {
-  int qpos, qvel, ctrl, warm, xpos, xquat, xanchor, xaxis, com, cinert, crb, cdof, cdofdot, cvel, cacc, M, LD, Dinv,
-      gpos, gmat, bias, smooth, qaccs, x, qfc, qacc, con, J, row, sens, ints, total;
-  int ldj;                                   // row stride of J (odd -> conflict-free column walks)
-  int i_cand, i_cong1, i_cong2, i_conadr, i_rowid;   // offsets inside the int region (in ints)
+  int qpos, qvel, ctrl, warm, xpos, xquat, com, cdof, cdofdot, cvel, cacc, M, LD, Dinv, gpos, gquat, bias, smooth, qaccs,
+      x, qfc, qacc, con, sens, ints, u, total;
+  int xanchor, xaxis, cinert, crb;   // inside u, first lifetime
+  int J, row;                        // inside u, second lifetime
+  int ldj;                           // row stride of J (odd -> conflict-free column walks)
+  int i_item, i_cong1, i_cong2, i_conadr, i_rowid;   // offsets inside the int region (in ints)
 };
 
 __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   int o = 0;
 #define REG(name, n) l.name = o; o += (n);
   REG(qpos, m.nq) REG(qvel, m.nv) REG(ctrl, m.nu) REG(warm, m.nv)
-  REG(xpos, 3 * m.nbody) REG(xquat, 4 * m.nbody) REG(xanchor, 3 * m.njnt) REG(xaxis, 3 * m.njnt)
-  REG(com, 3 * (m.ntree + 1)) REG(cinert, 10 * m.nbody) REG(crb, 10 * m.nbody)
+  REG(xpos, 3 * m.nbody) REG(xquat, 4 * m.nbody) REG(com, 3 * (m.ntree + 1))
   REG(cdof, 6 * m.nv) REG(cdofdot, 6 * m.nv) REG(cvel, 6 * m.nbody) REG(cacc, 6 * m.nbody)
   REG(M, m.nM) REG(LD, m.nM) REG(Dinv, m.nv)
-  REG(gpos, 3 * m.ngeom) REG(gmat, 9 * m.ngeom)
+  REG(gpos, 3 * m.ngeom) REG(gquat, 4 * m.ngeom)
   REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(x, m.nv) REG(qfc, m.nv) REG(qacc, m.nv)
-  REG(con, CON_STRIDE * m.nconmax)
-  l.ldj = (m.nv | 1);
-  REG(J, l.ldj * m.njmax) REG(row, ROW_STRIDE * m.njmax) REG(sens, m.nsensordata + 1)
+  REG(con, CON_STRIDE * m.nconmax) REG(sens, m.nsensordata + 1)
   int ni = I_HEAD;
-  l.i_cand = ni; ni += CAND_MAX;
+  l.i_item = ni; ni += ITEM_MAX;
   l.i_cong1 = ni; ni += m.nconmax;
   l.i_cong2 = ni; ni += m.nconmax;
   l.i_conadr = ni; ni += m.nconmax;
   l.i_rowid = ni; ni += m.njmax;
   REG(ints, (ni + 1) / 2)
+  l.u = o;
+  l.xanchor = o; l.xaxis = l.xanchor + 3 * m.njnt; l.cinert = l.xaxis + 3 * m.njnt; l.crb = l.cinert + 10 * m.nbody;
+  int first = 6 * m.njnt + 20 * m.nbody;
+  l.ldj = (m.nv | 1);
+  l.J = o; l.row = l.J + l.ldj * m.njmax;
+  int second = l.ldj * m.njmax + ROW_STRIDE * m.njmax;
+  o += first > second ? first : second;
 #undef REG
   l.total = o;
 }
@@ -84,44 +92,52 @@ struct StepArgs {
   real* dbg;                 // [n_env][lay.total], may be null
   int dbg_stage;             // 0: end of forward pass; 1: right after the constraint rows are built
   int forward_only;          // 1: mj_forward semantics -- no integration, no counters (reset observations, queries)
+  unsigned long long* stamps;   // diagnostic: per-stage wave-clock sums over all env copies [N_STAMPS], may be null
 };
 
-#define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
+enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_VEL, ST_SMOOTH, ST_ROWS, ST_PROJECT, ST_PGS,
+       ST_SENSORS, ST_EULER, ST_STORE, N_STAMPS };
 
-// child -> parent accumulation of `n` numbers per body (row stride `stride`), deepest level first; every parent
-// adds its children in descending id, the order a backward sweep over bodies meets them.
-__device__ inline void tree_accumulate(const DevModel& m, real* buf, int stride, int n, bool include_world, int L) {
-  for (int lev = m.maxdepth; lev >= 1; lev--) {
-    MJ_FOR(b, m.nbody) {
-      if (m.body_depth[b] == lev - 1 && m.body_childnum[b] > 0 && (b > 0 || include_world)) {
-        int adr = m.body_childadr[b], num = m.body_childnum[b];
-        for (int c = 0; c < num; c++) {
-          int child = m.body_childid[adr + c];
-          for (int k = 0; k < n; k++) buf[b * stride + k] += buf[child * stride + k];
-        }
-      }
-    }
-    wv::sync();
-  }
+// The lane's own records of the model, fetched once per launch
+struct LaneK {
+  // lane as body
+  int b_parent, b_depth, b_tree, b_dofadr, b_dofnum, b_jntadr, b_jntnum, b_subnum;
+  real b_mass;
+  // lane as dof
+  int d_parent, d_Madr, d_depth, d_body, d_descadr, d_descnum, d_act;
+  real d_damping, d_armature;
+};
+
+__device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
+  bool isb = L < m.nbody, isd = L < m.nv;
+  int b = isb ? L : 0, d = isd ? L : 0;
+  k.b_parent = m.body_parentid[b]; k.b_depth = isb ? m.body_depth[b] : -1; k.b_tree = m.body_treeid[b];
+  k.b_dofadr = m.body_dofadr[b]; k.b_dofnum = isb ? m.body_dofnum[b] : 0; k.b_jntadr = m.body_jntadr[b];
+  k.b_jntnum = isb ? m.body_jntnum[b] : 0; k.b_subnum = m.body_subtreenum[b]; k.b_mass = m.body_mass[b];
+  k.d_parent = m.dof_parentid[d]; k.d_Madr = m.dof_Madr[d]; k.d_depth = isd ? m.dof_depth[d] : -1;
+  k.d_body = m.dof_bodyid[d]; k.d_descadr = m.dof_descadr[d]; k.d_descnum = isd ? m.dof_descnum[d] : 0;
+  k.d_act = isd ? m.dof_actid[d] : -1; k.d_damping = m.dof_damping[d]; k.d_armature = m.dof_armature[d];
 }
 
 // ------------------------------------------------------------------ position stage
-__device__ inline void stage_kinematics(const DevModel& m, const Lay& l, real* S, int L) {
+__device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
   if (L == 0) {
     st3(S + l.xpos, v3(0, 0, 0));
     Quat q; q.w = 1; q.x = q.y = q.z = 0;
     stq(S + l.xquat, q);
   }
+  // everything that does not depend on the parent's frame is fetched before the level loop
+  V3 bpos = ld3(m.body_pos + 3 * (L < m.nbody ? L : 0));
+  Quat bquat = ldq(m.body_quat + 4 * (L < m.nbody ? L : 0));
   wv::sync();
   for (int lev = 1; lev <= m.maxdepth; lev++) {
-    MJ_FOR(b, m.nbody) {
-      if (m.body_depth[b] != lev) continue;
-      int p = m.body_parentid[b];
+    if (K.b_depth == lev) {
+      int b = L, p = K.b_parent;
       Quat pq = ldq(S + l.xquat + 4 * p);
-      V3 pos = ld3(S + l.xpos + 3 * p) + rot(pq, ld3(m.body_pos + 3 * b));
-      Quat quat = qmul(pq, ldq(m.body_quat + 4 * b));
-      for (int k = 0; k < m.body_jntnum[b]; k++) {
-        int j = m.body_jntadr[b] + k, qa = m.jnt_qposadr[j];
+      V3 pos = ld3(S + l.xpos + 3 * p) + rot(pq, bpos);
+      Quat quat = qmul(pq, bquat);
+      for (int k = 0; k < K.b_jntnum; k++) {
+        int j = K.b_jntadr + k, qa = m.jnt_qposadr[j];
         V3 jaxis = ld3(m.jnt_axis + 3 * j), jpos = ld3(m.jnt_pos + 3 * j);
         if (m.jnt_type[j] == JNT_FREE) {
           pos = ld3(S + l.qpos + qa);
@@ -150,42 +166,39 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, real* S
   }
 }
 
-__device__ inline V3 body_xipos(const DevModel& m, const Lay& l, const real* S, int b) {
-  return ld3(S + l.xpos + 3 * b) + rot(ldq(S + l.xquat + 4 * b), ld3(m.body_ipos + 3 * b));
-}
-
-__device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, real* S, int L) {
-  // mass-weighted centres, accumulated up the tree exactly like a backward body sweep would
-  MJ_FOR(b, m.nbody) {
-    V3 xi = b ? body_xipos(m, l, S, b) : v3(0, 0, 0);
-    st3(S + l.crb + 10 * b, xi * m.body_mass[b]);
+__device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+  // mass-weighted centres of mass; a tree's bodies are the id range of its root (depth-first numbering)
+  V3 xi = v3(0, 0, 0);
+  Quat q; q.w = 1; q.x = q.y = q.z = 0;
+  if (L > 0 && L < m.nbody) {
+    q = ldq(S + l.xquat + 4 * L);
+    xi = ld3(S + l.xpos + 3 * L) + rot(q, ld3(m.body_ipos + 3 * L));
+    st3(S + l.crb + 10 * L, xi * K.b_mass);
   }
   wv::sync();
-  tree_accumulate(m, S + l.crb, 10, 3, true, L);
-  MJ_FOR(t, m.ntree) {
-    int root = m.tree_rootbody[t];
+  if (L < 3 * m.ntree) {
+    int t = L / 3, k = L % 3, root = m.tree_rootbody[t], n = m.body_subtreenum[root];
+    real acc = 0;
+    for (int c = root; c < root + n; c++) acc += S[l.crb + 10 * c + k];
     real mass = m.body_subtreemass[root];
-    V3 c = mass < MJ_MINVAL ? body_xipos(m, l, S, root) : ld3(S + l.crb + 10 * root) * (1.0 / mass);
-    st3(S + l.com + 3 * t, c);
+    S[l.com + 3 * t + k] = mass < MJ_MINVAL ? S[l.xpos + 3 * root + k] : acc / mass;
   }
+  if (L < 3) S[l.com + 3 * m.ntree + L] = 0;
   wv::sync();
   // body inertias about their tree's centre of mass
-  MJ_FOR(b, m.nbody) {
+  if (L < m.nbody) {
     real ci[10];
-    int t = m.body_treeid[b];
-    if (b == 0 || t < 0) {
+    if (L == 0 || K.b_tree < 0) {
       for (int k = 0; k < 10; k++) ci[k] = 0;
     } else {
-      Quat q = ldq(S + l.xquat + 4 * b);
-      V3 xi = ld3(S + l.xpos + 3 * b) + rot(q, ld3(m.body_ipos + 3 * b));
-      M3 ximat = qmat(qmul(q, ldq(m.body_iquat + 4 * b)));
-      inert_com(ci, m.body_inertia + 3 * b, ximat, xi - ld3(S + l.com + 3 * t), m.body_mass[b]);
+      M3 ximat = qmat(qmul(q, ldq(m.body_iquat + 4 * L)));
+      inert_com(ci, m.body_inertia + 3 * L, ximat, xi - ld3(S + l.com + 3 * K.b_tree), K.b_mass);
     }
-    for (int k = 0; k < 10; k++) { S[l.cinert + 10 * b + k] = ci[k]; S[l.crb + 10 * b + k] = ci[k]; }
+    for (int k = 0; k < 10; k++) S[l.cinert + 10 * L + k] = ci[k];
   }
   // joint motion axes in the same frame
-  MJ_FOR(j, m.njnt) {
-    int b = m.jnt_bodyid[j], da = m.jnt_dofadr[j];
+  if (L < m.njnt) {
+    int j = L, b = m.jnt_bodyid[j], da = m.jnt_dofadr[j];
     V3 off = ld3(S + l.com + 3 * m.body_treeid[b]) - ld3(S + l.xanchor + 3 * j);
     if (m.jnt_type[j] == JNT_FREE) {
       M3 xm = qmat(ldq(S + l.xquat + 4 * b));
@@ -209,84 +222,97 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, real* 
   wv::sync();
 }
 
-__device__ inline void stage_crb(const DevModel& m, const Lay& l, real* S, int L) {
-  tree_accumulate(m, S + l.crb, 10, 10, false, L);
-  MJ_FOR(i, m.nv) {
+__device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+  // composite inertia of every body that carries dofs: sum of cinert over its subtree (an id range)
+  if (L > 0 && L < m.nbody && K.b_dofnum > 0) {
+    real acc[10];
+    for (int k = 0; k < 10; k++) acc[k] = S[l.cinert + 10 * L + k];
+    for (int c = L + 1; c < L + K.b_subnum; c++)
+      for (int k = 0; k < 10; k++) acc[k] += S[l.cinert + 10 * c + k];
+    for (int k = 0; k < 10; k++) S[l.crb + 10 * L + k] = acc[k];
+  }
+  wv::sync();
+  if (L < m.nv) {
     real buf[6], c[6], crb[10];
-    int b = m.dof_bodyid[i];
-    for (int k = 0; k < 10; k++) crb[k] = S[l.crb + 10 * b + k];
-    for (int k = 0; k < 6; k++) c[k] = S[l.cdof + 6 * i + k];
+    for (int k = 0; k < 10; k++) crb[k] = S[l.crb + 10 * K.d_body + k];
+    for (int k = 0; k < 6; k++) c[k] = S[l.cdof + 6 * L + k];
     inert_mul(buf, crb, c);
-    int adr = m.dof_Madr[i];
-    bool diag = true;
-    for (int j = i; j >= 0; j = m.dof_parentid[j]) {
+    for (int t = 0; t <= K.d_depth; t++) {
+      int j = m.M_colid[K.d_Madr + t];
       real cj[6];
       for (int k = 0; k < 6; k++) cj[k] = S[l.cdof + 6 * j + k];
       real v = dot6(cj, buf);
-      if (diag) { v = m.dof_armature[i] + v; diag = false; }
-      S[l.M + adr] = v;
-      S[l.LD + adr] = v;
-      adr++;
+      if (t == 0) v = K.d_armature + v;
+      S[l.M + K.d_Madr + t] = v;
+      S[l.LD + K.d_Madr + t] = v;
     }
   }
   wv::sync();
 }
 
-// in-place sparse L'DL of the matrix at S[ld..] (dof_Madr layout), Featherstone order; dinv gets 1/D
+// In-place sparse L'DL of the matrix at S[ld..] (dof_Madr layout), Featherstone order inside every kinematic tree.
+// Trees are independent, so up to two of them are eliminated side by side (32 lanes each); inside a tree the
+// lanes cover the (ancestor a, offset t) pairs of the pivot row.  dinv gets 1/D.
 __device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, int L) {
-  for (int k = m.nv - 1; k >= 0; k--) {
-    int D = m.dof_depth[k], kk = m.dof_Madr[k];
-    int a = L / MAX_DOF_DEPTH, t = L % MAX_DOF_DEPTH;
-    bool valid = a < D && t < D - a;
-    real tmp = 0, val = 0;
-    int ij = 0, ki = kk + 1 + a;
-    if (valid) {
-      int i = m.M_colid[ki];
-      tmp = S[ld + ki] / S[ld + kk];
-      ij = m.dof_Madr[i];
-      val = S[ld + ij + t] - tmp * S[ld + ki + t];
+  const int groups = m.ntree > 1 ? 2 : 1, width = 64 / groups;
+  const int g = L / width, p = L % width;
+  for (int t0 = 0; t0 < m.ntree; t0 += groups) {
+    int tree = t0 + g;
+    bool has_tree = tree < m.ntree;
+    int adr0 = has_tree ? m.tree_dofadr[tree] : 0, num = has_tree ? m.tree_dofnum[tree] : 0;
+    for (int kk = m.maxtreedof - 1; kk >= 0; kk--) {
+      bool live = kk < num;
+      int k = adr0 + (live ? kk : 0);
+      int D = live ? m.dof_depth[k] : 0, kkadr = m.dof_Madr[k];
+      // decode p -> (a, t) over the triangle t < D - a
+      int a = 0, rem = p;
+      while (a < D && rem >= D - a) { rem -= D - a; a++; }
+      bool valid = live && a < D;
+      int t = rem, ki = kkadr + 1 + a;
+      real tmp = 0, val = 0;
+      int ij = 0;
+      if (valid) {
+        ij = m.M_coldiag[ki];
+        tmp = S[ld + ki] / S[ld + kkadr];
+        val = S[ld + ij + t] - tmp * S[ld + ki + t];
+      }
+      wv::sync();
+      if (valid) {
+        S[ld + ij + t] = val;
+        if (t == 0) S[ld + ki] = tmp;
+      }
+      if (live && p == 0) S[dinv + k] = 1.0 / S[ld + kkadr];
+      wv::sync();
     }
-    wv::sync();
-    if (valid) {
-      S[ld + ij + t] = val;
-      if (t == 0) S[ld + ki] = tmp;
-    }
-    if (L == 0) S[dinv + k] = 1.0 / S[ld + kk];
-    wv::sync();
   }
 }
 
-// x <- M^-1 x with the factor at ld/dinv; x lives in LDS at S[x..x+nv).  Level-parallel over dof depth; every
-// dof applies its terms in the order the serial sweeps would (descendants descending, ancestors walking up).
-__device__ inline void solve_ld(const DevModel& m, real* S, int ld, int dinv, int x, int L, bool backward, bool scale,
-                                bool forward) {
+// x <- (selected factors of) M^-1 x with the factor at ld/dinv; x lives in LDS at S[x..x+nv).  Level-parallel over
+// dof depth; every dof applies its terms in the order the serial sweeps would (descendants descending, ancestors
+// walking up).
+__device__ inline void solve_ld(const DevModel& m, const LaneK& K, real* S, int ld, int dinv, int x, int L, bool backward,
+                                bool scale, bool forward) {
   if (backward) {
     for (int lev = m.maxdofdepth - 1; lev >= 0; lev--) {
-      MJ_FOR(i, m.nv) {
-        if (m.dof_depth[i] != lev) continue;
-        int adr = m.dof_descadr[i], num = m.dof_descnum[i];
-        real xi = S[x + i];
-        for (int c = num - 1; c >= 0; c--) {
-          int e = m.desc_Madr[adr + c];
-          xi -= S[ld + e] * S[x + m.M_rowid[e]];
-        }
-        S[x + i] = xi;
+      if (K.d_depth == lev && K.d_descnum > 0) {
+        real xi = S[x + L];
+        for (int c = K.d_descnum - 1; c >= 0; c--)
+          xi -= S[ld + m.desc_Madr[K.d_descadr + c]] * S[x + m.desc_row[K.d_descadr + c]];
+        S[x + L] = xi;
       }
       wv::sync();
     }
   }
   if (scale) {
-    MJ_FOR(i, m.nv) S[x + i] *= S[dinv + i];
+    if (L < m.nv) S[x + L] *= S[dinv + L];
     wv::sync();
   }
   if (forward) {
     for (int lev = 1; lev <= m.maxdofdepth; lev++) {
-      MJ_FOR(i, m.nv) {
-        if (m.dof_depth[i] != lev) continue;
-        int adr = m.dof_Madr[i] + 1;
-        real xi = S[x + i];
-        for (int j = m.dof_parentid[i]; j >= 0; j = m.dof_parentid[j]) xi -= S[ld + adr++] * S[x + j];
-        S[x + i] = xi;
+      if (K.d_depth == lev) {
+        real xi = S[x + L];
+        for (int t = 1; t <= K.d_depth; t++) xi -= S[ld + K.d_Madr + t] * S[x + m.M_colid[K.d_Madr + t]];
+        S[x + L] = xi;
       }
       wv::sync();
     }
@@ -294,12 +320,11 @@ __device__ inline void solve_ld(const DevModel& m, real* S, int ld, int dinv, in
 }
 
 __device__ inline void stage_geoms(const DevModel& m, const Lay& l, real* S, int L) {
-  MJ_FOR(g, m.ngeom) {
-    int b = m.geom_bodyid[g];
+  if (L < m.ngeom) {
+    int b = m.geom_bodyid[L];
     Quat bq = ldq(S + l.xquat + 4 * b);
-    st3(S + l.gpos + 3 * g, ld3(S + l.xpos + 3 * b) + rot(bq, ld3(m.geom_pos + 3 * g)));
-    M3 gm = qmat(qmul(bq, ldq(m.geom_quat + 4 * g)));
-    for (int k = 0; k < 9; k++) S[l.gmat + 9 * g + k] = gm.m[k];
+    st3(S + l.gpos + 3 * L, ld3(S + l.xpos + 3 * b) + rot(bq, ld3(m.geom_pos + 3 * L)));
+    stq(S + l.gquat + 4 * L, qmul(bq, ldq(m.geom_quat + 4 * L)));
   }
   wv::sync();
 }
@@ -307,51 +332,55 @@ __device__ inline void stage_geoms(const DevModel& m, const Lay& l, real* S, int
 // ------------------------------------------------------------------ collision
 __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S, int L) {
   int* I = (int*)(S + l.ints);
-  int ncand = 0, warn = 0;
-  // broad phase: bounding spheres (planes: signed distance of the other geom's bounding sphere)
+  int nitem = 0, warn = 0;
+  // broad phase: bounding spheres (planes: signed distance of the other geom's bounding sphere).  Every surviving
+  // pair expands into its narrow-phase work items, in pair order.
   for (int base = 0; base < m.npair; base += 64) {
-    int p = base + L;
-    bool pass = false;
+    int p = base + L, items = 0;
     if (p < m.npair) {
       int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-      real margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+      real bound = m.pair_bound[p];
+      int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
       V3 dif = ld3(S + l.gpos + 3 * g2) - ld3(S + l.gpos + 3 * g1);
-      if (m.geom_type[g1] == GEOM_PLANE) {
-        V3 n = v3(S[l.gmat + 9 * g1 + 2], S[l.gmat + 9 * g1 + 5], S[l.gmat + 9 * g1 + 8]);
-        pass = !(dot(dif, n) > m.geom_rbound[g2] + margin);
-      } else {
-        real bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
-        pass = !(dot(dif, dif) > bound * bound);
+      bool pass;
+      if (t1 == GEOM_PLANE) pass = !(dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2)) > bound);
+      else pass = !(dot(dif, dif) > bound * bound);
+      if (pass) {
+        items = pair_items(t1, t2);
+        if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) {
+          // only (numerically) parallel capsules need the four end-point candidates
+          real c = dot(col(qmat(ldq(S + l.gquat + 4 * g1)), 2), col(qmat(ldq(S + l.gquat + 4 * g2)), 2));
+          if (fabs(1.0 - c * c) >= 1e-12) items = 1;
+        }
       }
     }
-    unsigned long long mask = wv::ballot(pass);
-    if (pass) {
-      int slot = ncand + wv::popc(mask & ((1ull << L) - 1ull));
-      if (slot < CAND_MAX) I[l.i_cand + slot] = p;
-    }
-    ncand += wv::popc(mask);
+    // exclusive prefix of the item counts (1, 2, 4 or 8 per lane) from four ballots
+    unsigned long long lower = (1ull << L) - 1ull;
+    unsigned long long b1 = wv::ballot(items >= 1), b2 = wv::ballot(items >= 2), b4 = wv::ballot(items >= 4),
+                       b8 = wv::ballot(items >= 8);
+    int off = nitem + wv::popc(b1 & lower) + wv::popc(b2 & lower) + 2 * wv::popc(b4 & lower) + 4 * wv::popc(b8 & lower);
+    for (int k = 0; k < items; k++)
+      if (off + k < ITEM_MAX) I[l.i_item + off + k] = (p << 3) | k;
+    nitem += wv::popc(b1) + wv::popc(b2) + 2 * wv::popc(b4) + 4 * wv::popc(b8);
   }
-  if (ncand > CAND_MAX) { ncand = CAND_MAX; warn |= 4; }
+  if (nitem > ITEM_MAX) { nitem = ITEM_MAX; warn |= 4; }
   wv::sync();
-  // narrow phase: lane = (candidate, item)
-  int kmax = m.pair_kmax;   // items per candidate pair this model can need (set by the host: 1, 2, 4 or 8)
-  int per = 64 / kmax, ncon = 0;
-  for (int base = 0; base < ncand; base += per) {
-    int c = base + L / kmax, k = L % kmax;
+  // narrow phase: one lane per work item; contacts come out in (pair, item) order
+  int ncon = 0;
+  for (int base = 0; base < nitem; base += 64) {
+    int it = base + L;
     bool hit = false;
     RawCon rc;
     int g1 = 0, g2 = 0;
     real margin = 0, gap = 0;
-    if (c < ncand) {
-      int p = I[l.i_cand + c];
+    if (it < nitem) {
+      int code = I[l.i_item + it], p = code >> 3, k = code & 7;
       g1 = m.pair_geom[2 * p]; g2 = m.pair_geom[2 * p + 1];
-      int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-      if (k < pair_items(t1, t2)) {
-        margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
-        gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
-        hit = collide_item(t1, t2, ld3(S + l.gpos + 3 * g1), ldm(S + l.gmat + 9 * g1), ld3(m.geom_size + 3 * g1),
-                           ld3(S + l.gpos + 3 * g2), ldm(S + l.gmat + 9 * g2), ld3(m.geom_size + 3 * g2), margin, k, rc);
-      }
+      margin = m.pair_margin[p];
+      gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
+      hit = collide_item(m.geom_type[g1], m.geom_type[g2], ld3(S + l.gpos + 3 * g1), qmat(ldq(S + l.gquat + 4 * g1)),
+                         ld3(m.geom_size + 3 * g1), ld3(S + l.gpos + 3 * g2), qmat(ldq(S + l.gquat + 4 * g2)),
+                         ld3(m.geom_size + 3 * g2), margin, k, rc);
     }
     unsigned long long mask = wv::ballot(hit);
     if (hit) {
@@ -370,30 +399,30 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
     ncon += wv::popc(mask);
   }
   if (ncon > m.nconmax) { ncon = m.nconmax; warn |= 1; }
-  if (L == 0) { I[I_NCON] = ncon; I[I_WARN] = warn; I[I_NCAND] = ncand; }
+  if (L == 0) { I[I_NCON] = ncon; I[I_WARN] = warn; I[I_NITEM] = nitem; }
   wv::sync();
 }
 
 // ------------------------------------------------------------------ velocity stage (comVel + RNE bias)
-__device__ inline void stage_velocity(const DevModel& m, const Lay& l, real* S, int L, bool with_acc) {
-  // with_acc == false: cvel, cdof_dot, cacc (bias accelerations), cfrc -> qfrc_bias
+__device__ inline void stage_velocity(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L, bool with_acc) {
+  // with_acc == false: cvel, cdof_dot, cacc (bias accelerations), body forces -> qfrc_bias
   // with_acc == true : cacc including cdof*qacc only (for the accelerometer), nothing else is touched
   if (L == 0) {
     for (int r = 0; r < 6; r++) { if (!with_acc) S[l.cvel + r] = 0; }
     S[l.cacc + 0] = S[l.cacc + 1] = S[l.cacc + 2] = 0;
     S[l.cacc + 3] = -m.gravity_x; S[l.cacc + 4] = -m.gravity_y; S[l.cacc + 5] = -m.gravity_z;
+    if (!with_acc) for (int r = 0; r < 6; r++) S[l.crb + r] = 0;
   }
   wv::sync();
   for (int lev = 1; lev <= m.maxdepth; lev++) {
-    MJ_FOR(b, m.nbody) {
-      if (m.body_depth[b] != lev) continue;
-      int p = m.body_parentid[b];
+    if (K.b_depth == lev) {
+      int b = L, p = K.b_parent;
       real cvel[6], cacc[6];
       for (int r = 0; r < 6; r++) { cvel[r] = S[l.cvel + 6 * p + r]; cacc[r] = S[l.cacc + 6 * p + r]; }
-      int da = m.body_dofadr[b];
+      int da = K.b_dofadr;
       if (!with_acc) {
-        for (int k = 0; k < m.body_jntnum[b]; k++) {
-          int j = m.body_jntadr[b] + k;
+        for (int k = 0; k < K.b_jntnum; k++) {
+          int j = K.b_jntadr + k;
           if (m.jnt_type[j] == JNT_FREE) {
             for (int t = 0; t < 3; t++) {
               for (int r = 0; r < 6; r++) {
@@ -424,15 +453,15 @@ __device__ inline void stage_velocity(const DevModel& m, const Lay& l, real* S, 
         }
         for (int r = 0; r < 6; r++) S[l.cvel + 6 * b + r] = cvel[r];
       }
-      da = m.body_dofadr[b];
-      for (int t = 0; t < m.body_dofnum[b]; t++)
+      da = K.b_dofadr;
+      for (int t = 0; t < K.b_dofnum; t++)
         for (int r = 0; r < 6; r++) {
           cacc[r] += S[l.cdofdot + 6 * (da + t) + r] * S[l.qvel + da + t];
           if (with_acc) cacc[r] += S[l.cdof + 6 * (da + t) + r] * S[l.qacc + da + t];
         }
       for (int r = 0; r < 6; r++) S[l.cacc + 6 * b + r] = cacc[r];
       if (!with_acc) {
-        // body force  I*a + v x* (I*v)   (crb's rows are free again: reuse them for cfrc)
+        // body force  I*a + v x* (I*v)   (crb's rows are free again: they hold the body forces)
         real ci[10], t1[6], t2[6], t3[6];
         for (int k = 0; k < 10; k++) ci[k] = S[l.cinert + 10 * b + k];
         inert_mul(t1, ci, cacc);
@@ -444,35 +473,45 @@ __device__ inline void stage_velocity(const DevModel& m, const Lay& l, real* S, 
     wv::sync();
   }
   if (with_acc) return;
-  if (L == 0) for (int r = 0; r < 6; r++) S[l.crb + r] = 0;
-  wv::sync();
-  tree_accumulate(m, S + l.crb, 10, 6, false, L);
-  MJ_FOR(i, m.nv) {
-    real c[6], f[6];
-    int b = m.dof_bodyid[i];
-    for (int r = 0; r < 6; r++) { c[r] = S[l.cdof + 6 * i + r]; f[r] = S[l.crb + 10 * b + r]; }
-    S[l.bias + i] = dot6(c, f);
+  // force transmitted by each dof-carrying body = sum of the body forces over its subtree; project on its dofs
+  if (L > 0 && L < m.nbody && K.b_dofnum > 0) {
+    real f[6];
+    for (int r = 0; r < 6; r++) f[r] = S[l.crb + 10 * L + r];
+    for (int c = L + 1; c < L + K.b_subnum; c++)
+      for (int r = 0; r < 6; r++) f[r] += S[l.crb + 10 * c + r];
+    for (int t = 0; t < K.b_dofnum; t++) {
+      real c[6];
+      for (int r = 0; r < 6; r++) c[r] = S[l.cdof + 6 * (K.b_dofadr + t) + r];
+      S[l.bias + K.b_dofadr + t] = dot6(c, f);
+    }
   }
   wv::sync();
 }
 
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
-__device__ inline void stage_smooth(const DevModel& m, const Lay& l, real* S, int L) {
-  MJ_FOR(i, m.nv) {
+__device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+  if (L < m.nv) {
     real act = 0;
-    for (int u = 0; u < m.nu; u++) {
-      if (m.act_dofid[u] != i) continue;
+    if (K.d_act >= 0) {
+      int u = K.d_act;
       real c = S[l.ctrl + u];
       if (m.act_ctrllimited[u]) c = fmin(fmax(c, m.act_ctrlrange[2 * u]), m.act_ctrlrange[2 * u + 1]);
-      act += m.act_gear[u] * c;
+      act = m.act_gear[u] * c;
+    } else if (K.d_act == -2) {
+      for (int u = 0; u < m.nu; u++) {
+        if (m.act_dofid[u] != L) continue;
+        real c = S[l.ctrl + u];
+        if (m.act_ctrllimited[u]) c = fmin(fmax(c, m.act_ctrlrange[2 * u]), m.act_ctrlrange[2 * u + 1]);
+        act += m.act_gear[u] * c;
+      }
     }
-    real passive = -m.dof_damping[i] * S[l.qvel + i];
-    real sm = passive - S[l.bias + i] + act;
-    S[l.smooth + i] = sm;
-    S[l.qaccs + i] = sm;
+    real passive = -K.d_damping * S[l.qvel + L];
+    real sm = passive - S[l.bias + L] + act;
+    S[l.smooth + L] = sm;
+    S[l.qaccs + L] = sm;
   }
   wv::sync();
-  solve_ld(m, S, l.LD, l.Dinv, l.qaccs, L, true, true, true);
+  solve_ld(m, K, S, l.LD, l.Dinv, l.qaccs, L, true, true, true);
 }
 
 // ------------------------------------------------------------------ constraint rows
@@ -495,7 +534,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       int r = nlim + wv::popc(mask & ((1ull << L) - 1ull));
       if (r < m.njmax) {
         I[l.i_rowid + r] = -(it + 1);          // negative: limit row, item id it
-        S[l.row + ROW_STRIDE * r + ROW_POS] = dist;
+        S[l.row + ROW_STRIDE * r + ROW_F] = dist;
       }
     }
     nlim += wv::popc(mask);
@@ -525,7 +564,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
   wv::sync();
   int nefc = I[I_NEFC];
   // one lane per row: Jacobian row, reference acceleration, regularisation
-  MJ_FOR(r, nefc) {
+  for (int r = L; r < nefc; r += 64) {
     real* Jr = S + l.J + l.ldj * r;
     real* R = S + l.row + ROW_STRIDE * r;
     for (int k = 0; k < m.nv; k++) Jr[k] = 0;
@@ -538,7 +577,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       int it = -id - 1, j = it >> 1, side = (it & 1) ? 1 : -1;
       int dof = m.jnt_dofadr[j];
       Jr[dof] = -side;
-      pos = R[ROW_POS];
+      pos = R[ROW_F];
       margin = m.jnt_margin[j];
       diag = m.dof_invweight0[dof];
       solref = m.jnt_solref + 2 * j;
@@ -558,13 +597,18 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       int t1 = m.body_treeid[b1], t2 = m.body_treeid[b2];
       V3 off1 = t1 >= 0 ? cp - ld3(S + l.com + 3 * t1) : v3(0, 0, 0);
       V3 off2 = t2 >= 0 ? cp - ld3(S + l.com + 3 * t2) : v3(0, 0, 0);
-      int i1 = m.body_lastdof[b1], i2 = m.body_lastdof[b2];
+      // the two bodies' dof chains (descending dof ids, stored contiguously in the sparse-M row of the last dof)
+      int l1 = m.body_lastdof[b1], l2 = m.body_lastdof[b2];
+      int a1 = l1 >= 0 ? m.dof_Madr[l1] : 0, n1 = l1 >= 0 ? m.dof_depth[l1] + 1 : 0;
+      int a2 = l2 >= 0 ? m.dof_Madr[l2] : 0, n2 = l2 >= 0 ? m.dof_depth[l2] + 1 : 0;
+      int p1 = 0, p2 = 0;
+      int i1 = n1 > 0 ? m.M_colid[a1] : -1, i2 = n2 > 0 ? m.M_colid[a2] : -1;
       while (i1 >= 0 || i2 >= 0) {
         int i = i1 > i2 ? i1 : i2;
         V3 ca = ld3(S + l.cdof + 6 * i), cl = ld3(S + l.cdof + 6 * i + 3);
         V3 colv = v3(0, 0, 0);
-        if (i2 == i) { colv = cl + cross(ca, off2); i2 = m.dof_parentid[i2]; }
-        if (i1 == i) { colv = colv - (cl + cross(ca, off1)); i1 = m.dof_parentid[i1]; }
+        if (i2 == i) { colv = cl + cross(ca, off2); p2++; i2 = p2 < n2 ? m.M_colid[a2 + p2] : -1; }
+        if (i1 == i) { colv = colv - (cl + cross(ca, off1)); p1++; i1 = p1 < n1 ? m.M_colid[a1 + p1] : -1; }
         real jn = dot(n, colv);
         Jr[i] = dim == 1 ? jn : jn + sgn * mu * dot(tk, colv);
       }
@@ -594,19 +638,16 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     real imp = impedance(solimp, pos, margin);
     real dmax = fmin(fmax(solimp[1], MJ_MINIMP), MJ_MAXIMP);
     real timeconst = fmax(solref[0], 2 * m.timestep), dampratio = solref[1];
-    real K = 1.0 / fmax(MJ_MINVAL, dmax * dmax * timeconst * timeconst * dampratio * dampratio);
-    real B = 2.0 / fmax(MJ_MINVAL, dmax * timeconst);
+    real Kc = 1.0 / fmax(MJ_MINVAL, dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+    real Bc = 2.0 / fmax(MJ_MINVAL, dmax * timeconst);
     real Rr = fmax(MJ_MINVAL, (1 - imp) / imp * diag);
     if (contact) Rr = fmax(MJ_MINVAL, 2 * mu0 * mu0 * Rr);   // pyramid edges share 2*mu^2*R(first edge)
-    real aref = -B * vel - K * imp * (pos - margin);
+    real aref = -Bc * vel - Kc * imp * (pos - margin);
     real jar = jw - aref;
     real Dr = 1.0 / Rr;
     R[ROW_R] = Rr;
-    R[ROW_AREF] = aref;
     R[ROW_B] = ja - aref;
     R[ROW_F] = jar < 0 ? -Dr * jar : 0.0;
-    R[ROW_POS] = pos;
-    R[ROW_MARGIN] = margin;
   }
   wv::sync();
 }
@@ -619,35 +660,40 @@ __device__ inline void stage_project(const DevModel& m, const Lay& l, real* S, i
     int r = base + L;
     bool own = r < nefc;
     real* Jr = S + l.J + l.ldj * (own ? r : 0);
-    for (int k = m.nv - 1; k >= 0; k--) {
+    for (int k = m.nv - 1; k >= 0; k--) {       // k, adr and the column ids are wave-uniform (scalar loads)
+      int depth = m.dof_depth[k];
+      if (depth == 0) continue;
       real v = own ? Jr[k] : 0.0;
       if (wv::ballot(v != 0.0) == 0ull) continue;
-      int adr = m.dof_Madr[k] + 1;
-      for (int j = m.dof_parentid[k]; j >= 0; j = m.dof_parentid[j]) {
-        if (v != 0.0) Jr[j] -= v * S[l.LD + adr];
-        adr++;
+      int adr = m.dof_Madr[k];
+      for (int t = 1; t <= depth; t++) {
+        int j = m.M_colid[adr + t];
+        if (v != 0.0) Jr[j] -= v * S[l.LD + adr + t];
       }
     }
     if (own) {
       real acc = 0;
       for (int k = 0; k < m.nv; k++) acc += Jr[k] * Jr[k] * S[l.Dinv + k];
-      S[l.row + ROW_STRIDE * r + ROW_ARII] = acc + S[l.row + ROW_STRIDE * r + ROW_R];
+      real aii = acc + S[l.row + ROW_STRIDE * r + ROW_R];
+      S[l.row + ROW_STRIDE * r + ROW_ARII] = aii;
+      S[l.row + ROW_STRIDE * r + ROW_ARINV] = 1.0 / aii;
     }
   }
   wv::sync();
 }
 
 // projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed:
-// lane d carries u_d = (B' f)_d, a row's residual is one wave reduction, its update one fused multiply-add.
-__device__ inline void stage_pgs(const DevModel& m, const Lay& l, real* S, int L) {
+// lane d carries u_d = (B' f)_d, a row's residual is one wave reduction, its update one multiply-add.
+__device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
   int* I = (int*)(S + l.ints);
   int nefc = I[I_NEFC];
-  bool dof = L < m.nv;             // nv <= 64 (checked at create)
+  bool dof = L < m.nv;
+  const int width = m.nv <= 16 ? 16 : (m.nv <= 32 ? 32 : 64);
   real dinv = dof ? S[l.Dinv + L] : 0.0;
   real u = 0;
   if (nefc == 0) {
     if (L == 0) I[I_NITER] = 0;
-    MJ_FOR(i, m.nv) { S[l.qfc + i] = 0; S[l.qacc + i] = S[l.qaccs + i]; S[l.warm + i] = S[l.qaccs + i]; }
+    if (dof) { S[l.qfc + L] = 0; S[l.qacc + L] = S[l.qaccs + L]; S[l.warm + L] = S[l.qaccs + L]; }
     wv::sync();
     return;
   }
@@ -655,14 +701,14 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, real* S, int L
   if (dof)
     for (int r = 0; r < nefc; r++) u += S[l.J + l.ldj * r + L] * S[l.row + ROW_STRIDE * r + ROW_F];
   real part = 0.5 * dinv * u * u;
-  MJ_FOR(r, nefc) {
+  for (int r = L; r < nefc; r += 64) {
     const real* R = S + l.row + ROW_STRIDE * r;
     part += 0.5 * R[ROW_R] * R[ROW_F] * R[ROW_F] + R[ROW_F] * R[ROW_B];
   }
   real cost = wv::sum(part);
   if (cost > 0) {
     u = 0;
-    MJ_FOR(r, nefc) S[l.row + ROW_STRIDE * r + ROW_F] = 0;
+    for (int r = L; r < nefc; r += 64) S[l.row + ROW_STRIDE * r + ROW_F] = 0;
   }
   wv::sync();
   real scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
@@ -672,9 +718,10 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, real* S, int L
     for (int i = 0; i < nefc; i++) {
       const real* R = S + l.row + ROW_STRIDE * i;
       real bid = dof ? S[l.J + l.ldj * i + L] : 0.0;
-      real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII];
-      real res = wv::sum(bid * dinv * u) + Ri * fi + bi;
-      real fn = fi - res / aii;
+      real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = R[ROW_ARINV];
+      // the dofs sit in lanes [0, width): reduce there, then hand lane 0's sum to the whole wave
+      real res = wv::first(wv::sum_n(bid * dinv * u, width)) + Ri * fi + bi;
+      real fn = fi - res * ainv;
       if (fn < 0) fn = 0;
       real delta = fn - fi;
       real change = 0.5 * delta * delta * aii + delta * res;
@@ -691,31 +738,27 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, real* S, int L
   // back to joint space: qfrc_constraint = L' u ; qacc = qacc_smooth + L^-1 D^-1 u
   if (dof) S[l.x + L] = u;
   wv::sync();
-  MJ_FOR(i, m.nv) {
-    int adr = m.dof_descadr[i], num = m.dof_descnum[i];
-    real q = S[l.x + i];
-    for (int c = 0; c < num; c++) {
-      int e = m.desc_Madr[adr + c];
-      q += S[l.LD + e] * S[l.x + m.M_rowid[e]];
-    }
-    S[l.qfc + i] = q;
+  if (dof) {
+    real q = u;
+    for (int c = 0; c < K.d_descnum; c++) q += S[l.LD + m.desc_Madr[K.d_descadr + c]] * S[l.x + m.desc_row[K.d_descadr + c]];
+    S[l.qfc + L] = q;
   }
   wv::sync();
-  solve_ld(m, S, l.LD, l.Dinv, l.x, L, false, true, true);
-  MJ_FOR(i, m.nv) {
-    real a = S[l.qaccs + i] + S[l.x + i];
-    S[l.qacc + i] = a;
-    S[l.warm + i] = a;
+  solve_ld(m, K, S, l.LD, l.Dinv, l.x, L, false, true, true);
+  if (dof) {
+    real a = S[l.qaccs + L] + S[l.x + L];
+    S[l.qacc + L] = a;
+    S[l.warm + L] = a;
   }
   wv::sync();
 }
 
 // ------------------------------------------------------------------ sensors (mj_forward's sensor stage)
-__device__ inline void stage_sensors(const DevModel& m, const Lay& l, real* S, int L) {
+__device__ inline void stage_sensors(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
   int* I = (int*)(S + l.ints);
   bool need_acc = false;
   for (int s = 0; s < m.nsensor; s++) need_acc |= (m.sensor_type[s] == SENS_ACCELEROMETER);
-  if (need_acc) stage_velocity(m, l, S, L, true);
+  if (need_acc) stage_velocity(m, l, K, S, L, true);
   for (int s = 0; s < m.nsensor; s++) {
     int site = m.sensor_objid[s], adr = m.sensor_adr[s], body = m.site_bodyid[site], type = m.sensor_type[s];
     real cutoff = m.sensor_cutoff[s];
@@ -725,10 +768,10 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, real* S, i
     if (type == SENS_RANGEFINDER) {
       V3 vec = col(sm, 2);
       real best = 1e300;
-      MJ_FOR(g, m.ngeom) {
-        if (m.geom_bodyid[g] == body || m.geom_rgba[4 * g + 3] == 0) continue;
-        real x = ray_geom(m.geom_type[g], ld3(S + l.gpos + 3 * g), ldm(S + l.gmat + 9 * g), ld3(m.geom_size + 3 * g), sp, vec);
-        if (x >= 0 && x < best) best = x;
+      if (L < m.ngeom && m.geom_bodyid[L] != body && m.geom_rgba[4 * L + 3] != 0) {
+        real x = ray_geom(m.geom_type[L], ld3(S + l.gpos + 3 * L), qmat(ldq(S + l.gquat + 4 * L)), ld3(m.geom_size + 3 * L),
+                          sp, vec);
+        if (x >= 0) best = x;
       }
       best = wv::min_pos(best);
       real out = best > 1e299 ? -1.0 : best;
@@ -737,19 +780,19 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, real* S, i
     } else if (type == SENS_TOUCH) {
       real part = 0;
       int ncon = I[I_NCON];
-      MJ_FOR(c, ncon) {
-        int a = I[l.i_conadr + c];
+      if (L < ncon) {
+        int c = L, a = I[l.i_conadr + c];
         int g1 = I[l.i_cong1 + c], g2 = I[l.i_cong2 + c];
         int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-        if (a < 0 || (b1 != body && b2 != body)) continue;
-        int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
-        int rows = dim == 1 ? 1 : 2 * ((dim < 3 ? dim : 3) - 1);
-        real fn = 0;
-        for (int r = 0; r < rows; r++) fn += S[l.row + ROW_STRIDE * (a + r) + ROW_F];
-        if (fn <= 0) continue;
-        const real* C = S + l.con + CON_STRIDE * c;
-        V3 ray = ld3(C + CON_FRAME) * (b2 == body ? -1.0 : 1.0);
-        if (ray_sphere_at(sp, m.site_size[3 * site], ld3(C + CON_POS), ray) >= 0) part += fn;
+        if (a >= 0 && (b1 == body || b2 == body)) {
+          int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
+          int rows = dim == 1 ? 1 : 2 * ((dim < 3 ? dim : 3) - 1);
+          real fn = 0;
+          for (int r = 0; r < rows; r++) fn += S[l.row + ROW_STRIDE * (a + r) + ROW_F];
+          const real* C = S + l.con + CON_STRIDE * c;
+          V3 ray = ld3(C + CON_FRAME) * (b2 == body ? -1.0 : 1.0);
+          if (fn > 0 && ray_sphere_at(sp, m.site_size[3 * site], ld3(C + CON_POS), ray) >= 0) part = fn;
+        }
       }
       real out = wv::sum(part);
       if (cutoff > 0 && out > cutoff) out = cutoff;
@@ -778,30 +821,27 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, real* S, i
 }
 
 // ------------------------------------------------------------------ integrator
-__device__ inline void stage_euler(const DevModel& m, const Lay& l, real* S, int L) {
+__device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
   real h = m.timestep;
-  bool damped = false;
-  for (int i = 0; i < m.nv; i++) damped |= (m.dof_damping[i] > 0);
+  bool damped = wv::ballot(L < m.nv && K.d_damping > 0) != 0ull;
   if (damped) {
     // (M + h*diag(damping)) qacc = qfrc_smooth + qfrc_constraint
-    MJ_FOR(e, m.nM) S[l.LD + e] = S[l.M + e];
-    wv::sync();
-    MJ_FOR(i, m.nv) {
-      S[l.LD + m.dof_Madr[i]] += h * m.dof_damping[i];
-      S[l.x + i] = S[l.smooth + i] + S[l.qfc + i];
+    if (L < m.nv) {
+      for (int t = 0; t <= K.d_depth; t++) S[l.LD + K.d_Madr + t] = S[l.M + K.d_Madr + t] + (t == 0 ? h * K.d_damping : 0.0);
+      S[l.x + L] = S[l.smooth + L] + S[l.qfc + L];
     }
     wv::sync();
     factor_ld(m, S, l.LD, l.Dinv, L);
-    solve_ld(m, S, l.LD, l.Dinv, l.x, L, true, true, true);
+    solve_ld(m, K, S, l.LD, l.Dinv, l.x, L, true, true, true);
   } else {
-    MJ_FOR(i, m.nv) S[l.x + i] = S[l.qacc + i];
+    if (L < m.nv) S[l.x + L] = S[l.qacc + L];
     wv::sync();
   }
-  MJ_FOR(i, m.nv) S[l.qvel + i] += h * S[l.x + i];
+  if (L < m.nv) S[l.qvel + L] += h * S[l.x + L];
   wv::sync();
-  MJ_FOR(j, m.njnt) {
-    int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-    if (m.jnt_type[j] == JNT_FREE) {
+  if (L < m.njnt) {
+    int qa = m.jnt_qposadr[L], da = m.jnt_dofadr[L];
+    if (m.jnt_type[L] == JNT_FREE) {
       for (int k = 0; k < 3; k++) S[l.qpos + qa + k] += h * S[l.qvel + da + k];
       real len;
       V3 w = normalized(ld3(S + l.qvel + da + 3), &len);
@@ -820,6 +860,16 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   const int env = wv::env_index();
   Lay l;
   make_layout(m, l);
+  LaneK K;
+  load_lane_constants(m, L, K);
+  unsigned long long t_prev = a.stamps ? wv::clock() : 0ull;
+#define MJ_STAMP(k)                                                        \
+  if (a.stamps) {                                                          \
+    unsigned long long t_now = wv::clock();                                \
+    if (L == 0) wv::atomic_add(a.stamps + (k), t_now - t_prev);            \
+    t_prev = t_now;                                                        \
+  }
+#define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
   // state in
   MJ_FOR(i, m.nq) S[l.qpos + i] = a.qpos[(size_t)env * m.nq + i];
   MJ_FOR(i, m.nv) { S[l.qvel + i] = a.qvel[(size_t)env * m.nv + i]; S[l.warm + i] = a.warm[(size_t)env * m.nv + i]; }
@@ -836,24 +886,38 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     }
     wv::sync();
   }
+  MJ_STAMP(ST_LOAD)
   for (int frame = 0; frame < a.skip_frames; frame++) {
-    stage_kinematics(m, l, S, L);
-    stage_com_inertia(m, l, S, L);
-    stage_crb(m, l, S, L);
+    stage_kinematics(m, l, K, S, L);
+    MJ_STAMP(ST_KIN)
+    stage_com_inertia(m, l, K, S, L);
+    MJ_STAMP(ST_COM)
+    stage_crb(m, l, K, S, L);
+    MJ_STAMP(ST_CRB)
     factor_ld(m, S, l.LD, l.Dinv, L);
+    MJ_STAMP(ST_FACTOR)
     stage_geoms(m, l, S, L);
+    MJ_STAMP(ST_GEOM)
     stage_collision(m, l, S, L);
-    stage_velocity(m, l, S, L, false);
-    stage_smooth(m, l, S, L);
+    MJ_STAMP(ST_COLLIDE)
+    stage_velocity(m, l, K, S, L, false);
+    MJ_STAMP(ST_VEL)
+    stage_smooth(m, l, K, S, L);
+    MJ_STAMP(ST_SMOOTH)
     stage_rows(m, l, S, L);
+    MJ_STAMP(ST_ROWS)
     if (a.dbg && a.dbg_stage == 1 && frame == a.skip_frames - 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     stage_project(m, l, S, L);
-    stage_pgs(m, l, S, L);
-    stage_sensors(m, l, S, L);
+    MJ_STAMP(ST_PROJECT)
+    stage_pgs(m, l, K, S, L);
+    MJ_STAMP(ST_PGS)
+    stage_sensors(m, l, K, S, L);
+    MJ_STAMP(ST_SENSORS)
     if (a.dbg && a.dbg_stage == 0 && frame == a.skip_frames - 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
-    if (!a.forward_only) stage_euler(m, l, S, L);
+    if (!a.forward_only) stage_euler(m, l, K, S, L);
+    MJ_STAMP(ST_EULER)
   }
   // state out
   if (!a.forward_only) {
@@ -876,6 +940,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       a.obs[(size_t)env * a.n_agent * a.obs_dim + it] = v;
     }
   }
+  MJ_STAMP(ST_STORE)
+#undef MJ_STAMP
   if (a.forward_only) return;
   // truncation is evaluated before the counter moves (mujoco_rl.py:279,288)
   int ts = a.timestep[env];
@@ -886,6 +952,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   }
   wv::sync();
   if (L == 0) a.timestep[env] = ts + 1;
+#undef MJ_FOR
 }
 
 }  // namespace mj

@@ -19,14 +19,41 @@ __device__ __forceinline__ int shfl(int v, int src) { return __shfl(v, src, 64);
 __device__ __forceinline__ double shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ unsigned long long ballot(bool pred) { return __ballot(pred); }
 __device__ __forceinline__ int popc(unsigned long long x) { return __popcll(x); }
+// wave clock (s_memtime) and a device-scope counter add, for the diagnostic stage stamps only
+__device__ __forceinline__ unsigned long long clock() { return (unsigned long long)clock64(); }
+__device__ __forceinline__ void atomic_add(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 
-// all-reduce over the 64 lanes, xor butterfly (every lane ends with the same bits)
-__device__ __forceinline__ double sum(double v) {
-#pragma unroll
-  for (int mask = 1; mask < 64; mask <<= 1) v += shfl_xor(v, mask);
+// 64-bit value moved with a DPP control word (two v_mov_b32_dpp); every lane reads a lane of its own row of 16
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// All-reduce (sum) over aligned groups of `width` lanes, width in {16, 32, 64}: every lane ends with its group's
+// sum.  Inside a row of 16 the partner exchange is pure DPP (quad_perm xor 1, quad_perm xor 2, row_half_mirror,
+// row_mirror); each step pairs lanes that already hold equal partial sums, so the result has the bits of an
+// xor butterfly.  Rows are then combined through the LDS crossbar (ds_bpermute).
+__device__ __forceinline__ double sum_n(double v, int width) {
+  v += dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp<0x141>(v);   // row_half_mirror
+  v += dpp<0x140>(v);   // row_mirror
+  if (width > 16) v += shfl_xor(v, 16);
+  if (width > 32) v += shfl_xor(v, 32);
   return v;
 }
-__device__ __forceinline__ double min_pos(double v) {   // minimum, every lane gets it
+__device__ __forceinline__ double sum(double v) { return sum_n(v, 64); }
+
+// lane 0's value in every lane (v_readfirstlane: the result is wave-uniform)
+__device__ __forceinline__ double first(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double min_pos(double v) {   // minimum over the wave, every lane gets it
 #pragma unroll
   for (int mask = 1; mask < 64; mask <<= 1) v = fmin(v, shfl_xor(v, mask));
   return v;

@@ -122,6 +122,7 @@ class Model:
     ndesc: int = 0
     nchild: int = 0
     maxdofdepth: int = 0
+    maxtreedof: int = 0
     # options
     timestep: float = 0.002
     gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
@@ -489,6 +490,8 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
     A["dof_descadr"] = np.cumsum([0] + [len(x) for x in desc[:-1]]).astype(np.int32) if nv else np.zeros(0, np.int32)
     A["dof_descnum"] = np.array([len(x) for x in desc], np.int32)
     A["desc_Madr"] = np.array([a for x in desc for a in x], np.int32)
+    A["desc_row"] = M_rowid[A["desc_Madr"]] if A["desc_Madr"].size else np.zeros(0, np.int32)
+    A["M_coldiag"] = dof_Madr[M_colid] if nM else np.zeros(0, np.int32)   # address of the diagonal of each entry's column
     m.ndesc = int(A["desc_Madr"].size)
     m.maxdofdepth = int(dof_depth.max()) if nv else 0
     # children of every body (descending id, the order in which a backward pass over bodies meets them)
@@ -500,6 +503,15 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
     A["body_childid"] = np.array([c for x in kids for c in x], np.int32)
     m.nchild = int(A["body_childid"].size)
     A["tree_rootbody"] = np.array(roots, np.int32)
+    # bodies are numbered depth-first, so a body's subtree is the id range [b, b + body_subtreenum[b])
+    subtreenum = np.ones(nbody, np.int32)
+    for b in range(nbody - 1, 0, -1):
+        subtreenum[body_parentid[b]] += subtreenum[b]
+    A["body_subtreenum"] = subtreenum
+    # dofs of a tree are contiguous: first dof and dof count per tree
+    A["tree_dofadr"] = np.array([int(np.min(np.nonzero(dof_treeid == t)[0])) for t in range(len(roots))], np.int32)
+    A["tree_dofnum"] = np.array([int(np.sum(dof_treeid == t)) for t in range(len(roots))], np.int32)
+    m.maxtreedof = int(A["tree_dofnum"].max()) if len(roots) else 0
 
     # ---- geoms
     A["geom_type"] = np.array([g["type"] for g in c.geoms], np.int32)
@@ -585,6 +597,11 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
     A["act_ctrllimited"] = np.array([int(a["limited"]) for a in motors], np.int32)
     A["act_ctrlrange"] = np.array([a["range"] for a in motors], np.float64).reshape(m.nu, 2)
     m.names["actuator"] = [a["name"] for a in motors]
+    # the single actuator driving each dof (-1 none, -2 several: the kernel then scans the actuator list)
+    dof_actid = np.full(nv, -1, np.int32)
+    for u, a in enumerate(motors):
+        dof_actid[a["dof"]] = u if dof_actid[a["dof"]] == -1 else -2
+    A["dof_actid"] = dof_actid
 
     # ---- sensors (the subset the levels use; all are attached to a site)
     sens = c.root.find("sensor")
@@ -635,11 +652,17 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
             pairs.append((a, b))
     m.npair = len(pairs)
     A["pair_geom"] = np.array(pairs, np.int32).reshape(m.npair, 2)
+    # broad-phase constants per pair: contact margin and the bounding-sphere reach (plane pairs: the other geom's)
+    rb, mg = A["geom_rbound"], A["geom_margin"]
+    A["pair_margin"] = np.array([max(mg[a], mg[b]) for a, b in pairs], np.float64)
+    A["pair_bound"] = np.array([(rb[b] if gt[a] == GEOM_PLANE else rb[a] + rb[b]) + max(mg[a], mg[b])
+                                for a, b in pairs], np.float64)
 
-    if nconmax is not None:
-        m.nconmax = int(nconmax)
-    if njmax is not None:
-        m.njmax = int(njmax)
+    # caps per env copy (MuJoCo's <size nconmax njmax>): by default room for 8 contacts per kinematic tree and
+    # one limit row per limited joint plus a 4-row pyramid per contact
+    m.nconmax = int(nconmax) if nconmax is not None else min(64, 8 * max(m.ntree, 1))
+    n_limited = int(np.sum(A["jnt_limited"]))
+    m.njmax = int(njmax) if njmax is not None else n_limited + 4 * m.nconmax
 
     _set_const(m)
     return m

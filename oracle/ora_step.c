@@ -661,7 +661,7 @@ static void ora_fwd_constraint(const ora_model* m, ora_data* d) {
       double res = d->efc_b[i];
       for (int j = 0; j < nefc; j++) res += AR[(size_t)i * nefc + j] * f[j];
       double old = f[i], aii = AR[(size_t)i * nefc + i];
-      double fn = old - res / aii;
+      double fn = old - res * (1.0 / aii);   /* the solver keeps the inverse diagonal and multiplies */
       if (fn < 0) fn = 0;
       double delta = fn - old;
       double change = 0.5 * delta * delta * aii + delta * res;

@@ -15,8 +15,8 @@ REGION_SHAPES = {
     "qpos": ("nq",), "qvel": ("nv",), "ctrl": ("nu",), "warm": ("nv",), "xpos": ("nbody", 3), "xquat": ("nbody", 4),
     "xanchor": ("njnt", 3), "xaxis": ("njnt", 3), "cinert": ("nbody", 10), "crb": ("nbody", 10), "cdof": ("nv", 6),
     "cdofdot": ("nv", 6), "cvel": ("nbody", 6), "cacc": ("nbody", 6), "M": ("nM",), "LD": ("nM",), "Dinv": ("nv",),
-    "gpos": ("ngeom", 3), "gmat": ("ngeom", 9), "bias": ("nv",), "smooth": ("nv",), "qaccs": ("nv",), "x": ("nv",),
-    "qfc": ("nv",), "qacc": ("nv",), "con": ("nconmax", 16), "row": ("njmax", 8), "sens": ("nsensordata",),
+    "gpos": ("ngeom", 3), "gquat": ("ngeom", 4), "bias": ("nv",), "smooth": ("nv",), "qaccs": ("nv",), "x": ("nv",),
+    "qfc": ("nv",), "qacc": ("nv",), "con": ("nconmax", 16), "row": ("njmax", 5), "sens": ("nsensordata",),
 }
 
 

@@ -46,10 +46,14 @@ inline unsigned long long ballot(bool pred) {
   return m;
 }
 inline int popc(unsigned long long x) { return __builtin_popcountll(x); }
-inline double sum(double v) {
-  for (int mask = 1; mask < 64; mask <<= 1) v += shfl_xor(v, mask);
+inline unsigned long long clock() { return 0; }
+inline void atomic_add(unsigned long long* p, unsigned long long v) { *p += v; }
+inline double sum_n(double v, int width) {   // all-reduce over aligned groups of `width` lanes (16, 32 or 64)
+  for (int mask = 1; mask < width; mask <<= 1) v += shfl_xor(v, mask);
   return v;
 }
+inline double sum(double v) { return sum_n(v, 64); }
+inline double first(double v) { return shfl(v, 0); }   // lane 0's value in every lane
 inline double min_pos(double v) {
   for (int mask = 1; mask < 64; mask <<= 1) v = std::fmin(v, shfl_xor(v, mask));
   return v;

@@ -39,14 +39,16 @@ def test_intermediate_quantities_match_after_contacts_appear():
         assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter)
     assert ora.ncon > 0
     for name, ref in (("xpos", ora.xpos), ("xquat", ora.xquat), ("cdof", ora.cdof), ("M", ora.qM), ("gpos", ora.geom_xpos),
-                      ("gmat", ora.geom_xmat), ("cvel", ora.cvel), ("bias", ora.qfrc_bias), ("qaccs", ora.qacc_smooth)):
+                      ("cvel", ora.cvel), ("bias", ora.qfrc_bias), ("qaccs", ora.qacc_smooth)):
         assert np.allclose(img.region(name), ref, rtol=0, atol=1e-9), name
+    gmat = np.stack([mjcf.quat_to_mat(q).reshape(9) for q in img.region("gquat")])
+    assert np.allclose(gmat, ora.geom_xmat, atol=1e-9)
     assert np.allclose(img.region("qacc"), ora.qacc, rtol=1e-9, atol=1e-7)
     assert np.allclose(img.region("qfc"), ora.qfrc_constraint, rtol=1e-9, atol=1e-7)
     cons = ora.contacts()
     assert [(c["geom1"], c["geom2"]) for c in cons] == [tuple(x) for x in img.contact_geoms()]
     assert np.allclose(img.region("con")[:len(cons), 0], [c["dist"] for c in cons], atol=1e-12)
-    assert np.allclose(img.region("row")[:ora.nefc, 3], ora.efc_force[:ora.nefc], rtol=1e-9, atol=1e-7)
+    assert np.allclose(img.region("row")[:ora.nefc, 2], ora.efc_force[:ora.nefc], rtol=1e-9, atol=1e-7)
 
 
 def test_constraint_rows_match_before_projection():
@@ -65,8 +67,7 @@ def test_constraint_rows_match_before_projection():
     assert np.allclose(img.J()[:n], ora.efc_J[:n], atol=1e-12)
     rows = img.region("row")[:n]
     assert np.allclose(rows[:, 0], ora.efc_R[:n], rtol=1e-12)
-    assert np.allclose(rows[:, 1], ora.efc_aref[:n], rtol=1e-10, atol=1e-9)
-    assert np.allclose(rows[:, 2], ora.efc_b[:n], rtol=1e-10, atol=1e-9)
+    assert np.allclose(rows[:, 1], ora.efc_b[:n], rtol=1e-10, atol=1e-9)
 
 
 @pytest.mark.parametrize("level,steps", [("two_agent.xml", 400), ("single_agent.xml", 300), ("two_agent_3sensors.xml", 250),

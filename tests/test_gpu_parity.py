@@ -1,0 +1,248 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (libmjrl_hip.so via ctypes), against the CPU
+oracle on the same seeded inputs, plus size-independent properties at BASELINE.json's full batch sizes.
+
+Bars (BASELINE.json north_star): body/agent indices, done and truncation flags bit-exact; qpos/qvel within
+1e-5 relative over 1000 steps.  Observed agreement is ~1e-12, so the short runs assert 1e-9.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mjrl_amd import _capi, blob, levels, mjcf
+from mjrl_amd.mujoco_rl import MuJoCoRL
+from oracle.oracle import OracleEnv
+
+pytestmark = pytest.mark.gpu
+
+AGENTS = ["sender", "receiver"]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def make(level, n_env, **kw):
+    model = mjcf.compile_mjcf(levels.level_path(level), **kw)
+    packed = blob.pack(model)
+    handle = _capi.Handle(packed, n_env)
+    handle.reset()
+    return model, packed, handle
+
+
+def test_reset_state_and_forward_pass():
+    model, packed, h = make("two_agent.xml", 5)
+    ora = OracleEnv(packed)
+    assert np.array_equal(h.get_field("qpos"), np.tile(model.qpos0, (5, 1)))
+    assert np.array_equal(h.get_field("qvel"), np.zeros((5, model.nv)))
+    assert np.allclose(h.get_field("qacc_warmstart"), ora.qacc_warmstart, atol=1e-10)
+    assert np.allclose(h.get_field("sensordata"), ora.sensordata, atol=1e-12)
+    assert np.array_equal(h.get_field("timestep"), np.zeros(5, np.int32))
+
+
+@pytest.mark.parametrize("level,steps", [("two_agent.xml", 400), ("single_agent.xml", 300), ("two_agent_3sensors.xml", 300),
+                                         ("four_agent.xml", 300), ("sensor_touch.xml", 150), ("sensor_accelerometer.xml", 150),
+                                         ("sensor_rangefinder.xml", 150), ("sensor_framexaxis.xml", 150)])
+def test_trajectory_parity_through_the_c_abi(level, steps):
+    n_env = 6
+    model, packed, h = make(level, n_env)
+    oras = [OracleEnv(packed) for _ in range(n_env)]
+    rng = np.random.default_rng(2)
+    for _ in range(steps):
+        ctrl = rng.uniform(-1, 1, (n_env, max(model.nu, 1)))
+        if model.nu:
+            h.set_field("ctrl", ctrl[:, :model.nu])
+        h.step_host(None, 1)
+        for e, o in enumerate(oras):
+            o.ctrl[:model.nu] = ctrl[e, :model.nu]
+            o.step()
+    assert max(o.ncon for o in oras) > 0
+    oq, ov = np.stack([o.qpos for o in oras]), np.stack([o.qvel for o in oras])
+    assert rel(h.get_field("qpos"), oq) < 1e-9
+    assert rel(h.get_field("qvel"), ov) < 1e-9
+    assert np.allclose(h.get_field("sensordata"), np.stack([o.sensordata for o in oras]), atol=1e-7)
+    ncon = h.query("ncon")[:, 0]
+    assert np.array_equal(ncon, [OracleFwd(o) for o in oras])
+
+
+def OracleFwd(o):
+    o.forward()
+    return o.ncon
+
+
+def test_thousand_step_drift_stays_inside_the_north_star_tolerance():
+    """qpos/qvel within 1e-5 relative over 1000 steps of the 2-agent level with random actions (the drift curve is
+    printed; it is the evidence DESIGN.md quotes)."""
+    n_env = 4
+    model, packed, h = make("two_agent.xml", n_env)
+    oras = [OracleEnv(packed) for _ in range(n_env)]
+    rng = np.random.default_rng(9)
+    worst, curve = 0.0, []
+    for step in range(1000):
+        ctrl = rng.uniform(-1, 1, (n_env, model.nu))
+        h.set_field("ctrl", ctrl)
+        h.step_host(None, 1)
+        for e, o in enumerate(oras):
+            o.ctrl[:] = ctrl[e]
+            o.step()
+        if step % 100 == 99:
+            oq, ov = np.stack([o.qpos for o in oras]), np.stack([o.qvel for o in oras])
+            rq, rv = rel(h.get_field("qpos"), oq), rel(h.get_field("qvel"), ov)
+            worst = max(worst, rq, rv)
+            curve.append(f"step {step + 1}: qpos rel {rq:.2e}  qvel rel {rv:.2e}")
+    print("\n".join(curve))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "drift_curve.txt"), "w") as fh:
+            fh.write("\n".join(curve) + "\n")
+    assert worst < 1e-5
+
+
+def test_scatter_gather_flags_through_the_env_class():
+    """Indices and flags are bit-exact: ctrl lands where the reference's table says, observations are
+    sensordata|qpos|qvel, truncation fires on call max_steps+1 (mujoco_rl.py:279,288)."""
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 3, "maxSteps": 4})
+    assert env.agents_action_index == {"sender": [2, 3, 4, 5, 6, 7, 0, 1], "receiver": [10, 11, 12, 13, 14, 15, 8, 9]}
+    obs, infos = env.reset()
+    assert obs["sender"].shape == (3, 59) and infos == {"sender": {}, "receiver": {}}
+    oras = [OracleEnv(env._blob) for _ in range(3)]
+    rng = np.random.default_rng(4)
+    for call in range(6):
+        action = {a: rng.uniform(-1, 1, (3, 8)) for a in AGENTS}
+        obs, rew, term, trunc, info = env.step(action)
+        for e, o in enumerate(oras):
+            for a in AGENTS:
+                o.ctrl[env.agents_action_index[a]] = action[a][e]
+            o.step()
+        assert np.array_equal(env._handle.get_field("ctrl"), np.stack([o.ctrl for o in oras]))
+        for k, a in enumerate(AGENTS):
+            expect = np.stack([np.concatenate([o.sensordata[[k]], o.qpos, o.qvel]) for o in oras])
+            assert np.allclose(obs[a], expect, atol=1e-10)
+            assert np.array_equal(rew[a], np.zeros(3)) and not term[a].any()
+            assert trunc[a].all() == (call >= 4)
+        assert "__all__" in trunc and "__all__" not in term
+    assert np.array_equal(env._handle.get_field("timestep"), np.full(3, 6, np.int32))
+    env.close()
+
+
+def test_single_copy_has_the_reference_shapes_and_runs_host_plugins():
+    calls = []
+
+    class Language:
+        """The README's language channel (README.md:109-136) in its 4-tuple form."""
+        def __init__(self, env):
+            self.env = env
+            self.observation_space = {"low": [0], "high": [3]}
+            self.action_space = {"low": [0], "high": [3]}
+
+        def dynamic(self, agent, actions):
+            calls.append(agent)
+            store = self.env.data_store
+            store[agent]["utterance"] = int(actions[0])
+            other = [a for a in self.env.agents if a != agent][0]
+            heard = store[other].get("utterance", 0)
+            return 0, np.array([heard]), False, {}
+
+    def reward(env, agent):
+        return float(env.data.qpos[2] if agent == "sender" else env.data.qpos[17])
+
+    def done(env, agent):
+        return bool(env.data.qpos[2] < 0.2)
+
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "environmentDynamics": [Language],
+                    "rewardFunctions": [reward], "doneFunctions": [done]})
+    assert env.action_space("sender").shape == (9,) and env.observation_space("sender").shape == (60,)
+    assert env.action_routing == {"physical": [0, 8], "dynamic": {"Language": [8, 9]}}
+    obs, infos = env.reset()
+    assert obs["sender"].shape == (60,) and env.data_store == {"sender": {}, "receiver": {}}
+    calls.clear()
+    act = {"sender": np.r_[np.zeros(8), 2.0], "receiver": np.r_[np.zeros(8), 1.0]}
+    obs, rew, term, trunc, info = env.step(act)
+    assert calls == ["sender", "receiver"]
+    assert obs["sender"][-1] == 0 and obs["receiver"][-1] == 2     # the receiver already hears this step's utterance
+    obs, rew, term, trunc, info = env.step(act)
+    assert obs["sender"][-1] == 1
+    assert rew["sender"] == pytest.approx(obs["sender"][1 + 2]) and isinstance(term["sender"], bool)
+    assert term["__all__"] is False and info["sender"] == {"Language": {}}
+    assert env.distance("sender", "receiver") == pytest.approx(np.linalg.norm(env.data.body("sender").xipos - env.data.body("receiver").xipos))
+    assert env.collision("sender_geom", "receiver_geom") is False
+    assert env.get_data("sender")["type"] == "body" and env.get_data("border1_geom")["type"] == "geom"
+    env.close()
+
+
+def test_full_batch_properties():
+    """4096 copies (BASELINE.json metric size): finite, deterministic run to run, independent of batch position,
+    identical copies stay identical, and a masked reset touches only the masked copies."""
+    n_env = 4096
+    model, packed, h = make("two_agent.xml", n_env)
+    rng = np.random.default_rng(1)
+    base = rng.uniform(-1, 1, (200, 16, model.nu))          # 16 distinct action streams, tiled over the batch
+    def run(handle, perm):
+        handle.reset()
+        for t in range(200):
+            ctrl = np.tile(base[t], (n_env // 16, 1))[perm]
+            handle.set_field("ctrl", ctrl)
+            handle.step_device(None, 0, 1)
+        return handle.get_field("qpos"), handle.get_field("qvel")
+    ident = np.arange(n_env)
+    q1, v1 = run(h, ident)
+    assert np.isfinite(q1).all() and np.isfinite(v1).all()
+    assert np.array_equal(q1[:16], q1[16:32]) and np.array_equal(q1[:16], q1[-16:])      # same stream -> same bits
+    q2, v2 = run(h, ident)
+    assert np.array_equal(q1, q2) and np.array_equal(v1, v2)                              # run-to-run determinism
+    perm = rng.permutation(n_env)
+    q3, _ = run(h, perm)
+    assert np.array_equal(q3, q1[perm])                                                   # position independence
+    oras = [OracleEnv(packed) for _ in range(4)]
+    for t in range(200):
+        for e, o in enumerate(oras):
+            o.ctrl[:] = base[t, e]
+            o.step()
+    assert rel(q1[:4], np.stack([o.qpos for o in oras])) < 1e-9
+    mask = np.zeros(n_env, np.uint8)
+    mask[::7] = 1
+    h.reset(mask)
+    q4 = h.get_field("qpos")
+    assert np.array_equal(q4[::7], np.tile(model.qpos0, (len(q4[::7]), 1)))
+    keep = np.ones(n_env, bool)
+    keep[::7] = False
+    assert np.array_equal(q4[keep], q3[keep])      # the last run on this handle was the permuted one
+
+
+def test_step_batched_with_torch_tensors_stays_on_device():
+    import torch
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 64})
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    act = torch.rand((64, 2, 8), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    obs, rew, term, trunc = env.step_batched(act)
+    torch.cuda.synchronize()
+    ora = OracleEnv(env._blob)
+    a0 = act[0].cpu().numpy()
+    for k, a in enumerate(AGENTS):
+        ora.ctrl[env.agents_action_index[a]] = a0[k]
+    ora.step()
+    expect = np.concatenate([ora.sensordata[[0]], ora.qpos, ora.qvel])
+    assert np.allclose(obs[0, 0].cpu().numpy(), expect, atol=1e-10)
+    assert obs.shape == (64, 2, 59) and not term.any().item() and not trunc.any().item()
+    env.close()
+
+
+def test_errors_are_reported_not_swallowed():
+    model, packed, h = make("two_agent.xml", 2)
+    with pytest.raises(Exception, match="unknown field"):
+        h._check(h._lib.mjrl_get_field(h._h, b"nope", None, 0))
+    with pytest.raises(Exception, match="out of range"):
+        h.set_scatter_tables([[99]], 0)
+    with pytest.raises(Exception, match="blob rejected"):
+        _capi.Handle(b"\0" * 400, 1)
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS})
+    env.reset()
+    with pytest.raises(Exception, match="number of actions"):
+        env.step({"sender": np.zeros(3), "receiver": np.zeros(8)})
+    env.close()
+
+
+def test_smoke_entry():
+    import __graft_entry__ as entry
+    entry.smoke()
