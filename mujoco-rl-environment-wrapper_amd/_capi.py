@@ -166,7 +166,7 @@ class Handle:
 
     def query(self, name: str):
         shapes = {"xpos": ("nbody", 3), "xquat": ("nbody", 4), "xipos": ("nbody", 3), "geom_xpos": ("ngeom", 3),
-                  "geom_xmat": ("ngeom", 9), "ncon": (1,), "contact_geom": ("nconmax", 2)}
+                  "geom_xmat": ("ngeom", 9), "ncon": (1,), "warn": (1,), "contact_geom": ("nconmax", 2)}
         shape = tuple(self.size(s) if isinstance(s, str) else s for s in shapes[name])
         out = np.zeros((self.n_env,) + shape, np.float64)
         self._check(self._lib.mjrl_query(self._h, name.encode(), _host_ptr(out), out.nbytes))

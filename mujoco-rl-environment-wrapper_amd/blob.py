@@ -18,11 +18,11 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 7
+VERSION = 8
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
-               "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "reserved0"]
+               "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "has_accel", "nitemmax", "reserved0"]
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
@@ -74,6 +74,9 @@ def _sizes(model) -> dict:
         t = (int(model.geom_type[g1]), int(model.geom_type[g2]))
         kmax = max(kmax, {(0, 3): 2, (0, 6): 8, (3, 3): 4, (3, 6): 2}.get(t, 1))
     s["pair_kmax"] = kmax
+    s["has_accel"] = int(any(int(t) == 1 for t in model.sensor_type))     # accelerometers keep cacc/cdof_dot alive
+    # narrow-phase work-item list: room for every pair that can plausibly pass the bounding-sphere test at once
+    s["nitemmax"] = int(getattr(model, "nitemmax", 0)) or 64 + 160 * max(int(model.ntree), 1)
     s["reserved0"] = 0
     return s
 

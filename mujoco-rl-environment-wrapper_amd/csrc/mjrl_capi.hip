@@ -409,13 +409,14 @@ int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
   MJRL_HIP(e, hipMemcpy(img.data(), e->dbg, sizeof(double) * img.size(), hipMemcpyDeviceToHost));
   size_t per = 0;
   int off = 0;
-  enum { PLAIN, XIPOS, NCON, CONGEOM, GMAT } kind = PLAIN;
+  enum { PLAIN, XIPOS, NCON, CONGEOM, GMAT, WARN } kind = PLAIN;
   if (!strcmp(name, "xpos")) { per = 3 * m.nbody; off = l.xpos; }
   else if (!strcmp(name, "xquat")) { per = 4 * m.nbody; off = l.xquat; }
   else if (!strcmp(name, "geom_xpos")) { per = 3 * m.ngeom; off = l.gpos; }
   else if (!strcmp(name, "geom_xmat")) { per = 9 * m.ngeom; kind = GMAT; }
   else if (!strcmp(name, "xipos")) { per = 3 * m.nbody; kind = XIPOS; }
   else if (!strcmp(name, "ncon")) { per = 1; kind = NCON; }
+  else if (!strcmp(name, "warn")) { per = 1; kind = WARN; }
   else if (!strcmp(name, "contact_geom")) { per = 2 * m.nconmax; kind = CONGEOM; }
   else MJRL_FAIL(e, 4, "query: unknown quantity '%s'", name);
   if (nbytes != sizeof(double) * per * e->n_env) MJRL_FAIL(e, 4, "query(%s): buffer holds %zu bytes, need %zu", name, nbytes, sizeof(double) * per * e->n_env);
@@ -425,6 +426,7 @@ int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
     double* o = h_out + (size_t)env * per;
     if (kind == PLAIN) memcpy(o, S + off, sizeof(double) * per);
     else if (kind == NCON) o[0] = I[mj::I_NCON];
+    else if (kind == WARN) o[0] = I[mj::I_WARN];
     else if (kind == CONGEOM) {
       for (int c = 0; c < m.nconmax; c++) {
         bool live = c < I[mj::I_NCON];

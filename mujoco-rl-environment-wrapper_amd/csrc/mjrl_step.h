@@ -30,7 +30,7 @@ enum { CON_DIST = 0, CON_POS = 1, CON_FRAME = 4, CON_INCL = 13, CON_MU = 14, CON
 enum { ROW_R = 0, ROW_B = 1, ROW_F = 2, ROW_ARII = 3, ROW_ARINV = 4, ROW_STRIDE = 5 };
 // integer header of the int region
 enum { I_NCON = 0, I_NEFC = 1, I_NLIM = 2, I_NITER = 3, I_WARN = 4, I_NITEM = 5, I_HEAD = 8 };
-enum { ITEM_MAX = 256, MAX_DOF_DEPTH = 8 };
+enum { MAX_DOF_DEPTH = 8 };
 
 // LDS layout of one env copy, offsets in doubles from the env's base.  The block `u` is shared by two
 // lifetimes: {xanchor, xaxis, cinert, crb} live from the kinematics to the end of the bias forces,
@@ -49,13 +49,14 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
 #define REG(name, n) l.name = o; o += (n);
   REG(qpos, m.nq) REG(qvel, m.nv) REG(ctrl, m.nu) REG(warm, m.nv)
   REG(xpos, 3 * m.nbody) REG(xquat, 4 * m.nbody) REG(com, 3 * (m.ntree + 1))
-  REG(cdof, 6 * m.nv) REG(cdofdot, 6 * m.nv) REG(cvel, 6 * m.nbody) REG(cacc, 6 * m.nbody)
+  REG(cdof, 6 * m.nv) REG(cvel, 6 * m.nbody)
+  if (m.has_accel) { REG(cdofdot, 6 * m.nv) REG(cacc, 6 * m.nbody) }   // the accelerometer re-reads them after the solve
   REG(M, m.nM) REG(LD, m.nM) REG(Dinv, m.nv)
   REG(gpos, 3 * m.ngeom) REG(gquat, 4 * m.ngeom)
   REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(x, m.nv) REG(qfc, m.nv) REG(qacc, m.nv)
   REG(con, CON_STRIDE * m.nconmax) REG(sens, m.nsensordata + 1)
   int ni = I_HEAD;
-  l.i_item = ni; ni += ITEM_MAX;
+  l.i_item = ni; ni += m.nitemmax;
   l.i_cong1 = ni; ni += m.nconmax;
   l.i_cong2 = ni; ni += m.nconmax;
   l.i_conadr = ni; ni += m.nconmax;
@@ -64,6 +65,7 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   l.u = o;
   l.xanchor = o; l.xaxis = l.xanchor + 3 * m.njnt; l.cinert = l.xaxis + 3 * m.njnt; l.crb = l.cinert + 10 * m.nbody;
   int first = 6 * m.njnt + 20 * m.nbody;
+  if (!m.has_accel) { l.cdofdot = o + first; l.cacc = l.cdofdot + 6 * m.nv; first += 6 * m.nv + 6 * m.nbody; }
   l.ldj = (m.nv | 1);
   l.J = o; l.row = l.J + l.ldj * m.njmax;
   int second = l.ldj * m.njmax + ROW_STRIDE * m.njmax;
@@ -360,10 +362,10 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
                        b8 = wv::ballot(items >= 8);
     int off = nitem + wv::popc(b1 & lower) + wv::popc(b2 & lower) + 2 * wv::popc(b4 & lower) + 4 * wv::popc(b8 & lower);
     for (int k = 0; k < items; k++)
-      if (off + k < ITEM_MAX) I[l.i_item + off + k] = (p << 3) | k;
+      if (off + k < m.nitemmax) I[l.i_item + off + k] = (p << 3) | k;
     nitem += wv::popc(b1) + wv::popc(b2) + 2 * wv::popc(b4) + 4 * wv::popc(b8);
   }
-  if (nitem > ITEM_MAX) { nitem = ITEM_MAX; warn |= 4; }
+  if (nitem > m.nitemmax) { nitem = m.nitemmax; warn |= 4; }
   wv::sync();
   // narrow phase: one lane per work item; contacts come out in (pair, item) order
   int ncon = 0;

@@ -61,6 +61,7 @@ def test_trajectory_parity_through_the_c_abi(level, steps):
     assert rel(h.get_field("qpos"), oq) < 1e-9
     assert rel(h.get_field("qvel"), ov) < 1e-9
     assert np.allclose(h.get_field("sensordata"), np.stack([o.sensordata for o in oras]), atol=1e-7)
+    assert not h.query("warn").any()                      # no cap (contacts, rows, work items) was hit
     ncon = h.query("ncon")[:, 0]
     assert np.array_equal(ncon, [OracleFwd(o) for o in oras])
 
