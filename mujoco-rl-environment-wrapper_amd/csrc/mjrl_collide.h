@@ -126,11 +126,21 @@ __device__ __forceinline__ bool capsule_box(V3 cp, const M3& cm, V3 cs, V3 bp, c
   if (glo >= 0) tstar = lo;
   else if (ghi <= 0) tstar = hi;
   else {
-    for (int it = 0; it < 60; it++) {
-      real mid = 0.5 * (lo + hi);
-      if (segbox_slope(p0, ax, bs, mid) < 0) lo = mid; else hi = mid;
+    // the slope is piecewise linear in t with kinks where a coordinate crosses a box face: bracket the root between
+    // kinks, then solve the linear piece exactly
+    real pk[3] = {p0.x, p0.y, p0.z}, ak[3] = {ax.x, ax.y, ax.z}, sk[3] = {bs.x, bs.y, bs.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (fabs(ak[k]) < MJ_MINVAL) continue;
+#pragma unroll
+      for (int s = -1; s <= 1; s += 2) {
+        real tb = (s * sk[k] - pk[k]) / ak[k];
+        if (tb <= lo || tb >= hi) continue;
+        real gb = segbox_slope(p0, ax, bs, tb);
+        if (gb < 0) { lo = tb; glo = gb; } else { hi = tb; ghi = gb; }
+      }
     }
-    tstar = 0.5 * (lo + hi);
+    tstar = lo - glo * (hi - lo) / (ghi - glo);
   }
   real dstar = pointbox_dist(p0, ax, bs, tstar);
   real dpos = pointbox_dist(p0, ax, bs, len), dneg = pointbox_dist(p0, ax, bs, -len);

@@ -41,7 +41,7 @@ struct Lay {
   int xanchor, xaxis, cinert, crb;   // inside u, first lifetime
   int J, row;                        // inside u, second lifetime
   int ldj;                           // row stride of J (odd -> conflict-free column walks)
-  int i_item, i_cong1, i_cong2, i_conadr, i_rowid;   // offsets inside the int region (in ints)
+  int i_item, i_cong1, i_cong2, i_conadr, i_rowid, i_rowtree;   // offsets inside the int region (in ints)
 };
 
 __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
@@ -61,6 +61,7 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   l.i_cong2 = ni; ni += m.nconmax;
   l.i_conadr = ni; ni += m.nconmax;
   l.i_rowid = ni; ni += m.njmax;
+  l.i_rowtree = ni; ni += m.njmax;
   REG(ints, (ni + 1) / 2)
   l.u = o;
   l.xanchor = o; l.xaxis = l.xanchor + 3 * m.njnt; l.cinert = l.xaxis + 3 * m.njnt; l.crb = l.cinert + 10 * m.nbody;
@@ -119,6 +120,22 @@ __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
   k.d_parent = m.dof_parentid[d]; k.d_Madr = m.dof_Madr[d]; k.d_depth = isd ? m.dof_depth[d] : -1;
   k.d_body = m.dof_bodyid[d]; k.d_descadr = m.dof_descadr[d]; k.d_descnum = isd ? m.dof_descnum[d] : 0;
   k.d_act = isd ? m.dof_actid[d] : -1; k.d_damping = m.dof_damping[d]; k.d_armature = m.dof_armature[d];
+}
+
+// The lane's records in the tree-row lane map (tree t owns lanes 16t..16t+15, one dof per lane): the lane's dof and
+// the factor entries it multiplies in each step of the register-resident triangular solves.
+struct RowK {
+  int dof;
+  int eb[16], ef[16];
+};
+
+__device__ inline void load_row_constants(const DevModel& m, int L, RowK& r) {
+  r.dof = m.rowmap ? m.row_dof[L] : (L < m.nv ? L : -1);
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    r.eb[k] = m.rowmap ? m.solve_b[k * 64 + L] : -1;
+    r.ef[k] = m.rowmap ? m.solve_f[k * 64 + L] : -1;
+  }
 }
 
 // ------------------------------------------------------------------ position stage
@@ -258,35 +275,62 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
 __device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, int L) {
   const int groups = m.ntree > 1 ? 2 : 1, width = 64 / groups;
   const int g = L / width, p = L % width;
-  for (int t0 = 0; t0 < m.ntree; t0 += groups) {
-    int tree = t0 + g;
+  for (int ps = 0; ps < m.npass; ps++) {
+    int tree = ps * groups + g;
     bool has_tree = tree < m.ntree;
     int adr0 = has_tree ? m.tree_dofadr[tree] : 0, num = has_tree ? m.tree_dofnum[tree] : 0;
+    // the lane's (ancestor, offset) pair of every elimination step comes from the host-built schedule
+    const int32_t* sched = m.factor_sched + (size_t)ps * m.maxtreedof * 64 + L;
+    unsigned next = (unsigned)sched[(m.maxtreedof - 1) * 64];
     for (int kk = m.maxtreedof - 1; kk >= 0; kk--) {
-      bool live = kk < num;
-      int k = adr0 + (live ? kk : 0);
-      int D = live ? m.dof_depth[k] : 0, kkadr = m.dof_Madr[k];
-      // decode p -> (a, t) over the triangle t < D - a
-      int a = 0, rem = p;
-      while (a < D && rem >= D - a) { rem -= D - a; a++; }
-      bool valid = live && a < D;
-      int t = rem, ki = kkadr + 1 + a;
+      unsigned w = next;
+      if (kk > 0) next = (unsigned)sched[(kk - 1) * 64];
+      bool live = kk < num, valid = (w >> 26) & 1u;
+      int kkadr = w & 1023, ijt = (w >> 10) & 1023, a = (w >> 20) & 7, t = (w >> 23) & 7;
+      int ki = kkadr + 1 + a;
       real tmp = 0, val = 0;
-      int ij = 0;
       if (valid) {
-        ij = m.M_coldiag[ki];
         tmp = S[ld + ki] / S[ld + kkadr];
-        val = S[ld + ij + t] - tmp * S[ld + ki + t];
+        val = S[ld + ijt] - tmp * S[ld + ki + t];
       }
       wv::sync();
       if (valid) {
-        S[ld + ij + t] = val;
+        S[ld + ijt] = val;
         if (t == 0) S[ld + ki] = tmp;
       }
-      if (live && p == 0) S[dinv + k] = 1.0 / S[ld + kkadr];
+      if (live && p == 0) S[dinv + adr0 + kk] = 1.0 / S[ld + kkadr];
       wv::sync();
     }
   }
+}
+
+// x <- (selected factors of) M^-1 x for a vector held ONE DOF PER LANE in the tree-row lane map, entirely in
+// registers: step kk broadcasts x of the tree's kk-th dof inside the tree's row of 16 lanes (DPP), every lane
+// subtracts its factor entry times that value.  The factor entries are fetched from LDS up front, so the dependent
+// chain is DPP + multiply + subtract only.  Backward: descendants before ancestors; forward: ancestors first.
+__device__ inline real solve_rows(const DevModel& m, const RowK& R, const real* S, int ld, int dinv, real x, bool backward,
+                                  bool scale, bool forward) {
+  real lb[16], lf[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    lb[k] = (backward && R.eb[k] >= 0) ? S[ld + R.eb[k]] : 0.0;
+    lf[k] = (forward && R.ef[k] >= 0) ? S[ld + R.ef[k]] : 0.0;
+  }
+  real di = (scale && R.dof >= 0) ? S[dinv + R.dof] : 1.0;
+  if (backward) {
+#define MJ_BSTEP(KK) if (KK < m.maxtreedof) { real xk = wv::bcast16<KK>(x); x = x - lb[KK] * xk; }
+    MJ_BSTEP(15) MJ_BSTEP(14) MJ_BSTEP(13) MJ_BSTEP(12) MJ_BSTEP(11) MJ_BSTEP(10) MJ_BSTEP(9) MJ_BSTEP(8)
+    MJ_BSTEP(7) MJ_BSTEP(6) MJ_BSTEP(5) MJ_BSTEP(4) MJ_BSTEP(3) MJ_BSTEP(2) MJ_BSTEP(1)
+#undef MJ_BSTEP
+  }
+  if (scale) x = x * di;
+  if (forward) {
+#define MJ_FSTEP(KK) if (KK < m.maxtreedof) { real xk = wv::bcast16<KK>(x); x = x - lf[KK] * xk; }
+    MJ_FSTEP(0) MJ_FSTEP(1) MJ_FSTEP(2) MJ_FSTEP(3) MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7)
+    MJ_FSTEP(8) MJ_FSTEP(9) MJ_FSTEP(10) MJ_FSTEP(11) MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14)
+#undef MJ_FSTEP
+  }
+  return x;
 }
 
 // x <- (selected factors of) M^-1 x with the factor at ld/dinv; x lives in LDS at S[x..x+nv).  Level-parallel over
@@ -345,8 +389,17 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
       int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
       V3 dif = ld3(S + l.gpos + 3 * g2) - ld3(S + l.gpos + 3 * g1);
       bool pass;
-      if (t1 == GEOM_PLANE) pass = !(dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2)) > bound);
-      else pass = !(dot(dif, dif) > bound * bound);
+      if (t1 == GEOM_PLANE) {
+        pass = !(dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2)) > bound);
+      } else if (t2 == GEOM_BOX && t1 != GEOM_BOX) {
+        // geom1's bounding sphere against the box itself: a long wall's bounding sphere would cover the whole arena
+        V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(m.geom_size + 3 * g2);
+        real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
+        real reach = m.geom_rbound[g1] + m.pair_margin[p];
+        pass = !(ex * ex + ey * ey + ez * ez > reach * reach);
+      } else {
+        pass = !(dot(dif, dif) > bound * bound);
+      }
       if (pass) {
         items = pair_items(t1, t2);
         if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) {
@@ -491,7 +544,7 @@ __device__ inline void stage_velocity(const DevModel& m, const Lay& l, const Lan
 }
 
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
-__device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+__device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK& K, const RowK& R, real* S, int L) {
   if (L < m.nv) {
     real act = 0;
     if (K.d_act >= 0) {
@@ -513,7 +566,14 @@ __device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK
     S[l.qaccs + L] = sm;
   }
   wv::sync();
-  solve_ld(m, K, S, l.LD, l.Dinv, l.qaccs, L, true, true, true);
+  if (m.rowmap) {
+    real x = solve_rows(m, R, S, l.LD, l.Dinv, R.dof >= 0 ? S[l.qaccs + R.dof] : 0.0, true, true, true);
+    wv::sync();
+    if (R.dof >= 0) S[l.qaccs + R.dof] = x;
+    wv::sync();
+  } else {
+    solve_ld(m, K, S, l.LD, l.Dinv, l.qaccs, L, true, true, true);
+  }
 }
 
 // ------------------------------------------------------------------ constraint rows
@@ -570,7 +630,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     real* Jr = S + l.J + l.ldj * r;
     real* R = S + l.row + ROW_STRIDE * r;
     for (int k = 0; k < m.nv; k++) Jr[k] = 0;
-    int id = I[l.i_rowid + r];
+    int id = I[l.i_rowid + r], rtree = -1;
     real pos, margin, diag, mu0 = 0;
     const real *solref, *solimp;
     real sref[2], simp[5];
@@ -579,6 +639,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       int it = -id - 1, j = it >> 1, side = (it & 1) ? 1 : -1;
       int dof = m.jnt_dofadr[j];
       Jr[dof] = -side;
+      rtree = m.dof_treeid[dof];
       pos = R[ROW_F];
       margin = m.jnt_margin[j];
       diag = m.dof_invweight0[dof];
@@ -597,6 +658,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       real sgn = (sub & 1) ? -1.0 : 1.0;
       V3 tk = ld3(C + CON_FRAME + 3 * kt);
       int t1 = m.body_treeid[b1], t2 = m.body_treeid[b2];
+      rtree = (t1 >= 0 && t2 >= 0 && t1 != t2) ? -2 : (t1 > t2 ? t1 : t2);   // -2: the row couples two trees
       V3 off1 = t1 >= 0 ? cp - ld3(S + l.com + 3 * t1) : v3(0, 0, 0);
       V3 off2 = t2 >= 0 ? cp - ld3(S + l.com + 3 * t2) : v3(0, 0, 0);
       // the two bodies' dof chains (descending dof ids, stored contiguously in the sparse-M row of the last dof)
@@ -650,6 +712,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     R[ROW_R] = Rr;
     R[ROW_B] = ja - aref;
     R[ROW_F] = jar < 0 ? -Dr * jar : 0.0;
+    I[l.i_rowtree + r] = rtree;
   }
   wv::sync();
 }
@@ -684,24 +747,27 @@ __device__ inline void stage_project(const DevModel& m, const Lay& l, real* S, i
   wv::sync();
 }
 
-// projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed:
-// lane d carries u_d = (B' f)_d, a row's residual is one wave reduction, its update one multiply-add.
-__device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+// projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed: the lane that
+// owns dof d carries u_d = (B' f)_d, a row's residual is one reduction over its tree's lanes, its update one
+// multiply-add.  In the tree-row lane map a constraint row that touches one kinematic tree only involves that tree's
+// row of 16 lanes, so the trees sweep their own rows side by side (rows of different trees commute, the order inside
+// a tree is the solver's row order); a step with a row that couples two trees falls back to the serial sweep.
+__device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L) {
   int* I = (int*)(S + l.ints);
   int nefc = I[I_NEFC];
-  bool dof = L < m.nv;
-  const int width = m.nv <= 16 ? 16 : (m.nv <= 32 ? 32 : 64);
-  real dinv = dof ? S[l.Dinv + L] : 0.0;
+  const int mydof = RK.dof;
+  const bool dof = mydof >= 0;
+  real dinv = dof ? S[l.Dinv + mydof] : 0.0;
   real u = 0;
   if (nefc == 0) {
     if (L == 0) I[I_NITER] = 0;
-    if (dof) { S[l.qfc + L] = 0; S[l.qacc + L] = S[l.qaccs + L]; S[l.warm + L] = S[l.qaccs + L]; }
+    if (L < m.nv) { S[l.qfc + L] = 0; S[l.qacc + L] = S[l.qaccs + L]; S[l.warm + L] = S[l.qaccs + L]; }
     wv::sync();
     return;
   }
   // warm start: keep the forces implied by last step's acceleration only if they beat f = 0
   if (dof)
-    for (int r = 0; r < nefc; r++) u += S[l.J + l.ldj * r + L] * S[l.row + ROW_STRIDE * r + ROW_F];
+    for (int r = 0; r < nefc; r++) u += S[l.J + l.ldj * r + mydof] * S[l.row + ROW_STRIDE * r + ROW_F];
   real part = 0.5 * dinv * u * u;
   for (int r = L; r < nefc; r += 64) {
     const real* R = S + l.row + ROW_STRIDE * r;
@@ -712,47 +778,106 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     u = 0;
     for (int r = L; r < nefc; r += 64) S[l.row + ROW_STRIDE * r + ROW_F] = 0;
   }
+  // per-tree row lists (the work-item list of the collision stage is free again): slot[base_t + rank] = row
+  const int mytree = L >> 4;
+  int cnt_my = 0, base_my = 0, tmax = 0;
+  bool cross = false;
+  if (m.rowmap) {
+    int total = 0;
+    for (int t = 0; t < m.ntree; t++) {
+      int cnt = 0;
+      for (int base = 0; base < nefc; base += 64) {
+        int r = base + L;
+        int rt = r < nefc ? I[l.i_rowtree + r] : -1;
+        unsigned long long mask = wv::ballot(rt == t);
+        if (rt == t) I[l.i_item + total + cnt + wv::popc(mask & ((1ull << L) - 1ull))] = r;
+        cnt += wv::popc(mask);
+        if (t == 0) cross |= wv::ballot(rt == -2) != 0ull;
+      }
+      if (t == mytree) { cnt_my = cnt; base_my = total; }
+      total += cnt;
+      tmax = cnt > tmax ? cnt : tmax;
+    }
+  }
   wv::sync();
   real scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
   int iter = 0;
-  while (iter < m.iterations) {
-    real improvement = 0;
-    for (int i = 0; i < nefc; i++) {
-      const real* R = S + l.row + ROW_STRIDE * i;
-      real bid = dof ? S[l.J + l.ldj * i + L] : 0.0;
-      real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = R[ROW_ARINV];
-      // the dofs sit in lanes [0, width): reduce there, then hand lane 0's sum to the whole wave
-      real res = wv::first(wv::sum_n(bid * dinv * u, width)) + Ri * fi + bi;
-      real fn = fi - res * ainv;
-      if (fn < 0) fn = 0;
-      real delta = fn - fi;
-      real change = 0.5 * delta * delta * aii + delta * res;
-      if (change > 1e-10) { fn = fi; delta = 0; change = 0; }
-      improvement -= change;
-      u += delta * bid;
-      if (L == 0) S[l.row + ROW_STRIDE * i + ROW_F] = fn;
+  if (m.rowmap && !cross) {
+    const bool leader = (L & 15) == 0;
+    while (iter < m.iterations) {
+      real imp = 0;
+      for (int s = 0; s < tmax; s++) {
+        bool has = s < cnt_my;
+        int i = has ? I[l.i_item + base_my + s] : 0;
+        const real* R = S + l.row + ROW_STRIDE * i;
+        real bid = (dof && has) ? S[l.J + l.ldj * i + mydof] : 0.0;
+        real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = R[ROW_ARINV];
+        real res = wv::sum16(bid * dinv * u) + Ri * fi + bi;
+        real fn = fi - res * ainv;
+        if (fn < 0) fn = 0;
+        real delta = fn - fi;
+        real change = 0.5 * delta * delta * aii + delta * res;
+        if (change > 1e-10 || !has) { fn = fi; delta = 0; change = 0; }
+        imp -= change;
+        u += delta * bid;
+        if (leader && has) S[l.row + ROW_STRIDE * i + ROW_F] = fn;
+      }
+      iter++;
+      real improvement = wv::sum(leader ? imp : 0.0);
+      wv::sync();
+      if (improvement * scale < m.tolerance) break;
     }
-    iter++;
-    wv::sync();
-    if (improvement * scale < m.tolerance) break;
+  } else {
+    const int width = m.rowmap ? 64 : (m.nv <= 16 ? 16 : (m.nv <= 32 ? 32 : 64));
+    while (iter < m.iterations) {
+      real improvement = 0;
+      for (int i = 0; i < nefc; i++) {
+        const real* R = S + l.row + ROW_STRIDE * i;
+        real bid = dof ? S[l.J + l.ldj * i + mydof] : 0.0;
+        real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = R[ROW_ARINV];
+        // reduce over the lanes that hold dofs, then hand lane 0's sum to the whole wave
+        real res = wv::first(wv::sum_n(bid * dinv * u, width)) + Ri * fi + bi;
+        real fn = fi - res * ainv;
+        if (fn < 0) fn = 0;
+        real delta = fn - fi;
+        real change = 0.5 * delta * delta * aii + delta * res;
+        if (change > 1e-10) { fn = fi; delta = 0; change = 0; }
+        improvement -= change;
+        u += delta * bid;
+        if (L == 0) S[l.row + ROW_STRIDE * i + ROW_F] = fn;
+      }
+      iter++;
+      wv::sync();
+      if (improvement * scale < m.tolerance) break;
+    }
   }
   if (L == 0) I[I_NITER] = iter;
   // back to joint space: qfrc_constraint = L' u ; qacc = qacc_smooth + L^-1 D^-1 u
-  if (dof) S[l.x + L] = u;
+  if (dof) S[l.x + mydof] = u;
   wv::sync();
-  if (dof) {
-    real q = u;
+  if (L < m.nv) {
+    real q = S[l.x + L];
     for (int c = 0; c < K.d_descnum; c++) q += S[l.LD + m.desc_Madr[K.d_descadr + c]] * S[l.x + m.desc_row[K.d_descadr + c]];
     S[l.qfc + L] = q;
   }
-  wv::sync();
-  solve_ld(m, K, S, l.LD, l.Dinv, l.x, L, false, true, true);
-  if (dof) {
-    real a = S[l.qaccs + L] + S[l.x + L];
-    S[l.qacc + L] = a;
-    S[l.warm + L] = a;
+  if (m.rowmap) {
+    real x = solve_rows(m, RK, S, l.LD, l.Dinv, u, false, true, true);
+    if (dof) {
+      real a = S[l.qaccs + mydof] + x;
+      S[l.qacc + mydof] = a;
+      S[l.warm + mydof] = a;
+    }
+    wv::sync();
+  } else {
+    wv::sync();
+    solve_ld(m, K, S, l.LD, l.Dinv, l.x, L, false, true, true);
+    if (L < m.nv) {
+      real a = S[l.qaccs + L] + S[l.x + L];
+      S[l.qacc + L] = a;
+      S[l.warm + L] = a;
+    }
+    wv::sync();
   }
-  wv::sync();
 }
 
 // ------------------------------------------------------------------ sensors (mj_forward's sensor stage)
@@ -823,7 +948,7 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
 }
 
 // ------------------------------------------------------------------ integrator
-__device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+__device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L) {
   real h = m.timestep;
   bool damped = wv::ballot(L < m.nv && K.d_damping > 0) != 0ull;
   if (damped) {
@@ -834,7 +959,14 @@ __device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK&
     }
     wv::sync();
     factor_ld(m, S, l.LD, l.Dinv, L);
-    solve_ld(m, K, S, l.LD, l.Dinv, l.x, L, true, true, true);
+    if (m.rowmap) {
+      real x = solve_rows(m, RK, S, l.LD, l.Dinv, RK.dof >= 0 ? S[l.x + RK.dof] : 0.0, true, true, true);
+      wv::sync();
+      if (RK.dof >= 0) S[l.x + RK.dof] = x;
+      wv::sync();
+    } else {
+      solve_ld(m, K, S, l.LD, l.Dinv, l.x, L, true, true, true);
+    }
   } else {
     if (L < m.nv) S[l.x + L] = S[l.qacc + L];
     wv::sync();
@@ -864,6 +996,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   make_layout(m, l);
   LaneK K;
   load_lane_constants(m, L, K);
+  RowK RK;
+  load_row_constants(m, L, RK);
   unsigned long long t_prev = a.stamps ? wv::clock() : 0ull;
 #define MJ_STAMP(k)                                                        \
   if (a.stamps) {                                                          \
@@ -904,7 +1038,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     MJ_STAMP(ST_COLLIDE)
     stage_velocity(m, l, K, S, L, false);
     MJ_STAMP(ST_VEL)
-    stage_smooth(m, l, K, S, L);
+    stage_smooth(m, l, K, RK, S, L);
     MJ_STAMP(ST_SMOOTH)
     stage_rows(m, l, S, L);
     MJ_STAMP(ST_ROWS)
@@ -912,13 +1046,13 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     stage_project(m, l, S, L);
     MJ_STAMP(ST_PROJECT)
-    stage_pgs(m, l, K, S, L);
+    stage_pgs(m, l, K, RK, S, L);
     MJ_STAMP(ST_PGS)
     stage_sensors(m, l, K, S, L);
     MJ_STAMP(ST_SENSORS)
     if (a.dbg && a.dbg_stage == 0 && frame == a.skip_frames - 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
-    if (!a.forward_only) stage_euler(m, l, K, S, L);
+    if (!a.forward_only) stage_euler(m, l, K, RK, S, L);
     MJ_STAMP(ST_EULER)
   }
   // state out

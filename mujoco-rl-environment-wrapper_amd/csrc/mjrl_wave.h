@@ -47,6 +47,13 @@ __device__ __forceinline__ double sum_n(double v, int width) {
 }
 __device__ __forceinline__ double sum(double v) { return sum_n(v, 64); }
 
+// value of lane N of the caller's row of 16 lanes, in every lane of that row (DPP row_newbcast, no LDS traffic)
+template <int N>
+__device__ __forceinline__ double bcast16(double v) { return dpp<0x150 + N>(v); }
+
+// all-reduce (sum) inside each row of 16 lanes only
+__device__ __forceinline__ double sum16(double v) { return sum_n(v, 16); }
+
 // lane 0's value in every lane (v_readfirstlane: the result is wave-uniform)
 __device__ __forceinline__ double first(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));

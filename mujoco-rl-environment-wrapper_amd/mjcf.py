@@ -123,6 +123,9 @@ class Model:
     nchild: int = 0
     maxdofdepth: int = 0
     maxtreedof: int = 0
+    rowmap: int = 0
+    nfactor: int = 0
+    npass: int = 0
     # options
     timestep: float = 0.002
     gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
@@ -665,7 +668,85 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
     m.njmax = int(njmax) if njmax is not None else n_limited + 4 * m.nconmax
 
     _set_const(m)
+    _kernel_schedules(m)
     return m
+
+
+def _kernel_schedules(m: Model):
+    """Lane schedules the step kernel replays instead of decoding the tree structure on the fly.
+
+    * ``factor_sched[pass][kk][lane]``: the L'DL elimination eliminates the kk-th dof of up to two trees per pass
+      (32 lanes each); a lane owns one (ancestor a, offset t) pair of the pivot row.  Packed word:
+      bits 0-9 address of the pivot diagonal M[k][k] (L[k][i] sits at that + 1 + a, M[k][j] at that + 1 + a + t),
+      bits 10-19 address of M[i][j] to update, 20-22 a, 23-25 t, bit 26 pair valid.
+    * tree-row lane map (``rowmap`` = 1 when every tree has <= 16 dofs and there are <= 4 trees): tree t owns lanes
+      16t..16t+15, ``row_dof[lane]`` is the lane's dof (or -1).  ``solve_b[kk][lane]`` / ``solve_f[kk][lane]`` hold
+      the factor entries a lane multiplies in step kk of the backward / forward triangular solve (or -1).
+    """
+    A = m.arrays
+    nv, ntree = m.nv, m.ntree
+    Madr, depth, colid = A["dof_Madr"], A["dof_depth"], A["M_colid"]
+    tadr, tnum = A["tree_dofadr"], A["tree_dofnum"]
+    groups = 2 if ntree > 1 else 1
+    width = 64 // groups
+    npass = (ntree + groups - 1) // groups if ntree else 0
+    sched = np.zeros((max(npass, 1), max(m.maxtreedof, 1), 64), np.int64)
+    for ps in range(npass):
+        for g in range(groups):
+            tree = ps * groups + g
+            if tree >= ntree:
+                continue
+            for kk in range(int(tnum[tree])):
+                k = int(tadr[tree]) + kk
+                D, kkadr = int(depth[k]), int(Madr[k])
+                pairs = [(a, t) for a in range(D) for t in range(D - a)]
+                if len(pairs) > width:
+                    raise ValueError("a dof chain is too deep for the factorisation schedule (more than %d pairs)" % width)
+                for lane in range(width):
+                    word = kkadr
+                    if lane < len(pairs):
+                        a, t = pairs[lane]
+                        ki = kkadr + 1 + a
+                        ij = int(Madr[colid[ki]])
+                        word |= ((ij + t) << 10) | (a << 20) | (t << 23) | (1 << 26)
+                        if ki + t >= 1024 or ij + t >= 1024 or a > 7 or t > 7:
+                            raise ValueError("sparse inertia matrix too large for the packed schedule (nM >= 1024)")
+                    sched[ps, kk, g * width + lane] = word
+    m.npass = npass
+    A["factor_sched"] = sched.astype(np.uint32).view(np.int32).reshape(-1)
+    m.nfactor = int(A["factor_sched"].size)
+
+    rowmap = int(ntree >= 1 and ntree <= 4 and m.maxtreedof <= 16)
+    m.rowmap = rowmap
+    row_dof = np.full(64, -1, np.int32)
+    solve_b = np.full((16, 64), -1, np.int32)
+    solve_f = np.full((16, 64), -1, np.int32)
+    if rowmap:
+        for t in range(ntree):
+            for loc in range(int(tnum[t])):
+                row_dof[16 * t + loc] = int(tadr[t]) + loc
+        for lane in range(64):
+            d = int(row_dof[lane])
+            if d < 0:
+                continue
+            t = lane // 16
+            anc = [int(colid[Madr[d] + s]) for s in range(1, int(depth[d]) + 1)]      # proper ancestors of d, walking up
+            for kk in range(int(tnum[t])):
+                k = int(tadr[t]) + kk
+                # backward step kk: x[d] -= L[k][d] * x[k] when d is a proper ancestor of k
+                kanc = [int(colid[Madr[k] + s]) for s in range(1, int(depth[k]) + 1)]
+                if d in kanc:
+                    solve_b[kk, lane] = int(Madr[k]) + 1 + kanc.index(d)
+                # forward step kk: x[d] -= L[d][k] * x[k] when k is a proper ancestor of d
+                if k in anc:
+                    solve_f[kk, lane] = int(Madr[d]) + 1 + anc.index(k)
+    A["row_dof"], A["solve_b"], A["solve_f"] = row_dof, solve_b.reshape(-1), solve_f.reshape(-1)
+    # tree of every body's dofs as seen by a constraint row (static bodies: -1) is body_treeid; dof -> lane
+    dof_lane = np.full(max(nv, 1), -1, np.int32)
+    for lane in range(64):
+        if row_dof[lane] >= 0:
+            dof_lane[row_dof[lane]] = lane
+    A["dof_lane"] = dof_lane[:nv] if nv else np.zeros(0, np.int32)
 
 
 # ----------------------------------------------------------------------------- constants at qpos0

@@ -220,17 +220,23 @@ static inline int ora_capsule_box(ora_rawcon* c, const double* cpos, const doubl
   v3_sub(rel, cpos, bpos);
   m3_mulTv(p0, bmat, rel);
   m3_mulTv(ax, bmat, axis_w);
-  /* closest parameter on the segment: root of a monotone piecewise-linear slope, by bisection */
+  /* closest parameter on the segment: root of a monotone slope that is piecewise linear in t, with kinks where a
+   * coordinate crosses a box face.  Bracket the root between kinks, then solve the linear piece exactly. */
   double lo = -len, hi = len, tstar;
   double glo = ora_segbox_slope(p0, ax, bsize, lo), ghi = ora_segbox_slope(p0, ax, bsize, hi);
   if (glo >= 0.0) tstar = lo;
   else if (ghi <= 0.0) tstar = hi;
   else {
-    for (int it = 0; it < 60; it++) {
-      double mid = 0.5 * (lo + hi);
-      if (ora_segbox_slope(p0, ax, bsize, mid) < 0.0) lo = mid; else hi = mid;
+    for (int k = 0; k < 3; k++) {
+      if (fabs(ax[k]) < ORA_MINVAL) continue;
+      for (int s = -1; s <= 1; s += 2) {
+        double tb = (s * bsize[k] - p0[k]) / ax[k];
+        if (tb <= lo || tb >= hi) continue;
+        double gb = ora_segbox_slope(p0, ax, bsize, tb);
+        if (gb < 0.0) { lo = tb; glo = gb; } else { hi = tb; ghi = gb; }
+      }
     }
-    tstar = 0.5 * (lo + hi);
+    tstar = lo - glo * (hi - lo) / (ghi - glo);
   }
   double dstar = ora_pointbox_dist(p0, ax, bsize, tstar);
   double dpos = ora_pointbox_dist(p0, ax, bsize, len), dneg = ora_pointbox_dist(p0, ax, bsize, -len);

@@ -54,6 +54,9 @@ inline double sum_n(double v, int width) {   // all-reduce over aligned groups o
 }
 inline double sum(double v) { return sum_n(v, 64); }
 inline double first(double v) { return shfl(v, 0); }   // lane 0's value in every lane
+template <int N>
+inline double bcast16(double v) { return shfl(v, (lane() & ~15) + N); }   // lane N of the caller's row of 16
+inline double sum16(double v) { return sum_n(v, 16); }
 inline double min_pos(double v) {
   for (int mask = 1; mask < 64; mask <<= 1) v = std::fmin(v, shfl_xor(v, mask));
   return v;
