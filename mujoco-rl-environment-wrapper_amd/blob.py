@@ -18,11 +18,12 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 9
+VERSION = 10
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
-               "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "has_accel", "nitemmax", "rowmap", "nfactor", "npass"]
+               "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "has_accel", "nitemmax", "rowmap", "nfactor", "npass",
+               "ntab", "reserved0"]
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
@@ -62,6 +63,7 @@ I32_FIELDS = [
     ("body_subtreenum", "nbody"), ("tree_dofadr", "ntree"), ("tree_dofnum", "ntree"),
     ("desc_row", "ndesc"), ("M_coldiag", "nM"), ("dof_actid", "nv"),
     ("factor_sched", "nfactor"), ("row_dof", "64"), ("solve_b", "1024"), ("solve_f", "1024"), ("dof_lane", "nv"),
+    ("lds_tab", "ntab"), ("pair_word", "npair"), ("pair_reach", "npair"),
 ]
 
 
@@ -78,6 +80,7 @@ def _sizes(model) -> dict:
     s["has_accel"] = int(any(int(t) == 1 for t in model.sensor_type))     # accelerometers keep cacc/cdof_dot alive
     # narrow-phase work-item list: room for every pair that can plausibly pass the bounding-sphere test at once
     s["nitemmax"] = int(getattr(model, "nitemmax", 0)) or 64 + 160 * max(int(model.ntree), 1)
+    s["reserved0"] = 0
     return s
 
 

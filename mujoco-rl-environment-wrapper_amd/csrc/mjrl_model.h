@@ -47,8 +47,8 @@ static inline int mjrl_model_from_blob(DevModel* m, const void* host_blob, size_
   const char* b = (const char*)base;
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom, nsite = m->nsite,
       ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nM = m->nM, ndesc = m->ndesc, nchild = m->nchild,
-      ntree = m->ntree, nfactor = m->nfactor;
-  (void)nfactor; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
+      ntree = m->ntree, nfactor = m->nfactor, ntab = m->ntab;
+  (void)nfactor; (void)ntab; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
   (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
 #define X(name, count) m->name = (const double*)(b + off); off += 8 * (size_t)(count);
   MJRL_F64_FIELDS(X)

@@ -37,7 +37,7 @@ enum { MAX_DOF_DEPTH = 8 };
 // {J, row} from the constraint-row build to the sensors.
 struct Lay {
   int qpos, qvel, ctrl, warm, xpos, xquat, com, cdof, cdofdot, cvel, cacc, M, LD, Dinv, gpos, gquat, bias, smooth, qaccs,
-      x, qfc, qacc, con, sens, ints, u, total;
+      x, qfc, qacc, con, sens, gsize, tab, ints, u, total;
   int xanchor, xaxis, cinert, crb;   // inside u, first lifetime
   int J, row;                        // inside u, second lifetime
   int ldj;                           // row stride of J (odd -> conflict-free column walks)
@@ -55,6 +55,7 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   REG(gpos, 3 * m.ngeom) REG(gquat, 4 * m.ngeom)
   REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(x, m.nv) REG(qfc, m.nv) REG(qacc, m.nv)
   REG(con, CON_STRIDE * m.nconmax) REG(sens, m.nsensordata + 1)
+  REG(gsize, 3 * m.ngeom) REG(tab, (m.ntab + 3) / 4)     // model constants staged once per launch
   int ni = I_HEAD;
   l.i_item = ni; ni += m.nitemmax;
   l.i_cong1 = ni; ni += m.nconmax;
@@ -120,6 +121,43 @@ __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
   k.d_parent = m.dof_parentid[d]; k.d_Madr = m.dof_Madr[d]; k.d_depth = isd ? m.dof_depth[d] : -1;
   k.d_body = m.dof_bodyid[d]; k.d_descadr = m.dof_descadr[d]; k.d_descnum = isd ? m.dof_descnum[d] : 0;
   k.d_act = isd ? m.dof_actid[d] : -1; k.d_damping = m.dof_damping[d]; k.d_armature = m.dof_armature[d];
+}
+
+// Structure tables kept in LDS as 16-bit words (order fixed by mjcf._kernel_schedules): the row build walks them
+// with data-dependent indices, which from HBM would cost one exposed load latency per hop.
+struct Tab {
+  const unsigned short* t;
+  int Mcol, Madr, depth, dtree, lastdof, btree, gbody, gtype, gcondim;
+  __device__ __forceinline__ int colid(int e) const { return t[Mcol + e]; }
+  __device__ __forceinline__ int madr(int d) const { return t[Madr + d]; }
+  __device__ __forceinline__ int ddepth(int d) const { return t[depth + d]; }
+  __device__ __forceinline__ int dof_tree(int d) const { return t[dtree + d]; }
+  __device__ __forceinline__ int body_lastdof(int b) const { return (int)t[lastdof + b] - 1; }
+  __device__ __forceinline__ int body_tree(int b) const { return (int)t[btree + b] - 1; }
+  __device__ __forceinline__ int geom_body(int g) const { return t[gbody + g]; }
+  __device__ __forceinline__ int geom_type(int g) const { return t[gtype + g]; }
+  __device__ __forceinline__ int geom_condim(int g) const { return t[gcondim + g]; }
+};
+
+__device__ inline Tab make_tab(const DevModel& m, const Lay& l, const real* S) {
+  Tab T;
+  T.t = (const unsigned short*)(S + l.tab);
+  T.Mcol = 0; T.Madr = m.nM; T.depth = T.Madr + m.nv; T.dtree = T.depth + m.nv; T.lastdof = T.dtree + m.nv;
+  T.btree = T.lastdof + m.nbody; T.gbody = T.btree + m.nbody; T.gtype = T.gbody + m.ngeom; T.gcondim = T.gtype + m.ngeom;
+  return T;
+}
+
+// copy the launch-invariant tables into LDS (one coalesced sweep per launch)
+__device__ inline void stage_constants(const DevModel& m, const Lay& l, real* S, int L) {
+  unsigned short* t = (unsigned short*)(S + l.tab);
+  for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned short)m.lds_tab[i];
+  for (int i = L; i < 3 * m.ngeom; i += 64) S[l.gsize + i] = m.geom_size[i];
+}
+
+__device__ __forceinline__ float int_as_float(int v) {
+  float f;
+  __builtin_memcpy(&f, &v, sizeof(f));
+  return f;
 }
 
 // The lane's records in the tree-row lane map (tree t owns lanes 16t..16t+15, one dof per lane): the lane's dof and
@@ -381,22 +419,25 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
   int nitem = 0, warn = 0;
   // broad phase: bounding spheres (planes: signed distance of the other geom's bounding sphere).  Every surviving
   // pair expands into its narrow-phase work items, in pair order.
+  // one packed word + one float per candidate pair; the next chunk's are in flight while this chunk is tested
+  int word_next = 0, reach_next = 0;
+  if (L < m.npair) { word_next = m.pair_word[L]; reach_next = m.pair_reach[L]; }
   for (int base = 0; base < m.npair; base += 64) {
     int p = base + L, items = 0;
+    int word = word_next;
+    real bound = (real)int_as_float(reach_next);
+    if (p + 64 < m.npair) { word_next = m.pair_word[p + 64]; reach_next = m.pair_reach[p + 64]; }
     if (p < m.npair) {
-      int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-      real bound = m.pair_bound[p];
-      int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+      int g1 = word & 255, g2 = (word >> 8) & 255, t1 = (word >> 16) & 15, t2 = (word >> 20) & 15;
       V3 dif = ld3(S + l.gpos + 3 * g2) - ld3(S + l.gpos + 3 * g1);
       bool pass;
       if (t1 == GEOM_PLANE) {
         pass = !(dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2)) > bound);
       } else if (t2 == GEOM_BOX && t1 != GEOM_BOX) {
         // geom1's bounding sphere against the box itself: a long wall's bounding sphere would cover the whole arena
-        V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(m.geom_size + 3 * g2);
+        V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
         real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
-        real reach = m.geom_rbound[g1] + m.pair_margin[p];
-        pass = !(ex * ex + ey * ey + ez * ez > reach * reach);
+        pass = !(ex * ex + ey * ey + ez * ez > bound * bound);
       } else {
         pass = !(dot(dif, dif) > bound * bound);
       }
@@ -430,12 +471,13 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
     real margin = 0, gap = 0;
     if (it < nitem) {
       int code = I[l.i_item + it], p = code >> 3, k = code & 7;
-      g1 = m.pair_geom[2 * p]; g2 = m.pair_geom[2 * p + 1];
+      int word = m.pair_word[p];
+      g1 = word & 255; g2 = (word >> 8) & 255;
       margin = m.pair_margin[p];
       gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
-      hit = collide_item(m.geom_type[g1], m.geom_type[g2], ld3(S + l.gpos + 3 * g1), qmat(ldq(S + l.gquat + 4 * g1)),
-                         ld3(m.geom_size + 3 * g1), ld3(S + l.gpos + 3 * g2), qmat(ldq(S + l.gquat + 4 * g2)),
-                         ld3(m.geom_size + 3 * g2), margin, k, rc);
+      hit = collide_item((word >> 16) & 15, (word >> 20) & 15, ld3(S + l.gpos + 3 * g1), qmat(ldq(S + l.gquat + 4 * g1)),
+                         ld3(S + l.gsize + 3 * g1), ld3(S + l.gpos + 3 * g2), qmat(ldq(S + l.gquat + 4 * g2)),
+                         ld3(S + l.gsize + 3 * g2), margin, k, rc);
     }
     unsigned long long mask = wv::ballot(hit);
     if (hit) {
@@ -577,8 +619,13 @@ __device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK
 }
 
 // ------------------------------------------------------------------ constraint rows
-__device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int L) {
+// One lane per row builds the Jacobian row, its reference acceleration and regularisation, and (unless a debug
+// dump of the raw rows was requested) immediately projects it:  J <- J L^-1  by back substitution restricted to the
+// row's own dof chains, and AR_ii = sum_d B_id^2 / D_d + R_i.  A row only touches the dof chains of its (at most
+// two) bodies; the chains are read from the LDS structure tables.
+__device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int L, bool project) {
   int* I = (int*)(S + l.ints);
+  const Tab T = make_tab(m, l, S);
   int ncon = I[I_NCON], warn = I[I_WARN];
   // joint limits: item = (joint, side), lower side first
   int nlim = 0;
@@ -602,30 +649,51 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     nlim += wv::popc(mask);
   }
   if (nlim > m.njmax) { nlim = m.njmax; warn |= 2; }
-  wv::sync();
-  // contacts: address of each pyramid (serial prefix over at most nconmax entries)
-  if (L == 0) {
-    int adr = nlim;
-    for (int c = 0; c < ncon; c++) {
-      const real* C = S + l.con + CON_STRIDE * c;
-      int g1 = I[l.i_cong1 + c], g2 = I[l.i_cong2 + c];
-      int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
-      int rows = dim == 1 ? 1 : 2 * ((dim < 3 ? dim : 3) - 1);
-      int a = -1;
-      if (C[CON_DIST] < C[CON_INCL]) {
-        if (adr + rows <= m.njmax) {
-          a = adr;
-          for (int s = 0; s < rows; s++) I[l.i_rowid + adr + s] = c * 8 + s;
-          adr += rows;
-        } else warn |= 2;
-      }
-      I[l.i_conadr + c] = a;
+  // contacts: one lane per contact, pyramid addresses by prefix sums of the row counts (1, 2 or 4 rows each)
+  {
+    int rows = 0;
+    if (L < ncon) {
+      const real* C = S + l.con + CON_STRIDE * L;
+      int g1 = I[l.i_cong1 + L], g2 = I[l.i_cong2 + L];
+      int dim = T.geom_condim(g1) > T.geom_condim(g2) ? T.geom_condim(g1) : T.geom_condim(g2);
+      if (C[CON_DIST] < C[CON_INCL]) rows = dim == 1 ? 1 : 2 * ((dim < 3 ? dim : 3) - 1);
     }
-    I[I_NEFC] = adr; I[I_NLIM] = nlim; I[I_WARN] = warn;
+    unsigned long long lower = (1ull << L) - 1ull;
+    unsigned long long b1 = wv::ballot(rows >= 1), b2 = wv::ballot(rows >= 2), b4 = wv::ballot(rows >= 4);
+    int adr = nlim + wv::popc(b1 & lower) + wv::popc(b2 & lower) + 2 * wv::popc(b4 & lower);
+    int total = nlim + wv::popc(b1) + wv::popc(b2) + 2 * wv::popc(b4);
+    // contacts are admitted in order until the row cap is reached; a pyramid that does not fit is dropped whole
+    bool fits = rows > 0 && adr + rows <= m.njmax;
+    unsigned long long over = wv::ballot(rows > 0 && !fits);
+    if (over) {
+      // rare: re-run the prefix serially so that later, smaller pyramids are placed exactly as a serial sweep would
+      wv::sync();
+      if (L == 0) {
+        int a = nlim;
+        for (int c = 0; c < ncon; c++) {
+          const real* C = S + l.con + CON_STRIDE * c;
+          int g1 = I[l.i_cong1 + c], g2 = I[l.i_cong2 + c];
+          int dim = T.geom_condim(g1) > T.geom_condim(g2) ? T.geom_condim(g1) : T.geom_condim(g2);
+          int rws = dim == 1 ? 1 : 2 * ((dim < 3 ? dim : 3) - 1);
+          int at = -1;
+          if (C[CON_DIST] < C[CON_INCL] && a + rws <= m.njmax) { at = a; a += rws; }
+          I[l.i_conadr + c] = at;
+        }
+        I[I_NEFC] = a;
+      }
+      wv::sync();
+      warn |= 2;
+      if (L < ncon) { adr = I[l.i_conadr + L]; fits = adr >= 0; }
+      total = I[I_NEFC];
+    }
+    if (L < ncon) {
+      I[l.i_conadr + L] = fits ? adr : -1;
+      if (fits) for (int s = 0; s < rows; s++) I[l.i_rowid + adr + s] = L * 8 + s;
+    }
+    if (L == 0) { I[I_NEFC] = total; I[I_NLIM] = nlim; I[I_WARN] = warn; }
   }
   wv::sync();
   int nefc = I[I_NEFC];
-  // one lane per row: Jacobian row, reference acceleration, regularisation
   for (int r = L; r < nefc; r += 64) {
     real* Jr = S + l.J + l.ldj * r;
     real* R = S + l.row + ROW_STRIDE * r;
@@ -635,11 +703,14 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     const real *solref, *solimp;
     real sref[2], simp[5];
     bool contact = id >= 0;
+    // the row's dof chains: chain x = sparse-M row of dof lx, entries at ax .. ax + nx - 1 (descending dof ids)
+    int a1 = 0, n1 = 0, a2 = 0, n2 = 0;
     if (!contact) {
       int it = -id - 1, j = it >> 1, side = (it & 1) ? 1 : -1;
       int dof = m.jnt_dofadr[j];
       Jr[dof] = -side;
-      rtree = m.dof_treeid[dof];
+      rtree = T.dof_tree(dof);
+      a2 = T.madr(dof); n2 = T.ddepth(dof) + 1;
       pos = R[ROW_F];
       margin = m.jnt_margin[j];
       diag = m.dof_invweight0[dof];
@@ -649,30 +720,29 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       int c = id >> 3, sub = id & 7;
       const real* C = S + l.con + CON_STRIDE * c;
       int g1 = I[l.i_cong1 + c], g2 = I[l.i_cong2 + c];
-      int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-      int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
+      int b1 = T.geom_body(g1), b2 = T.geom_body(g2);
+      int dim = T.geom_condim(g1) > T.geom_condim(g2) ? T.geom_condim(g1) : T.geom_condim(g2);
       V3 cp = ld3(C + CON_POS), n = ld3(C + CON_FRAME);
       real mu = C[CON_MU];     // friction[0] == friction[1]: both tangent directions share it
       mu0 = mu;
       int kt = 1 + (sub >> 1);
       real sgn = (sub & 1) ? -1.0 : 1.0;
       V3 tk = ld3(C + CON_FRAME + 3 * kt);
-      int t1 = m.body_treeid[b1], t2 = m.body_treeid[b2];
+      int t1 = T.body_tree(b1), t2 = T.body_tree(b2);
       rtree = (t1 >= 0 && t2 >= 0 && t1 != t2) ? -2 : (t1 > t2 ? t1 : t2);   // -2: the row couples two trees
       V3 off1 = t1 >= 0 ? cp - ld3(S + l.com + 3 * t1) : v3(0, 0, 0);
       V3 off2 = t2 >= 0 ? cp - ld3(S + l.com + 3 * t2) : v3(0, 0, 0);
-      // the two bodies' dof chains (descending dof ids, stored contiguously in the sparse-M row of the last dof)
-      int l1 = m.body_lastdof[b1], l2 = m.body_lastdof[b2];
-      int a1 = l1 >= 0 ? m.dof_Madr[l1] : 0, n1 = l1 >= 0 ? m.dof_depth[l1] + 1 : 0;
-      int a2 = l2 >= 0 ? m.dof_Madr[l2] : 0, n2 = l2 >= 0 ? m.dof_depth[l2] + 1 : 0;
+      int l1 = T.body_lastdof(b1), l2 = T.body_lastdof(b2);
+      if (l1 >= 0) { a1 = T.madr(l1); n1 = T.ddepth(l1) + 1; }
+      if (l2 >= 0) { a2 = T.madr(l2); n2 = T.ddepth(l2) + 1; }
       int p1 = 0, p2 = 0;
-      int i1 = n1 > 0 ? m.M_colid[a1] : -1, i2 = n2 > 0 ? m.M_colid[a2] : -1;
+      int i1 = n1 > 0 ? T.colid(a1) : -1, i2 = n2 > 0 ? T.colid(a2) : -1;
       while (i1 >= 0 || i2 >= 0) {
         int i = i1 > i2 ? i1 : i2;
         V3 ca = ld3(S + l.cdof + 6 * i), cl = ld3(S + l.cdof + 6 * i + 3);
         V3 colv = v3(0, 0, 0);
-        if (i2 == i) { colv = cl + cross(ca, off2); p2++; i2 = p2 < n2 ? m.M_colid[a2 + p2] : -1; }
-        if (i1 == i) { colv = colv - (cl + cross(ca, off1)); p1++; i1 = p1 < n1 ? m.M_colid[a1 + p1] : -1; }
+        if (i2 == i) { colv = cl + cross(ca, off2); p2++; i2 = p2 < n2 ? T.colid(a2 + p2) : -1; }
+        if (i1 == i) { colv = colv - (cl + cross(ca, off1)); p1++; i1 = p1 < n1 ? T.colid(a1 + p1) : -1; }
         real jn = dot(n, colv);
         Jr[i] = dim == 1 ? jn : jn + sgn * mu * dot(tk, colv);
       }
@@ -691,13 +761,21 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       solimp = simp;
       contact = dim > 1;
     }
-    // velocity, smooth acceleration and warm-start acceleration along the row (ascending dof order)
+    // velocity, smooth acceleration and warm-start acceleration along the row: ascending over the union of the two
+    // chains (every other entry of the row is zero, so this is the full ascending dot product)
     real vel = 0, ja = 0, jw = 0;
-    for (int k = 0; k < m.nv; k++) {
-      real jk = Jr[k];
-      vel += jk * S[l.qvel + k];
-      ja += jk * S[l.qaccs + k];
-      jw += jk * S[l.warm + k];
+    {
+      int p1 = n1 - 1, p2 = n2 - 1;
+      int i1 = p1 >= 0 ? T.colid(a1 + p1) : 1 << 20, i2 = p2 >= 0 ? T.colid(a2 + p2) : 1 << 20;
+      while (p1 >= 0 || p2 >= 0) {
+        int i = i1 < i2 ? i1 : i2;
+        if (i1 == i) { p1--; i1 = p1 >= 0 ? T.colid(a1 + p1) : 1 << 20; }
+        if (i2 == i) { p2--; i2 = p2 >= 0 ? T.colid(a2 + p2) : 1 << 20; }
+        real jk = Jr[i];
+        vel += jk * S[l.qvel + i];
+        ja += jk * S[l.qaccs + i];
+        jw += jk * S[l.warm + i];
+      }
     }
     real imp = impedance(solimp, pos, margin);
     real dmax = fmin(fmax(solimp[1], MJ_MINIMP), MJ_MAXIMP);
@@ -713,36 +791,27 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     R[ROW_B] = ja - aref;
     R[ROW_F] = jar < 0 ? -Dr * jar : 0.0;
     I[l.i_rowtree + r] = rtree;
-  }
-  wv::sync();
-}
-
-// J <- J L^-1 (row-wise back substitution against the factor), then AR_ii = sum_d B_id^2 / D_d + R_i
-__device__ inline void stage_project(const DevModel& m, const Lay& l, real* S, int L) {
-  int* I = (int*)(S + l.ints);
-  int nefc = I[I_NEFC];
-  for (int base = 0; base < nefc; base += 64) {
-    int r = base + L;
-    bool own = r < nefc;
-    real* Jr = S + l.J + l.ldj * (own ? r : 0);
-    for (int k = m.nv - 1; k >= 0; k--) {       // k, adr and the column ids are wave-uniform (scalar loads)
-      int depth = m.dof_depth[k];
-      if (depth == 0) continue;
-      real v = own ? Jr[k] : 0.0;
-      if (wv::ballot(v != 0.0) == 0ull) continue;
-      int adr = m.dof_Madr[k];
-      for (int t = 1; t <= depth; t++) {
-        int j = m.M_colid[adr + t];
-        if (v != 0.0) Jr[j] -= v * S[l.LD + adr + t];
+    if (!project) continue;
+    // J <- J L^-1 restricted to the chains: descending over the union, each dof pushes its value to its ancestors
+    real acc = 0;
+    {
+      int p1 = 0, p2 = 0;
+      int i1 = n1 > 0 ? T.colid(a1) : -1, i2 = n2 > 0 ? T.colid(a2) : -1;
+      while (i1 >= 0 || i2 >= 0) {
+        int k = i1 > i2 ? i1 : i2;
+        if (i1 == k) { p1++; i1 = p1 < n1 ? T.colid(a1 + p1) : -1; }
+        if (i2 == k) { p2++; i2 = p2 < n2 ? T.colid(a2 + p2) : -1; }
+        real v = Jr[k];
+        acc += v * v * S[l.Dinv + k];
+        if (v != 0.0) {
+          int adr = T.madr(k), depth = T.ddepth(k);
+          for (int t = 1; t <= depth; t++) Jr[T.colid(adr + t)] -= v * S[l.LD + adr + t];
+        }
       }
     }
-    if (own) {
-      real acc = 0;
-      for (int k = 0; k < m.nv; k++) acc += Jr[k] * Jr[k] * S[l.Dinv + k];
-      real aii = acc + S[l.row + ROW_STRIDE * r + ROW_R];
-      S[l.row + ROW_STRIDE * r + ROW_ARII] = aii;
-      S[l.row + ROW_STRIDE * r + ROW_ARINV] = 1.0 / aii;
-    }
+    real aii = acc + Rr;
+    R[ROW_ARII] = aii;
+    R[ROW_ARINV] = 1.0 / aii;
   }
   wv::sync();
 }
@@ -1010,6 +1079,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   MJ_FOR(i, m.nq) S[l.qpos + i] = a.qpos[(size_t)env * m.nq + i];
   MJ_FOR(i, m.nv) { S[l.qvel + i] = a.qvel[(size_t)env * m.nv + i]; S[l.warm + i] = a.warm[(size_t)env * m.nv + i]; }
   MJ_FOR(i, m.nu) S[l.ctrl + i] = a.ctrl[(size_t)env * m.nu + i];
+  stage_constants(m, l, S, L);
   wv::sync();
   // scatter the physical part of every agent's action (mujoco_parent.py:323-332)
   if (a.actions) {
@@ -1040,11 +1110,11 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     MJ_STAMP(ST_VEL)
     stage_smooth(m, l, K, RK, S, L);
     MJ_STAMP(ST_SMOOTH)
-    stage_rows(m, l, S, L);
+    // (a raw-row debug dump keeps J unprojected; such a launch is for inspection only)
+    stage_rows(m, l, S, L, !(a.dbg && a.dbg_stage == 1));
     MJ_STAMP(ST_ROWS)
     if (a.dbg && a.dbg_stage == 1 && frame == a.skip_frames - 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
-    stage_project(m, l, S, L);
     MJ_STAMP(ST_PROJECT)
     stage_pgs(m, l, K, RK, S, L);
     MJ_STAMP(ST_PGS)

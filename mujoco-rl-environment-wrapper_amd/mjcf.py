@@ -126,6 +126,7 @@ class Model:
     rowmap: int = 0
     nfactor: int = 0
     npass: int = 0
+    ntab: int = 0
     # options
     timestep: float = 0.002
     gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
@@ -658,8 +659,15 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
     # broad-phase constants per pair: contact margin and the bounding-sphere reach (plane pairs: the other geom's)
     rb, mg = A["geom_rbound"], A["geom_margin"]
     A["pair_margin"] = np.array([max(mg[a], mg[b]) for a, b in pairs], np.float64)
-    A["pair_bound"] = np.array([(rb[b] if gt[a] == GEOM_PLANE else rb[a] + rb[b]) + max(mg[a], mg[b])
-                                for a, b in pairs], np.float64)
+    # reach of the broad-phase test: plane pairs and (sphere|capsule)-box pairs test ONE bounding sphere against the
+    # plane / the box itself, every other pair tests the two bounding spheres against each other
+    def reach(a, b):
+        if gt[a] == GEOM_PLANE:
+            return rb[b]
+        if gt[b] == GEOM_BOX and gt[a] != GEOM_BOX:
+            return rb[a]
+        return rb[a] + rb[b]
+    A["pair_bound"] = np.array([reach(a, b) + max(mg[a], mg[b]) for a, b in pairs], np.float64)
 
     # caps per env copy (MuJoCo's <size nconmax njmax>): by default room for 8 contacts per kinematic tree and
     # one limit row per limited joint plus a 4-row pyramid per contact
@@ -747,6 +755,22 @@ def _kernel_schedules(m: Model):
         if row_dof[lane] >= 0:
             dof_lane[row_dof[lane]] = lane
     A["dof_lane"] = dof_lane[:nv] if nv else np.zeros(0, np.int32)
+    # Structure tables the row build walks with data-dependent indices; the kernel keeps them in LDS as 16-bit words.
+    # Order (see mjrl_step.h, TabOff): M_colid[nM], dof_Madr[nv], dof_depth[nv], dof_treeid[nv], body_lastdof+1[nbody],
+    # body_treeid+1[nbody], geom_bodyid[ngeom], geom_type[ngeom], geom_condim[ngeom]
+    A["lds_tab"] = np.concatenate([
+        colid, Madr, depth, A["dof_treeid"], A["body_lastdof"] + 1, A["body_treeid"] + 1,
+        A["geom_bodyid"], A["geom_type"], A["geom_condim"]]).astype(np.int32)
+    m.ntab = int(A["lds_tab"].size)
+    if A["lds_tab"].size and (A["lds_tab"].max() > 65535 or A["lds_tab"].min() < 0):
+        raise ValueError("structure table entry does not fit 16 bits")
+    # broad-phase word per candidate pair: geom1 | geom2 << 8 | type1 << 16 | type2 << 20, and the reach as float32
+    # (rounded up: the broad phase only has to be conservative)
+    pg = A["pair_geom"]
+    gt = A["geom_type"]
+    A["pair_word"] = np.array([int(a) | (int(b) << 8) | (int(gt[a]) << 16) | (int(gt[b]) << 20) for a, b in pg], np.int32)
+    A["pair_reach"] = (np.nextafter(A["pair_bound"].astype(np.float32), np.float32(np.inf))).view(np.int32) \
+        if len(pg) else np.zeros(0, np.int32)
 
 
 # ----------------------------------------------------------------------------- constants at qpos0

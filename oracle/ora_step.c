@@ -91,8 +91,8 @@ ora_model* ora_model_create(const void* blob, size_t nbytes) {
 #undef X
   p += 8 * ORA_NOPTS;
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom, nsite = m->nsite, nM = m->nM, ndesc = m->ndesc, nchild = m->nchild, ntree = m->ntree,
-      ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nfactor = m->nfactor;
-  (void)nfactor;
+      ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nfactor = m->nfactor, ntab = m->ntab;
+  (void)nfactor; (void)ntab;
   (void)nM; (void)ndesc; (void)nchild; (void)ntree; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor; (void)npair;
 #define X(name, count) m->name = (const double*)p; p += 8 * (size_t)(count);
   ORA_F64_FIELDS(X)

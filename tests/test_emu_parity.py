@@ -52,16 +52,23 @@ def test_intermediate_quantities_match_after_contacts_appear():
 
 
 def test_constraint_rows_match_before_projection():
+    """Raw Jacobian rows, regularisation and bias of one contact-rich step (a stage-1 dump leaves J unprojected, so
+    that launch is for inspection only and ends the comparison)."""
     model, ora, emu = pair("two_agent.xml")
     rng = np.random.default_rng(5)
     for k in range(500):
         ctrl = rng.uniform(-1, 1, model.nu)
         ora.ctrl[:] = ctrl
         emu.ctrl[:] = ctrl
-        img = emu.step(dbg_stage=1)
+        emu.step()
         ora.step()
         if k > 150 and ora.ncon >= 2:
             break
+    ctrl = rng.uniform(-1, 1, model.nu)
+    ora.ctrl[:] = ctrl
+    emu.ctrl[:] = ctrl
+    img = emu.step(dbg_stage=1)
+    ora.step()
     n = ora.nefc
     assert n >= 8 and img.nefc == n
     assert np.allclose(img.J()[:n], ora.efc_J[:n], atol=1e-12)
