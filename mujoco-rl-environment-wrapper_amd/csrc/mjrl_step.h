@@ -922,12 +922,22 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   }
   if (L == 0) I[I_NITER] = iter;
   // back to joint space: qfrc_constraint = L' u ; qacc = qacc_smooth + L^-1 D^-1 u
-  if (dof) S[l.x + mydof] = u;
-  wv::sync();
-  if (L < m.nv) {
-    real q = S[l.x + L];
-    for (int c = 0; c < K.d_descnum; c++) q += S[l.LD + m.desc_Madr[K.d_descadr + c]] * S[l.x + m.desc_row[K.d_descadr + c]];
-    S[l.qfc + L] = q;
+  if (m.rowmap) {
+    // (L' u)_d = u_d + sum over descendants k of L[k][d] u_k: the backward-solve pattern with the ORIGINAL u
+    real q = u;
+#define MJ_QSTEP(KK) if (KK < m.maxtreedof) { real uk = wv::bcast16<KK>(u); if (RK.eb[KK] >= 0) q += S[l.LD + RK.eb[KK]] * uk; }
+    MJ_QSTEP(1) MJ_QSTEP(2) MJ_QSTEP(3) MJ_QSTEP(4) MJ_QSTEP(5) MJ_QSTEP(6) MJ_QSTEP(7) MJ_QSTEP(8)
+    MJ_QSTEP(9) MJ_QSTEP(10) MJ_QSTEP(11) MJ_QSTEP(12) MJ_QSTEP(13) MJ_QSTEP(14) MJ_QSTEP(15)
+#undef MJ_QSTEP
+    if (dof) S[l.qfc + mydof] = q;
+  } else {
+    if (dof) S[l.x + mydof] = u;
+    wv::sync();
+    if (L < m.nv) {
+      real q = S[l.x + L];
+      for (int c = 0; c < K.d_descnum; c++) q += S[l.LD + m.desc_Madr[K.d_descadr + c]] * S[l.x + m.desc_row[K.d_descadr + c]];
+      S[l.qfc + L] = q;
+    }
   }
   if (m.rowmap) {
     real x = solve_rows(m, RK, S, l.LD, l.Dinv, u, false, true, true);

@@ -11,8 +11,15 @@ namespace wv {
 __device__ __forceinline__ int lane() { return threadIdx.x; }
 __device__ __forceinline__ int env_index() { return blockIdx.x; }
 
-// LDS writes of every lane become visible to every lane of the wave
-__device__ __forceinline__ void sync() { __syncthreads(); }
+// LDS writes of every lane become visible to every lane of the wave.  The workgroup IS one wave, and the LDS
+// executes one wave's DS instructions in issue order, so no s_barrier and no counter drain are needed: a
+// wavefront-scope fence keeps the compiler from moving LDS accesses across this point and emits no instruction,
+// which leaves global loads issued earlier (table prefetches) in flight instead of draining them at every stage
+// boundary the way __syncthreads() (s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier) would.
+__device__ __forceinline__ void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ double shfl(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl(int v, int src) { return __shfl(v, src, 64); }
