@@ -264,6 +264,13 @@ class MuJoCoRL(MuJoCoParent):
         return data
 
     # ------------------------------------------------------------------ array path
+    def reset_batched(self, mask=None):
+        """Reset every copy (or the copies flagged in ``mask``) without building per-agent dicts; asynchronous on
+        the handle's stream.  The array-path counterpart of ``reset()`` for runs without host plugins."""
+        self._handle.reset(mask)
+        self.timestep = 0 if mask is None else self.timestep
+        self._obs_cache = None
+
     def step_batched(self, actions, obs=None, reward=None, term=None, trunc=None):
         """One step of every copy without per-agent dicts and without host plugins.
 
