@@ -28,22 +28,26 @@ LEVEL = "two_agent.xml"          # stand-in for the unshipped MultiEnvs.xml (SUR
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, MI355X_MICROARCH.md chip-level table
 
 
-def algorithmic_bytes_per_env_step(nq, nv, n_act_total, obs_total, n_agent, s=8):
-    """state in/out + warm start in/out + actions + observations + per-agent
-    reward/term/trunc.  fp64 state (s = 8): 2-agent level -> 2460 B."""
-    return s * (2 * nq + 2 * nv + 2 * nv + n_act_total + obs_total) + n_agent * (4 + 1 + 1)
+def algorithmic_bytes_per_env_step(nq, nv, n_act_total, obs_total, n_agent, n_slot=0, s=8):
+    """state in/out + warm start in/out + actions + observations + data-store read/write +
+    per-agent reward/term/trunc.  fp64 (s = 8): 2-agent level without plugins 2460 B, with the Language channel
+    (one action, one observation and one data-store slot more per agent) 2524 B."""
+    return s * (2 * nq + 2 * nv + 2 * nv + n_act_total + obs_total) + n_agent * n_slot * 2 * s + n_agent * (4 + 1 + 1)
 
 
 def action_stream(seed, first_env, n_env, n_steps, n_agent, act_dim):
-    """uniform(-1, 1) keyed on the GLOBAL env id, so a copy's trajectory does not depend on the GPU count."""
+    """uniform(-1, 1) keyed on the GLOBAL env id, so a copy's trajectory does not depend on the GPU count.  Slots past
+    the eight motors are utterances of the Language channel: uniform(0, 3)."""
     out = np.empty((n_steps, n_env, n_agent, act_dim), np.float64)
     for e in range(n_env):
         rng = np.random.Generator(np.random.Philox(key=seed, counter=[0, 0, 0, first_env + e]))
         out[:, e] = rng.uniform(-1.0, 1.0, (n_steps, n_agent, act_dim))
+    if act_dim > 8:
+        out[..., 8:] = 1.5 * (out[..., 8:] + 1.0)
     return out
 
 
-def cpu_baseline(blob_bytes, scatter, seconds=8.0):
+def cpu_baseline(blob_bytes, scatter, seconds=8.0, language=False):
     """The CPU oracle (kind "port": the repo's own fp64 restatement of the step; mujoco is not installed on the
     box) timed on the host cores on a bounded sample of the same workload: one env copy per worker, the same
     action distribution, for `seconds` of wall time; once single-threaded, once with one process per core."""
@@ -54,15 +58,19 @@ def cpu_baseline(blob_bytes, scatter, seconds=8.0):
         env = OracleEnv(blob_bytes)
         rng = np.random.default_rng(seed)
         n = 0
+        store = [{} for _ in range(scatter.shape[0])]
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < duration:
             for _ in range(64):
                 act = rng.uniform(-1, 1, scatter.shape)
                 env.ctrl[scatter.reshape(-1)] = act.reshape(-1)
                 env.step()
-                # the reference's observation gather: sensordata | qpos | qvel per agent
+                # the reference's observation gather: sensordata | qpos | qvel per agent (+ the language channel)
                 for a in range(scatter.shape[0]):
-                    np.concatenate([env.sensordata[[a]], env.qpos, env.qvel])
+                    obs = np.concatenate([env.sensordata[[a]], env.qpos, env.qvel])
+                    if language:
+                        store[a]["utterance"] = int(rng.uniform(0, 3))
+                        obs = np.concatenate((obs, np.array([store[1 - a].get("utterance", 0)])))
             n += 64
             if env.time > 2.0:          # episode of 1024 steps ~ 2 s of sim time
                 env.reset()
@@ -93,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-language", action="store_true", help="config 2: physics + gather only, no Language channel")
     args = ap.parse_args()
 
     import torch
@@ -113,10 +122,13 @@ def main():
     from mjrl_amd.mujoco_rl import MuJoCoRL
 
     n_env = args.envs_per_gpu
+    from mjrl_amd.dynamics import Language
+    plugins = [] if args.no_language else [Language]
     env = MuJoCoRL({"xmlPath": levels.level_path(LEVEL), "agents": AGENTS, "numEnvs": n_env, "deviceId": local,
-                    "skipFrames": 1, "maxSteps": 1024})
-    env.reset()
-    n_agent, act_dim, obs_dim = len(AGENTS), 8, env._handle.size("obs_dim")
+                    "skipFrames": 1, "maxSteps": 1024, "environmentDynamics": plugins})
+    env.reset_batched()
+    n_agent, obs_dim = len(AGENTS), env._handle.size("obs_dim")
+    act_dim = 8 + len(plugins)
     total_steps = args.warmup + args.steps
     # a cyclic buffer of ACT_RING steps of actions, resident in HBM before the timed region
     acts_host = action_stream(0, rank * n_env, n_env, ACT_RING, n_agent, act_dim)
@@ -163,7 +175,8 @@ def main():
 
     if rank == 0:
         m = env._compiled
-        bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * obs_dim, n_agent)
+        bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * obs_dim, n_agent,
+                                                   n_slot=len(plugins))
         achieved = bytes_per * n_env / (kernel_ms * 1e-3) / 1e9
         traffic = None
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
@@ -184,7 +197,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             scatter = np.array([env.agents_action_index[a] for a in AGENTS])
-            line["cpu_baseline"] = cpu_baseline(env._blob, scatter)
+            line["cpu_baseline"] = cpu_baseline(env._blob, scatter, language=bool(plugins))
         print(json.dumps(line), flush=True)
     env.close()
     if world > 1:

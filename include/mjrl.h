@@ -52,6 +52,20 @@ int mjrl_set_gather_tables(mjrl_env* env, int n_agent, const int32_t* n_sensor, 
 int mjrl_set_scatter_tables(mjrl_env* env, int n_agent, int mode, const int32_t* n_idx, const int32_t* idx);
 int mjrl_set_max_steps(mjrl_env* env, int max_steps);   /* truncation horizon, mujoco_rl.py:59,412 */
 
+/* Fused on-device plugin vocabulary ("GPU fast path"): a short program run by the step kernel after the
+ * observation gather, in list order, agent-minor, strictly sequentially -- the order of the reference's plugin loop
+ * (environmentDynamics mujoco_rl.py:215-241, rewardFunctions :276-277, doneFunctions :281-286).  It replaces those
+ * host loops for plugins that fit the vocabulary; anything else stays a host plugin.
+ *   prog_i [n_op][8] = {kind, i1..i7}, prog_f [n_op][4]:
+ *   kind 1 LANGUAGE      i1 action slot, i2 store slot, i3 extra-obs index   (README.md:109-136, 4-tuple form)
+ *   kind 2 DIST_REWARD   i1 target kind (0 body xipos, 1 geom xpos), i2 target id, i3 store slot or -1, i4 mode; f0 scale
+ *   kind 3 DIST_DONE     i1 target kind, i2 target id; f0 threshold
+ * n_slot doubles of device data store per (env, agent) (NaN = key absent; cleared by mjrl_reset, mujoco_rl.py:312),
+ * n_extra_obs observation values appended after each agent's physical observation (obs_dim grows by it).
+ * Must be called after mjrl_set_gather_tables. */
+int mjrl_set_program(mjrl_env* env, int n_op, const int32_t* prog_i, const double* prog_f, int n_slot,
+                     int n_extra_obs, const int32_t* agent_body);
+
 /* Sizes a caller needs to allocate buffers: "nq","nv","nu","nbody","ngeom","nsensordata","obs_dim",
  * "n_agent","n_env","lds_doubles","ncon_stride", ...; -1 for an unknown name. */
 int mjrl_size(const mjrl_env* env, const char* name);
@@ -76,7 +90,7 @@ int mjrl_step_host(mjrl_env* env, const double* h_actions, int act_dim, int skip
                    double* h_reward, uint8_t* h_term, uint8_t* h_trunc);
 
 /* State access for parity tests and host-side plugins (synchronous, host buffers [n_env][n]).
- * Fields: "qpos","qvel","ctrl","qacc_warmstart","sensordata","timestep"(int32). */
+ * Fields: "qpos","qvel","ctrl","qacc_warmstart","sensordata","timestep"(int32),"store" [n_env][n_agent][n_slot]. */
 int mjrl_get_field(mjrl_env* env, const char* name, void* h_out, size_t nbytes);
 int mjrl_set_field(mjrl_env* env, const char* name, const void* h_in, size_t nbytes);
 

@@ -18,7 +18,7 @@ SYMBOLS = [
     "mjrl_version", "mjrl_last_error", "mjrl_create", "mjrl_destroy", "mjrl_set_stream", "mjrl_sync",
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
-    "mjrl_lds_offset", "mjrl_step_profile",
+    "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program",
 ]
 
 _lib = None
@@ -58,6 +58,7 @@ def load():
     L.mjrl_step_debug.argtypes = [vp, vp, ci, ci, ci, vp, sz]
     L.mjrl_lds_offset.argtypes = [vp, ctypes.c_char_p]
     L.mjrl_step_profile.argtypes = [vp, vp, ci, ci, vp, ci]
+    L.mjrl_set_program.argtypes = [vp, ci, ip, vp, ci, ci, ip]
     _lib = L
     return L
 
@@ -131,6 +132,18 @@ class Handle:
         flat, fp = _i32([i for x in idx_lists for i in x])
         self._check(self._lib.mjrl_set_scatter_tables(self._h, len(idx_lists), int(mode), cp, fp))
 
+    def set_program(self, prog_i, prog_f, n_slot: int, n_extra_obs: int, agent_body):
+        pi = np.ascontiguousarray(np.asarray(prog_i, dtype=np.int32).reshape(-1, 8))
+        pf = np.ascontiguousarray(np.asarray(prog_f, dtype=np.float64).reshape(-1, 4))
+        if pi.shape[0] != pf.shape[0]:
+            raise Exception("program: integer and float parts differ in length")
+        n_op = pi.shape[0]
+        if n_op == 0:
+            pi, pf = np.zeros((1, 8), np.int32), np.zeros((1, 4))
+        body, bp = _i32(agent_body)
+        self._check(self._lib.mjrl_set_program(self._h, n_op, pi.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                               _host_ptr(pf), int(n_slot), int(n_extra_obs), bp))
+
     def reset(self, mask=None, d_obs: int | None = None):
         m = None
         if mask is not None:
@@ -154,6 +167,8 @@ class Handle:
         per = {"qpos": "nq", "qvel": "nv", "ctrl": "nu", "qacc_warmstart": "nv", "sensordata": "nsensordata"}
         if name == "timestep":
             out = np.zeros(self.n_env, np.int32)
+        elif name == "store":
+            out = np.zeros((self.n_env, max(self.size("n_agent"), 1), max(self.size("n_slot"), 0)), np.float64)
         else:
             out = np.zeros((self.n_env, self.size(per[name])), np.float64)
         self._check(self._lib.mjrl_get_field(self._h, name.encode(), _host_ptr(out), out.nbytes))

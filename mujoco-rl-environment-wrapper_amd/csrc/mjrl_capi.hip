@@ -19,9 +19,11 @@ __global__ __launch_bounds__(64) void mjrl_step_kernel(DevModel m, mj::StepArgs 
 
 // masked reset of the HBM state (mj_resetData for the selected copies)
 __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double* ctrl, double* warm, int* timestep,
-                                  const unsigned char* mask, int n_env) {
+                                  const unsigned char* mask, int n_env, double* store, int store_per_env) {
   int env = blockIdx.x;
   if (env >= n_env || (mask && !mask[env])) return;
+  // an empty data store (mujoco_rl.py:312): every slot "absent"
+  for (int i = threadIdx.x; i < store_per_env; i += blockDim.x) store[(size_t)env * store_per_env + i] = __longlong_as_double(0x7FF8000000000000ll);
   for (int i = threadIdx.x; i < m.nq; i += blockDim.x) qpos[(size_t)env * m.nq + i] = m.qpos0[i];
   for (int i = threadIdx.x; i < m.nv; i += blockDim.x) { qvel[(size_t)env * m.nv + i] = 0; warm[(size_t)env * m.nv + i] = 0; }
   for (int i = threadIdx.x; i < m.nu; i += blockDim.x) ctrl[(size_t)env * m.nu + i] = 0;
@@ -48,6 +50,11 @@ struct mjrl_env {
   std::vector<std::vector<int32_t>> h_scatter;   // per agent
   int32_t *d_gather = nullptr, *d_scatter = nullptr;
   int scatter_act_dim = -1;
+  // fused plugin program
+  std::vector<int32_t> h_obs_len;                // physical observation length per agent
+  int base_obs_dim = 0, n_extra = 0, n_op = 0, n_slot = 0;
+  int32_t *d_prog_i = nullptr, *d_agent_body = nullptr, *d_obs_len = nullptr;
+  double *d_prog_f = nullptr, *store = nullptr;
   // staging for the host-buffer entry points
   double *s_act = nullptr, *s_obs = nullptr, *s_rew = nullptr;
   unsigned char *s_term = nullptr, *s_trunc = nullptr;
@@ -71,7 +78,7 @@ struct mjrl_env {
 
 extern "C" {
 
-const char* mjrl_version(void) { return "mjrl-hip 0.2 (blob layout 7, gfx950)"; }
+const char* mjrl_version(void) { return "mjrl-hip 0.3 (blob layout 10, gfx950)"; }
 
 const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 
@@ -79,7 +86,8 @@ void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_blob, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
-                  e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc};
+                  e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
+                  e->d_obs_len, e->d_prog_f, e->store};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
@@ -87,7 +95,7 @@ void mjrl_destroy(mjrl_env* e) {
 
 static int launch_reset(mjrl_env* e, const unsigned char* d_mask) {
   hipLaunchKernelGGL(mjrl_reset_kernel, dim3(e->n_env), dim3(64), 0, e->stream, e->dm, e->qpos, e->qvel, e->ctrl, e->warm,
-                     e->timestep, d_mask, e->n_env);
+                     e->timestep, d_mask, e->n_env, e->store, e->n_agent * e->n_slot);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }
@@ -151,6 +159,62 @@ int mjrl_sync(mjrl_env* e) {
 
 int mjrl_set_max_steps(mjrl_env* e, int max_steps) { e->max_steps = max_steps; return 0; }
 
+// device gather table = physical part [base_obs_dim] + n_extra slots per agent owned by the fused program (-2)
+static int upload_gather(mjrl_env* e) {
+  int dim = e->base_obs_dim + e->n_extra;
+  std::vector<int32_t> table((size_t)e->n_agent * dim, -1);
+  for (int a = 0; a < e->n_agent; a++) {
+    for (int k = 0; k < e->base_obs_dim; k++) table[(size_t)a * dim + k] = e->h_gather[(size_t)a * e->base_obs_dim + k];
+    for (int k = 0; k < e->n_extra; k++) table[(size_t)a * dim + e->h_obs_len[a] + k] = -2;
+  }
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->d_gather) { hipFree(e->d_gather); e->d_gather = nullptr; }
+  if (e->d_obs_len) { hipFree(e->d_obs_len); e->d_obs_len = nullptr; }
+  MJRL_HIP(e, hipMalloc(&e->d_gather, sizeof(int32_t) * std::max<size_t>(table.size(), 1)));
+  MJRL_HIP(e, hipMemcpy(e->d_gather, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice));
+  MJRL_HIP(e, hipMalloc(&e->d_obs_len, sizeof(int32_t) * e->n_agent));
+  MJRL_HIP(e, hipMemcpy(e->d_obs_len, e->h_obs_len.data(), sizeof(int32_t) * e->n_agent, hipMemcpyHostToDevice));
+  e->obs_dim = dim;
+  e->s_obs_n = 0;     // staging is re-sized on the next host-buffer step
+  if (e->s_obs) { hipFree(e->s_obs); e->s_obs = nullptr; }
+  return 0;
+}
+
+int mjrl_set_program(mjrl_env* e, int n_op, const int32_t* prog_i, const double* prog_f, int n_slot, int n_extra_obs,
+                     const int32_t* agent_body) {
+  if (!e->n_agent || e->h_obs_len.empty()) MJRL_FAIL(e, 1, "set_program: set the gather tables first");
+  if (e->n_agent > mj::MAX_AGENT) MJRL_FAIL(e, 1, "set_program: at most %d agents", (int)mj::MAX_AGENT);
+  if (n_op < 0 || n_slot < 0 || n_extra_obs < 0) MJRL_FAIL(e, 1, "set_program: negative size");
+  for (int op = 0; op < n_op; op++) {
+    const int32_t* pi = prog_i + 8 * op;
+    bool ok = true;
+    if (pi[0] == mj::OP_LANGUAGE) ok = pi[2] >= 0 && pi[2] < n_slot && pi[3] >= 0 && pi[3] < n_extra_obs && pi[1] >= 0 && e->n_agent >= 2;
+    else if (pi[0] == mj::OP_DIST_REWARD) ok = pi[3] < n_slot && (pi[4] == 0 || pi[3] >= 0) && pi[2] >= 0 && pi[2] < (pi[1] == 0 ? e->hm.nbody : e->hm.ngeom);
+    else if (pi[0] == mj::OP_DIST_DONE) ok = pi[2] >= 0 && pi[2] < (pi[1] == 0 ? e->hm.nbody : e->hm.ngeom);
+    else ok = false;
+    if (!ok) MJRL_FAIL(e, 2, "set_program: op %d (kind %d) is malformed", op, pi[0]);
+  }
+  for (int a = 0; a < e->n_agent; a++)
+    if (agent_body[a] < 0 || agent_body[a] >= e->hm.nbody) MJRL_FAIL(e, 2, "set_program: agent body id out of range");
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  for (void** p : {(void**)&e->d_prog_i, (void**)&e->d_prog_f, (void**)&e->d_agent_body, (void**)&e->store})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  e->n_op = n_op; e->n_slot = n_slot; e->n_extra = n_extra_obs;
+  MJRL_HIP(e, hipMalloc(&e->d_prog_i, sizeof(int32_t) * 8 * std::max(n_op, 1)));
+  MJRL_HIP(e, hipMalloc(&e->d_prog_f, sizeof(double) * 4 * std::max(n_op, 1)));
+  MJRL_HIP(e, hipMalloc(&e->d_agent_body, sizeof(int32_t) * e->n_agent));
+  size_t nstore = (size_t)e->n_env * e->n_agent * std::max(n_slot, 1);
+  MJRL_HIP(e, hipMalloc(&e->store, sizeof(double) * nstore));
+  if (n_op) {
+    MJRL_HIP(e, hipMemcpy(e->d_prog_i, prog_i, sizeof(int32_t) * 8 * n_op, hipMemcpyHostToDevice));
+    MJRL_HIP(e, hipMemcpy(e->d_prog_f, prog_f, sizeof(double) * 4 * n_op, hipMemcpyHostToDevice));
+  }
+  MJRL_HIP(e, hipMemcpy(e->d_agent_body, agent_body, sizeof(int32_t) * e->n_agent, hipMemcpyHostToDevice));
+  std::vector<double> nan(nstore, __builtin_nan(""));
+  MJRL_HIP(e, hipMemcpy(e->store, nan.data(), sizeof(double) * nstore, hipMemcpyHostToDevice));
+  return upload_gather(e);
+}
+
 int mjrl_set_gather_tables(mjrl_env* e, int n_agent, const int32_t* n_sensor, const int32_t* sensor_idx,
                            const int32_t* n_qpos, const int32_t* qpos_idx, const int32_t* n_qvel,
                            const int32_t* qvel_idx) {
@@ -179,14 +243,12 @@ int mjrl_set_gather_tables(mjrl_env* e, int n_agent, const int32_t* n_sensor, co
       table[(size_t)a * dim + k++] = (2 << 24) | idx;
     }
   }
-  MJRL_HIP(e, hipStreamSynchronize(e->stream));
-  if (e->d_gather) { hipFree(e->d_gather); e->d_gather = nullptr; }
-  MJRL_HIP(e, hipMalloc(&e->d_gather, sizeof(int32_t) * std::max<size_t>(table.size(), 1)));
-  MJRL_HIP(e, hipMemcpy(e->d_gather, table.data(), sizeof(int32_t) * table.size(), hipMemcpyHostToDevice));
+  e->h_obs_len.assign(n_agent, 0);
+  for (int a = 0; a < n_agent; a++) e->h_obs_len[a] = n_sensor[a] + n_qpos[a] + n_qvel[a];
   e->h_gather = table;
   e->n_agent = n_agent;
-  e->obs_dim = dim;
-  return 0;
+  e->base_obs_dim = dim;
+  return upload_gather(e);
 }
 
 int mjrl_set_scatter_tables(mjrl_env* e, int n_agent, int mode, const int32_t* n_idx, const int32_t* idx) {
@@ -216,6 +278,8 @@ int mjrl_size(const mjrl_env* e, const char* name) {
   if (!strcmp(name, "obs_dim")) return e->obs_dim;
   if (!strcmp(name, "n_agent")) return e->n_agent;
   if (!strcmp(name, "n_env")) return e->n_env;
+  if (!strcmp(name, "n_slot")) return e->n_slot;
+  if (!strcmp(name, "n_extra_obs")) return e->n_extra;
   if (!strcmp(name, "lds_doubles")) return e->lay.total;
   if (!strcmp(name, "con_stride")) return mj::CON_STRIDE;
   if (!strcmp(name, "row_stride")) return mj::ROW_STRIDE;
@@ -272,6 +336,9 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.dbg = d_dbg; a.dbg_stage = dbg_stage;
   a.forward_only = forward_only;
   a.stamps = d_stamps;
+  a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
+  a.agent_body = e->d_agent_body; a.agent_obs_len = e->d_obs_len; a.store = e->store;
+  if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
   hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, a);
   MJRL_HIP(e, hipGetLastError());
@@ -345,6 +412,7 @@ static int find_field(mjrl_env* e, const char* name, field_ref* f) {
   else if (!strcmp(name, "qacc_warmstart")) *f = {e->warm, sizeof(double) * n * m.nv};
   else if (!strcmp(name, "sensordata")) *f = {e->sens, sizeof(double) * n * m.nsensordata};
   else if (!strcmp(name, "timestep")) *f = {e->timestep, sizeof(int) * n};
+  else if (!strcmp(name, "store")) *f = {e->store, sizeof(double) * n * e->n_agent * e->n_slot};
   else MJRL_FAIL(e, 4, "unknown field '%s'", name);
   return 0;
 }

@@ -97,6 +97,23 @@ struct StepArgs {
   int dbg_stage;             // 0: end of forward pass; 1: right after the constraint rows are built
   int forward_only;          // 1: mj_forward semantics -- no integration, no counters (reset observations, queries)
   unsigned long long* stamps;   // diagnostic: per-stage wave-clock sums over all env copies [N_STAMPS], may be null
+  // Fused plugin vocabulary, run after the gather in list order, agent-minor, strictly sequentially -- the order of the
+  // reference's plugin loop (mujoco_rl.py:215-241 dynamics, :276-277 rewards, :281-286 dones).  Op word layout: OP_*.
+  const int32_t* prog_i;       // [n_op][8]
+  const real* prog_f;          // [n_op][4]
+  int n_op, n_slot;
+  const int32_t* agent_body;   // [n_agent] body id of each agent
+  const int32_t* agent_obs_len;   // [n_agent] length of the physical part of the agent's observation
+  real* store;                 // [n_env][n_agent][n_slot] device data store; NaN = key not present
+};
+
+// fused plugin ops: prog_i = {kind, i1..i7}, prog_f = {f0..f3}
+enum {
+  OP_LANGUAGE = 1,        // i1 action slot, i2 store slot, i3 extra-obs index: store = int(action); obs = other agent's store (0 if absent)
+  OP_DIST_REWARD = 2,     // i1 target kind (0 body xipos, 1 geom xpos), i2 target id, i3 store slot (-1 none), i4 mode; f0 scale
+                          //   mode 0: reward += scale * (-dist);  mode 1: reward += scale * (previous dist - dist), store = dist
+  OP_DIST_DONE = 3,       // i1 target kind, i2 target id; f0 threshold: terminated |= dist < threshold
+  MAX_AGENT = 8
 };
 
 enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_VEL, ST_SMOOTH, ST_ROWS, ST_PROJECT, ST_PGS,
@@ -1148,6 +1165,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   if (a.obs) {
     MJ_FOR(it, a.n_agent * a.obs_dim) {
       int code = a.gather[it];
+      if (code == -2) continue;        // slot owned by a fused dynamics op (written below by lane 0)
       real v = 0;
       if (code >= 0) {
         int kind = code >> 24, idx = code & 0xFFFFFF;
@@ -1162,9 +1180,52 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // truncation is evaluated before the counter moves (mujoco_rl.py:279,288)
   int ts = a.timestep[env];
   MJ_FOR(ag, a.n_agent) {
-    if (a.reward) a.reward[(size_t)env * a.n_agent + ag] = 0;
-    if (a.term) a.term[(size_t)env * a.n_agent + ag] = 0;
     if (a.trunc) a.trunc[(size_t)env * a.n_agent + ag] = ts >= a.max_steps;
+  }
+  if (L == 0) {
+    // rewards start at 0, terminations at false (mujoco_rl.py:262-263); the fused ops then run like the plugin loop
+    real rew[MAX_AGENT];
+    bool term[MAX_AGENT];
+    for (int ag = 0; ag < a.n_agent; ag++) { rew[ag] = 0; term[ag] = false; }
+    const real* act = a.actions ? a.actions + (size_t)env * a.n_agent * a.act_dim : nullptr;
+    real* store = a.store ? a.store + (size_t)env * a.n_agent * a.n_slot : nullptr;
+    for (int op = 0; op < a.n_op; op++) {
+      const int32_t* pi = a.prog_i + 8 * op;
+      const real* pf = a.prog_f + 4 * op;
+      for (int ag = 0; ag < a.n_agent; ag++) {
+        if (pi[0] == OP_LANGUAGE) {
+          real utter = act ? (real)(long long)act[ag * a.act_dim + pi[1]] : 0.0;
+          store[ag * a.n_slot + pi[2]] = utter;
+          int other = ag == 0 ? 1 : 0;
+          real heard = other < a.n_agent ? store[other * a.n_slot + pi[2]] : 0.0;
+          if (heard != heard) heard = 0.0;
+          if (a.obs) a.obs[((size_t)env * a.n_agent + ag) * a.obs_dim + a.agent_obs_len[ag] + pi[3]] = heard;
+        } else {
+          int body = a.agent_body[ag];
+          V3 p = ld3(S + l.xpos + 3 * body) + rot(ldq(S + l.xquat + 4 * body), ld3(m.body_ipos + 3 * body));
+          V3 t;
+          if (pi[1] == 0) t = ld3(S + l.xpos + 3 * pi[2]) + rot(ldq(S + l.xquat + 4 * pi[2]), ld3(m.body_ipos + 3 * pi[2]));
+          else t = ld3(S + l.gpos + 3 * pi[2]);
+          V3 d3 = p - t;
+          real dist = sqrt(dot(d3, d3));
+          if (pi[0] == OP_DIST_REWARD) {
+            if (pi[4] == 0) {
+              rew[ag] += pf[0] * (-dist);
+            } else {
+              real prev = store[ag * a.n_slot + pi[3]];
+              if (prev == prev) rew[ag] += pf[0] * (prev - dist);
+            }
+            if (pi[3] >= 0) store[ag * a.n_slot + pi[3]] = dist;
+          } else if (pi[0] == OP_DIST_DONE) {
+            term[ag] = term[ag] || dist < pf[0];
+          }
+        }
+      }
+    }
+    for (int ag = 0; ag < a.n_agent; ag++) {
+      if (a.reward) a.reward[(size_t)env * a.n_agent + ag] = rew[ag];
+      if (a.term) a.term[(size_t)env * a.n_agent + ag] = term[ag];
+    }
   }
   wv::sync();
   if (L == 0) a.timestep[env] = ts + 1;

@@ -20,6 +20,7 @@ import time
 
 import numpy as np
 
+from . import dynamics as fused_vocabulary
 from .helper import update_deep
 from .mujoco_parent import MuJoCoParent
 from .spaces import Box
@@ -67,6 +68,30 @@ class MuJoCoRL(MuJoCoParent):
         self._action_space = self._create_action_space()
         self._first_action_space = self._action_space[list(self._action_space.keys())[0]]
         self._upload_tables(self.agents)
+        self._setup_fused_program(config_dict.get("fusedPlugins", True))
+
+    def _setup_fused_program(self, allowed: bool):
+        """When every configured plugin belongs to the device vocabulary (dynamics.py) the plugin loop runs inside
+        the step kernel; otherwise (or with ``fusedPlugins: False``) it stays the host loop below."""
+        self._program = fused_vocabulary.build_program(self) if allowed else None
+        if self._program is None:
+            return
+        names = self._compiled.names["body"]
+        for agent in self.agents:
+            if agent not in names:
+                raise Exception(f"agent {agent} is not a body of the level")
+        pi, pf = self._program.arrays()
+        self._handle.set_program(pi, pf, len(self._program.slots), self._program.n_extra,
+                                 [names.index(agent) for agent in self.agents])
+
+    @property
+    def device_store(self):
+        """The fused program's per-agent data store: ``{agent: {key: array[numEnvs]}}`` (NaN = key absent)."""
+        if self._program is None or not self._program.slots:
+            return {agent: {} for agent in self.agents}
+        raw = self._handle.get_field("store")
+        return {agent: {key: raw[:, k, slot] for key, slot in self._program.slots.items()}
+                for k, agent in enumerate(self.agents)}
 
     # ------------------------------------------------------------------ construction helpers
     def _load_info_json(self):
@@ -171,8 +196,45 @@ class MuJoCoRL(MuJoCoParent):
     def _blank(self, value):
         return value if self.n_env == 1 else np.full(self.n_env, value)
 
+    def _step_fused(self, action: dict):
+        """step() when the plugin loop runs on the device: one launch, then only the dict packaging."""
+        width = self._first_action_space.shape[0]
+        arr = np.zeros((self.n_env, len(self.agents), width), np.float64)
+        for k, agent in enumerate(self.agents):
+            act = np.asarray(action[agent], dtype=np.float64).reshape(self.n_env, -1)
+            if act.shape[-1] < width:
+                raise Exception(f"The number of actions for agent {agent} is not correct.")
+            arr[:, k] = act[:, :width]
+        n_agent, obs_dim = len(self.agents), self._handle.size("obs_dim")
+        obs = np.zeros((self.n_env, n_agent, obs_dim))
+        rew = np.zeros((self.n_env, n_agent))
+        term = np.zeros((self.n_env, n_agent), np.uint8)
+        trunc = np.zeros((self.n_env, n_agent), np.uint8)
+        self._handle.step_host(arr, self.skip_frames, obs, rew, term, trunc)
+        self.frame += self.skip_frames
+        self._obs_cache = None
+        extra = self._program.n_extra
+        squeeze = (lambda x: x[0]) if self.n_env == 1 else (lambda x: x)
+        observations = {a: squeeze(obs[:, k, :self._obs_len[a] + extra].copy()) for k, a in enumerate(self.agents)}
+        rewards = {a: squeeze(rew[:, k].copy()) for k, a in enumerate(self.agents)}
+        terminations = {a: squeeze(term[:, k].astype(bool)) for k, a in enumerate(self.agents)}
+        if self.n_env == 1:
+            rewards = {a: float(v) for a, v in rewards.items()}
+            terminations = {a: bool(v) for a, v in terminations.items()}
+        infos = {a: {d.__class__.__name__: {} for d in self.environment_dynamics} for a in self.agents}
+        truncations = self._check_truncations()
+        if len(self.done_functions) != 0:
+            if self.n_env == 1:
+                terminations["__all__"] = any(terminations.values())
+            else:
+                terminations["__all__"] = np.logical_or.reduce([terminations[a] for a in self.agents])
+        self.timestep += 1
+        return observations, rewards, terminations, truncations, infos
+
     def step(self, action: dict):
         """mujoco_rl.py:243-289."""
+        if self._program is not None:
+            return self._step_fused(action)
         lo, hi = self.action_routing["physical"]
         physical = {agent: np.asarray(action[agent])[..., lo:hi] for agent in action.keys()}
         self.apply_action(physical, skip_frames=self.skip_frames)
@@ -278,8 +340,8 @@ class MuJoCoRL(MuJoCoParent):
         tensors nothing leaves HBM and the launch is asynchronous on the current torch stream; outputs are
         torch tensors (pass preallocated ones to avoid allocations).  Returns ``(obs, reward, term, trunc)``.
         """
-        if self.environment_dynamics or self.reward_functions or self.done_functions:
-            raise Exception("step_batched runs no host plugins; use step() or the fused dynamics vocabulary")
+        if self._program is None and (self.environment_dynamics or self.reward_functions or self.done_functions):
+            raise Exception("step_batched runs no host plugins; use step() or the fused vocabulary (dynamics.py)")
         n_agent, obs_dim = len(self.agents), self._handle.size("obs_dim")
         if isinstance(actions, np.ndarray):
             actions = np.ascontiguousarray(actions, dtype=np.float64)

@@ -30,7 +30,7 @@ def lib():
         P = ctypes.c_void_p
         L.emu_step.argtypes = [ctypes.c_char_p, ctypes.c_size_t, P, P, P, P, P, P, P, P, ctypes.c_int, ctypes.c_int,
                                ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P,
-                               ctypes.c_int, ctypes.c_int]
+                               ctypes.c_int, ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int, P, P, P, P, P, P]
         _lib = L
     return _lib
 
@@ -73,6 +73,17 @@ class LdsImage:
 
 
 class EmuEnv:
+    @staticmethod
+    def _program_args(program):
+        if program is None:
+            return (None, None, 0, 0, None, None, None, None, None, None)
+        pi = np.ascontiguousarray(program["prog_i"], dtype=np.int32)
+        pf = np.ascontiguousarray(program["prog_f"], dtype=np.float64)
+        program["_keep"] = (pi, pf)
+        return (_p(pi), _p(pf), pi.shape[0], int(program["n_slot"]), _p(program["agent_body"]),
+                _p(program["agent_obs_len"]), _p(program["store"]), _p(program.get("reward")), _p(program.get("term")),
+                _p(program.get("trunc")))
+
     def __init__(self, model, blob: bytes):
         self.model, self.blob = model, blob
         self.qpos = model.qpos0.copy()
@@ -88,13 +99,15 @@ class EmuEnv:
         return lib().emu_lds_offset(self.blob, len(self.blob), name.encode())
 
     def step(self, nsteps=1, skip_frames=1, dbg_stage=0, forward_only=False, actions=None, scatter=None, n_agent=0,
-             scatter_mode=0, gather=None, obs=None):
+             scatter_mode=0, gather=None, obs=None, program=None, max_steps=1 << 30):
+        """``program``: dict(prog_i, prog_f, n_slot, agent_body, agent_obs_len, store, reward, term, trunc) for the
+        fused plugin ops."""
         act_dim = 0 if actions is None else actions.shape[-1]
         obs_dim = 0 if gather is None else gather.shape[-1]
         rc = lib().emu_step(self.blob, len(self.blob), _p(self.qpos), _p(self.qvel), _p(self.ctrl), _p(self.warm),
                             _p(self.sens), _p(self.timestep), _p(actions), _p(scatter), n_agent, act_dim, scatter_mode,
-                            _p(gather), obs_dim, _p(obs), skip_frames, nsteps, 1 << 30, _p(self.dump), dbg_stage,
-                            int(forward_only))
+                            _p(gather), obs_dim, _p(obs), skip_frames, nsteps, max_steps, _p(self.dump), dbg_stage,
+                            int(forward_only), *self._program_args(program))
         if rc:
             raise RuntimeError(f"emu_step failed with code {rc}")
         return LdsImage(self.dump, self.model, self.offset)

@@ -101,7 +101,9 @@ int emu_lds_offset(const void* blob, size_t nbytes, const char* region) {
 int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
              int* timestep, const double* actions, const int32_t* scatter, int n_agent, int act_dim, int scatter_mode,
              const int32_t* gather, int obs_dim, double* obs, int skip_frames, int nsteps, int max_steps, double* dbg,
-             int dbg_stage, int forward_only) {
+             int dbg_stage, int forward_only, const int32_t* prog_i, const double* prog_f, int n_op, int n_slot,
+             const int32_t* agent_body, const int32_t* agent_obs_len, double* store, double* reward,
+             unsigned char* term, unsigned char* trunc) {
   DevModel m;
   if (mjrl_model_from_blob(&m, blob, nbytes, blob)) return -1;
   mj::Lay l;
@@ -111,7 +113,9 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.qpos = qpos; a.qvel = qvel; a.ctrl = ctrl; a.warm = warm; a.sensordata = sens; a.timestep = timestep;
   a.actions = actions; a.scatter = scatter; a.n_agent = n_agent; a.act_dim = act_dim; a.scatter_mode = scatter_mode;
   a.gather = gather; a.obs_dim = obs_dim; a.obs = obs;
-  a.reward = nullptr; a.term = nullptr; a.trunc = nullptr;
+  a.reward = reward; a.term = term; a.trunc = trunc;
+  a.prog_i = prog_i; a.prog_f = prog_f; a.n_op = forward_only ? 0 : n_op; a.n_slot = n_slot;
+  a.agent_body = agent_body; a.agent_obs_len = agent_obs_len; a.store = store;
   a.max_steps = max_steps; a.skip_frames = skip_frames; a.n_env = 1;
   a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;
   emu::cur_env = 0;

@@ -163,3 +163,49 @@ def test_contact_cap_drops_in_order_and_flags():
         ora.step()
     assert img.ncon == ora.ncon == 2 and img.warn & 1 and ora.warnings & 1
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-10)
+
+
+def test_fused_plugin_ops_follow_the_reference_loop_order():
+    """Language channel + distance reward / done as ops of the step kernel, against a direct transcription of the
+    reference's plugin loop (dynamic-major, agent-minor, each call seeing the earlier calls' data-store writes;
+    README.md:109-136, mujoco_rl.py:215-241, 276-286)."""
+    model, ora, emu = pair("two_agent.xml")
+    scatter = np.array([[2, 3, 4, 5, 6, 7, 0, 1, -1], [10, 11, 12, 13, 14, 15, 8, 9, -1]], np.int32)
+    gather = np.full((2, 60), -1, np.int32)
+    for a in range(2):
+        gather[a, 0] = a
+        gather[a, 1:31] = (1 << 24) | np.arange(30)
+        gather[a, 31:59] = (2 << 24) | np.arange(28)
+        gather[a, 59] = -2
+    bodies = np.array([model.names["body"].index("sender"), model.names["body"].index("receiver")], np.int32)
+    target = model.names["body"].index("reference")
+    prog_i = np.array([[1, 8, 0, 0, 0, 0, 0, 0], [2, 0, target, 1, 1, 0, 0, 0], [3, 0, target, 0, 0, 0, 0, 0]], np.int32)
+    prog_f = np.array([[0, 0, 0, 0], [2.0, 0, 0, 0], [3.4, 0, 0, 0]], np.float64)
+    program = dict(prog_i=prog_i, prog_f=prog_f, n_slot=2, agent_body=bodies, agent_obs_len=np.array([59, 59], np.int32),
+                   store=np.full((2, 2), np.nan), reward=np.zeros(2), term=np.zeros(2, np.uint8), trunc=np.zeros(2, np.uint8))
+    obs = np.zeros((2, 60))
+    rng = np.random.default_rng(8)
+    store = [dict(), dict()]
+    for step in range(25):
+        actions = np.concatenate([rng.uniform(-1, 1, (2, 8)), rng.uniform(0, 3, (2, 1))], axis=1)
+        emu.step(actions=actions, scatter=scatter, n_agent=2, gather=gather, obs=obs, program=program, max_steps=20)
+        for a in range(2):
+            ora.ctrl[scatter[a, :8]] = actions[a, :8]
+        ora.step()
+        # the reference loop, written out
+        heard, rewards, dones = [0, 0], [0.0, 0.0], [False, False]
+        for a in range(2):
+            store[a]["utterance"] = int(actions[a, 8])
+            heard[a] = store[1 - a].get("utterance", 0)
+        for a in range(2):
+            dist = np.linalg.norm(ora.xipos[bodies[a]] - ora.xipos[target])
+            if "distance" in store[a]:
+                rewards[a] += 2.0 * (store[a]["distance"] - dist)
+            store[a]["distance"] = dist
+        for a in range(2):
+            dones[a] = np.linalg.norm(ora.xipos[bodies[a]] - ora.xipos[target]) < 3.4
+        assert [obs[0, 59], obs[1, 59]] == heard
+        assert np.allclose(program["reward"], rewards, atol=1e-10)
+        assert list(program["term"].astype(bool)) == dones
+        assert program["trunc"].all() == (step >= 20)
+    assert any(dones) and not all(dones)      # the threshold separates the two agents

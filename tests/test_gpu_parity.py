@@ -229,6 +229,43 @@ def test_step_batched_with_torch_tensors_stays_on_device():
     env.close()
 
 
+def test_fused_vocabulary_equals_the_host_plugin_loop():
+    """Config 3: Language channel + rangefinder obs, with a target-distance reward and done.  The same plugins run
+    once as ops of the step kernel and once through the host plugin loop (fusedPlugins False); both sit on the
+    same GPU physics, so every output must agree (utterances exactly)."""
+    from mjrl_amd.dynamics import Language, TargetDistanceReward, TargetReached
+
+    def make_env(fused):
+        return MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 5, "maxSteps": 12,
+                         "environmentDynamics": [Language], "fusedPlugins": fused,
+                         "rewardFunctions": [TargetDistanceReward("reference", mode="delta", scale=2.0)],
+                         "doneFunctions": [TargetReached("reference", 3.4)]})
+    fused, host = make_env(True), make_env(False)
+    assert fused._program is not None and host._program is None
+    assert fused.observation_space("sender").shape == (60,) and fused.action_space("sender").shape == (9,)
+    np.random.seed(0)
+    o1, _ = fused.reset()
+    np.random.seed(0)
+    o2, _ = host.reset()
+    assert o1["sender"].shape == o2["sender"].shape == (5, 60)
+    rng = np.random.default_rng(3)
+    for step in range(16):
+        action = {a: np.concatenate([rng.uniform(-1, 1, (5, 8)), rng.uniform(0, 3, (5, 1))], axis=1) for a in AGENTS}
+        f, h = fused.step(action), host.step(action)
+        for a in AGENTS:
+            assert np.array_equal(f[0][a][:, 59], h[0][a][:, 59])              # what was heard
+            assert np.allclose(f[0][a], h[0][a], atol=1e-12)
+            assert np.allclose(f[1][a], h[1][a], atol=1e-10)
+            assert np.array_equal(f[2][a], h[2][a]) and np.array_equal(f[3][a], h[3][a])
+        assert np.array_equal(f[2]["__all__"], h[2]["__all__"]) and f[4] == h[4]
+    assert f[3]["sender"].all() and np.abs(f[1]["sender"]).max() > 0 and f[2]["sender"].any() != f[2]["receiver"].any()
+    assert np.array_equal(fused.device_store["sender"]["utterance"], np.trunc(action["sender"][:, 8]))
+    fused.reset()
+    assert np.isnan(fused.device_store["sender"]["utterance"]).all()
+    fused.close()
+    host.close()
+
+
 def test_errors_are_reported_not_swallowed():
     model, packed, h = make("two_agent.xml", 2)
     with pytest.raises(Exception, match="unknown field"):
