@@ -94,8 +94,13 @@ int mjrl_step_host(mjrl_env* env, const double* h_actions, int act_dim, int skip
 int mjrl_get_field(mjrl_env* env, const char* name, void* h_out, size_t nbytes);
 int mjrl_set_field(mjrl_env* env, const char* name, const void* h_in, size_t nbytes);
 
-/* Derived quantities of the CURRENT state for host-side plugins (get_data / distance / collision,
- * mujoco_parent.py:394-478): runs the position stage + collision for every copy and returns
+/* Keep the frames of every step's forward pass in HBM for mjrl_query (on by default once mjrl_query is used; turn
+ * it on up front when host plugins will query, so that the first query after a step is served from that step). */
+int mjrl_set_query_cache(mjrl_env* env, int enabled);
+
+/* Derived quantities for host-side plugins (get_data / distance / collision, mujoco_parent.py:394-478), as the
+ * reference's MjData holds them after mj_step: the frames of the LAST FORWARD PASS (inside the last step, or of the
+ * forward pass after a reset / state write):
  *   "xpos" [n_env][nbody][3]  "xquat" [n_env][nbody][4]  "xipos" [n_env][nbody][3]
  *   "geom_xpos" [n_env][ngeom][3]  "geom_xmat" [n_env][ngeom][9]
  *   "ncon" [n_env] (as double)  "contact_geom" [n_env][nconmax][2] (as double, -1 padded). */

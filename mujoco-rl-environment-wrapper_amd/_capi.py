@@ -18,7 +18,7 @@ SYMBOLS = [
     "mjrl_version", "mjrl_last_error", "mjrl_create", "mjrl_destroy", "mjrl_set_stream", "mjrl_sync",
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
-    "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program",
+    "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
 ]
 
 _lib = None
@@ -59,6 +59,7 @@ def load():
     L.mjrl_lds_offset.argtypes = [vp, ctypes.c_char_p]
     L.mjrl_step_profile.argtypes = [vp, vp, ci, ci, vp, ci]
     L.mjrl_set_program.argtypes = [vp, ci, ip, vp, ci, ci, ip]
+    L.mjrl_set_query_cache.argtypes = [vp, ci]
     _lib = L
     return L
 
@@ -111,6 +112,9 @@ class Handle:
 
     def sync(self):
         self._check(self._lib.mjrl_sync(self._h))
+
+    def set_query_cache(self, enabled: bool):
+        self._check(self._lib.mjrl_set_query_cache(self._h, int(bool(enabled))))
 
     def set_max_steps(self, n: int):
         self._check(self._lib.mjrl_set_max_steps(self._h, int(n)))

@@ -55,6 +55,9 @@ struct mjrl_env {
   int base_obs_dim = 0, n_extra = 0, n_op = 0, n_slot = 0;
   int32_t *d_prog_i = nullptr, *d_agent_body = nullptr, *d_obs_len = nullptr;
   double *d_prog_f = nullptr, *store = nullptr;
+  // forward-pass frames kept for host-side plugin queries
+  double* frames = nullptr;
+  bool frames_valid = false;
   // staging for the host-buffer entry points
   double *s_act = nullptr, *s_obs = nullptr, *s_rew = nullptr;
   unsigned char *s_term = nullptr, *s_trunc = nullptr;
@@ -87,7 +90,7 @@ void mjrl_destroy(mjrl_env* e) {
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_blob, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
-                  e->d_obs_len, e->d_prog_f, e->store};
+                  e->d_obs_len, e->d_prog_f, e->store, e->frames};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
@@ -339,6 +342,8 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
   a.agent_body = e->d_agent_body; a.agent_obs_len = e->d_obs_len; a.store = e->store;
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
+  a.frames = e->frames;
+  if (e->frames && skip_frames > 0) e->frames_valid = true;
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
   hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, a);
   MJRL_HIP(e, hipGetLastError());
@@ -397,6 +402,7 @@ int mjrl_reset(mjrl_env* e, const uint8_t* h_mask, double* d_obs) {
     d_mask = e->d_mask;
   }
   if (int rc = launch_reset(e, d_mask)) return rc;
+  e->frames_valid = false;
   // mj_forward after the reset (mujoco_parent.py:350): refreshes sensordata and the warm start of every copy
   // (a forward pass on an un-reset copy recomputes the same values it already holds)
   return launch_step(e, nullptr, 0, 1, d_obs, nullptr, nullptr, nullptr, nullptr, 0, 1);
@@ -426,9 +432,19 @@ int mjrl_get_field(mjrl_env* e, const char* name, void* h_out, size_t nbytes) {
   return 0;
 }
 
+int mjrl_set_query_cache(mjrl_env* e, int enabled) {
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (enabled && !e->frames)
+    MJRL_HIP(e, hipMalloc(&e->frames, sizeof(double) * (size_t)e->n_env * mj::frame_doubles(e->hm)));
+  if (!enabled && e->frames) { hipFree(e->frames); e->frames = nullptr; }
+  e->frames_valid = false;
+  return 0;
+}
+
 int mjrl_set_field(mjrl_env* e, const char* name, const void* h_in, size_t nbytes) {
   field_ref f;
   if (int rc = find_field(e, name, &f)) return rc;
+  e->frames_valid = false;      // the state the cached frames belong to is being replaced
   if (nbytes != f.bytes) MJRL_FAIL(e, 4, "set_field(%s): buffer holds %zu bytes, field has %zu", name, nbytes, f.bytes);
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   if (f.bytes) MJRL_HIP(e, hipMemcpy(f.ptr, h_in, f.bytes, hipMemcpyHostToDevice));
@@ -469,57 +485,63 @@ int mjrl_step_profile(mjrl_env* e, const double* d_actions, int act_dim, int ski
 
 int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
   const DevModel& m = e->hm;
-  const mj::Lay& l = e->lay;
-  if (int rc = ensure_dbg(e)) return rc;
-  if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, e->dbg, 0, 1)) return rc;
+  // The frames of the last forward pass: kept by the step kernel when the query cache is on (what the reference's
+  // data.xipos / data.contact hold after mj_step); otherwise, or after a state write, one forward-only launch.
+  if (!e->frames) if (int rc = mjrl_set_query_cache(e, 1)) return rc;
+  if (!e->frames_valid) {
+    if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1)) return rc;
+  }
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
-  std::vector<double> img((size_t)e->n_env * l.total);
-  MJRL_HIP(e, hipMemcpy(img.data(), e->dbg, sizeof(double) * img.size(), hipMemcpyDeviceToHost));
+  const int fd = mj::frame_doubles(m);
+  std::vector<double> img((size_t)e->n_env * fd);
+  MJRL_HIP(e, hipMemcpy(img.data(), e->frames, sizeof(double) * img.size(), hipMemcpyDeviceToHost));
+  const int o_xpos = 0, o_xquat = 3 * m.nbody, o_gpos = 7 * m.nbody, o_gquat = 7 * m.nbody + 3 * m.ngeom,
+            o_ncon = 7 * m.nbody + 7 * m.ngeom, o_con = o_ncon + 1;
   size_t per = 0;
   int off = 0;
-  enum { PLAIN, XIPOS, NCON, CONGEOM, GMAT, WARN } kind = PLAIN;
-  if (!strcmp(name, "xpos")) { per = 3 * m.nbody; off = l.xpos; }
-  else if (!strcmp(name, "xquat")) { per = 4 * m.nbody; off = l.xquat; }
-  else if (!strcmp(name, "geom_xpos")) { per = 3 * m.ngeom; off = l.gpos; }
+  enum { PLAIN, XIPOS, GMAT, WARN } kind = PLAIN;
+  if (!strcmp(name, "xpos")) { per = 3 * m.nbody; off = o_xpos; }
+  else if (!strcmp(name, "xquat")) { per = 4 * m.nbody; off = o_xquat; }
+  else if (!strcmp(name, "geom_xpos")) { per = 3 * m.ngeom; off = o_gpos; }
   else if (!strcmp(name, "geom_xmat")) { per = 9 * m.ngeom; kind = GMAT; }
   else if (!strcmp(name, "xipos")) { per = 3 * m.nbody; kind = XIPOS; }
-  else if (!strcmp(name, "ncon")) { per = 1; kind = NCON; }
+  else if (!strcmp(name, "ncon")) { per = 1; off = o_ncon; }
+  else if (!strcmp(name, "contact_geom")) { per = 2 * m.nconmax; off = o_con; }
   else if (!strcmp(name, "warn")) { per = 1; kind = WARN; }
-  else if (!strcmp(name, "contact_geom")) { per = 2 * m.nconmax; kind = CONGEOM; }
   else MJRL_FAIL(e, 4, "query: unknown quantity '%s'", name);
   if (nbytes != sizeof(double) * per * e->n_env) MJRL_FAIL(e, 4, "query(%s): buffer holds %zu bytes, need %zu", name, nbytes, sizeof(double) * per * e->n_env);
+  if (kind == WARN) {
+    // cap-overflow flags live in the LDS image only: one debug forward pass
+    if (int rc = ensure_dbg(e)) return rc;
+    bool keep = e->frames_valid;
+    if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, e->dbg, 0, 1)) return rc;
+    e->frames_valid = keep;
+    MJRL_HIP(e, hipStreamSynchronize(e->stream));
+    std::vector<double> lds((size_t)e->n_env * e->lay.total);
+    MJRL_HIP(e, hipMemcpy(lds.data(), e->dbg, sizeof(double) * lds.size(), hipMemcpyDeviceToHost));
+    for (int env = 0; env < e->n_env; env++)
+      h_out[env] = ((const int*)(lds.data() + (size_t)env * e->lay.total + e->lay.ints))[mj::I_WARN];
+    return 0;
+  }
+  auto quat_to_mat = [](const double* q, double* r) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    r[0] = w * w + x * x - y * y - z * z; r[1] = 2 * (x * y - w * z); r[2] = 2 * (x * z + w * y);
+    r[3] = 2 * (x * y + w * z); r[4] = w * w - x * x + y * y - z * z; r[5] = 2 * (y * z - w * x);
+    r[6] = 2 * (x * z - w * y); r[7] = 2 * (y * z + w * x); r[8] = w * w - x * x - y * y + z * z;
+  };
   for (int env = 0; env < e->n_env; env++) {
-    const double* S = img.data() + (size_t)env * l.total;
-    const int* I = (const int*)(S + l.ints);
+    const double* F = img.data() + (size_t)env * fd;
     double* o = h_out + (size_t)env * per;
-    if (kind == PLAIN) memcpy(o, S + off, sizeof(double) * per);
-    else if (kind == NCON) o[0] = I[mj::I_NCON];
-    else if (kind == WARN) o[0] = I[mj::I_WARN];
-    else if (kind == CONGEOM) {
-      for (int c = 0; c < m.nconmax; c++) {
-        bool live = c < I[mj::I_NCON];
-        o[2 * c] = live ? I[l.i_cong1 + c] : -1;
-        o[2 * c + 1] = live ? I[l.i_cong2 + c] : -1;
-      }
-    } else if (kind == GMAT) {
-      for (int g = 0; g < m.ngeom; g++) {
-        const double* q = S + l.gquat + 4 * g;
-        double w = q[0], x = q[1], y = q[2], z = q[3];
-        double r[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
-                       2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
-                       2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
-        memcpy(o + 9 * g, r, sizeof(r));
-      }
+    if (kind == PLAIN) memcpy(o, F + off, sizeof(double) * per);
+    else if (kind == GMAT) {
+      for (int g = 0; g < m.ngeom; g++) quat_to_mat(F + o_gquat + 4 * g, o + 9 * g);
     } else {
       for (int b = 0; b < m.nbody; b++) {
-        const double* q = S + l.xquat + 4 * b;
+        double r[9];
+        quat_to_mat(F + o_xquat + 4 * b, r);
         const double* ip = m.body_ipos + 3 * b;
-        double w = q[0], x = q[1], y = q[2], z = q[3];
-        double r[9] = {w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y),
-                       2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x),
-                       2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z};
         for (int k = 0; k < 3; k++)
-          o[3 * b + k] = S[l.xpos + 3 * b + k] + r[3 * k] * ip[0] + r[3 * k + 1] * ip[1] + r[3 * k + 2] * ip[2];
+          o[3 * b + k] = F[o_xpos + 3 * b + k] + r[3 * k] * ip[0] + r[3 * k + 1] * ip[1] + r[3 * k + 2] * ip[2];
       }
     }
   }

@@ -105,7 +105,13 @@ struct StepArgs {
   const int32_t* agent_body;   // [n_agent] body id of each agent
   const int32_t* agent_obs_len;   // [n_agent] length of the physical part of the agent's observation
   real* store;                 // [n_env][n_agent][n_slot] device data store; NaN = key not present
+  // Optional copy of the forward pass's frames for host-side plugin queries (data.body().xipos, data.contact ...,
+  // mujoco_parent.py:404-416, 472-475): [n_env][frame_doubles] = xpos | xquat | gpos | gquat | ncon | contact geoms.
+  // The reference reads those after mj_step, i.e. as the forward pass inside the step left them (pre-integration).
+  real* frames;
 };
+
+__host__ __device__ inline int frame_doubles(const DevModel& m) { return 7 * m.nbody + 7 * m.ngeom + 1 + 2 * m.nconmax; }
 
 // fused plugin ops: prog_i = {kind, i1..i7}, prog_f = {f0..f3}
 enum {
@@ -1149,6 +1155,20 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     MJ_STAMP(ST_SENSORS)
     if (a.dbg && a.dbg_stage == 0 && frame == a.skip_frames - 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
+    if (a.frames && frame == a.skip_frames - 1) {
+      real* F = a.frames + (size_t)env * frame_doubles(m);
+      const int* I = (const int*)(S + l.ints);
+      MJ_FOR(i, 3 * m.nbody) F[i] = S[l.xpos + i];
+      MJ_FOR(i, 4 * m.nbody) F[3 * m.nbody + i] = S[l.xquat + i];
+      MJ_FOR(i, 3 * m.ngeom) F[7 * m.nbody + i] = S[l.gpos + i];
+      MJ_FOR(i, 4 * m.ngeom) F[7 * m.nbody + 3 * m.ngeom + i] = S[l.gquat + i];
+      int ncon = I[I_NCON];
+      if (L == 0) F[7 * m.nbody + 7 * m.ngeom] = ncon;
+      MJ_FOR(c, m.nconmax) {
+        F[7 * m.nbody + 7 * m.ngeom + 1 + 2 * c] = c < ncon ? I[l.i_cong1 + c] : -1;
+        F[7 * m.nbody + 7 * m.ngeom + 2 + 2 * c] = c < ncon ? I[l.i_cong2 + c] : -1;
+      }
+    }
     if (!a.forward_only) stage_euler(m, l, K, RK, S, L);
     MJ_STAMP(ST_EULER)
   }

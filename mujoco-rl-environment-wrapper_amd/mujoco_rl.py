@@ -75,6 +75,9 @@ class MuJoCoRL(MuJoCoParent):
         the step kernel; otherwise (or with ``fusedPlugins: False``) it stays the host loop below."""
         self._program = fused_vocabulary.build_program(self) if allowed else None
         if self._program is None:
+            # host plugins read body / geom frames and contacts after every step: have the kernel keep them
+            if self.environment_dynamics or self.reward_functions or self.done_functions:
+                self._handle.set_query_cache(True)
             return
         names = self._compiled.names["body"]
         for agent in self.agents:
