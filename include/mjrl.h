@@ -106,6 +106,13 @@ int mjrl_set_query_cache(mjrl_env* env, int enabled);
  *   "ncon" [n_env] (as double)  "contact_geom" [n_env][nconmax][2] (as double, -1 padded). */
 int mjrl_query(mjrl_env* env, const char* name, double* h_out, size_t nbytes);
 
+/* Agent cameras (get_camera_data, mujoco_parent.py:540-555): every fixed camera of the level, ray cast at the
+ * current state; rgb [n_env][ncam][height][width][3] uint8, rows bottom-up as glReadPixels returns them
+ * (mujoco_parent.py:571, 538).  The image model (headlight Lambert shading of the geom colours, black background) is
+ * this library's own: the reference's OpenGL output cannot be reproduced here. */
+int mjrl_render_device(mjrl_env* env, int width, int height, uint8_t* d_rgb);
+int mjrl_render_host(mjrl_env* env, int width, int height, uint8_t* h_rgb);
+
 /* Debug: step once like mjrl_step_device and also dump every copy's LDS image
  * ([n_env][lds_doubles] doubles; stage 0 = end of the forward pass, 1 = after the row build).
  * mjrl_lds_offset gives the offset of a named region inside one image. */

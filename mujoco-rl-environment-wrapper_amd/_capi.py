@@ -19,6 +19,7 @@ SYMBOLS = [
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
+    "mjrl_render_device", "mjrl_render_host",
 ]
 
 _lib = None
@@ -60,6 +61,8 @@ def load():
     L.mjrl_step_profile.argtypes = [vp, vp, ci, ci, vp, ci]
     L.mjrl_set_program.argtypes = [vp, ci, ip, vp, ci, ci, ip]
     L.mjrl_set_query_cache.argtypes = [vp, ci]
+    L.mjrl_render_device.argtypes = [vp, ci, ci, vp]
+    L.mjrl_render_host.argtypes = [vp, ci, ci, vp]
     _lib = L
     return L
 
@@ -112,6 +115,15 @@ class Handle:
 
     def sync(self):
         self._check(self._lib.mjrl_sync(self._h))
+
+    def render(self, width: int, height: int, d_rgb: int | None = None):
+        """uint8 ``[n_env, ncam, height, width, 3]``; with ``d_rgb`` (device address) nothing is copied back."""
+        if d_rgb:
+            self._check(self._lib.mjrl_render_device(self._h, int(width), int(height), ctypes.c_void_p(d_rgb)))
+            return None
+        out = np.zeros((self.n_env, self.size("ncam"), height, width, 3), np.uint8)
+        self._check(self._lib.mjrl_render_host(self._h, int(width), int(height), _host_ptr(out)))
+        return out
 
     def set_query_cache(self, enabled: bool):
         self._check(self._lib.mjrl_set_query_cache(self._h, int(bool(enabled))))

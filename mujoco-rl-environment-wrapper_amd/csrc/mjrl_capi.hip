@@ -30,6 +30,56 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
   if (threadIdx.x == 0) timestep[env] = 0;
 }
 
+// Fixed body-mounted cameras as a ray caster (replaces mjv_updateScene + mjr_render + mjr_readPixels of
+// mujoco_parent.py:518-538 for the agent cameras).  One wave per env copy: body and geom frames from the current
+// qpos, then the lanes sweep the pixels of every camera; every lane tests the same geom at the same time, so the
+// geom-type switch is wave-uniform.  Camera convention of the reference's renderer: looks along -z, +x right, +y up,
+// vertical field of view fovy, rows stored bottom-up (glReadPixels order), uint8 RGB.
+__global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* qpos, int n_env, int width, int height,
+                                                         unsigned char* rgb) {
+  extern __shared__ double lds[];
+  using namespace mj;
+  const int L = wv::lane(), env = wv::env_index();
+  real* S = lds;
+  Lay l;
+  make_layout(m, l);
+  LaneK K;
+  load_lane_constants(m, L, K);
+  for (int i = L; i < m.nq; i += 64) S[l.qpos + i] = qpos[(size_t)env * m.nq + i];
+  stage_constants(m, l, S, L);
+  wv::sync();
+  stage_kinematics(m, l, K, S, L);
+  stage_geoms(m, l, S, L);
+  for (int cam = 0; cam < m.ncam; cam++) {
+    int body = m.cam_bodyid[cam];
+    Quat bq = ldq(S + l.xquat + 4 * body);
+    V3 cp = ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.cam_pos + 3 * cam));
+    M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
+    real t = tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (real)width / (real)height;
+    unsigned char* img = rgb + ((size_t)env * m.ncam + cam) * width * height * 3;
+    for (int pix = L; pix < width * height; pix += 64) {
+      int r = pix / width, c = pix % width;
+      V3 vec = normalized(mul(cm, v3((2.0 * (c + 0.5) / width - 1.0) * t * aspect, (2.0 * (r + 0.5) / height - 1.0) * t, -1.0)), 0);
+      real best = -1;
+      int hit = -1;
+      for (int g = 0; g < m.ngeom; g++) {
+        if (m.geom_rgba[4 * g + 3] == 0) continue;
+        real x = ray_geom(m.geom_type[g], ld3(S + l.gpos + 3 * g), qmat(ldq(S + l.gquat + 4 * g)), ld3(S + l.gsize + 3 * g), cp, vec);
+        if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
+      }
+      unsigned char out[3] = {0, 0, 0};
+      if (hit >= 0) {
+        V3 n = geom_normal(m.geom_type[hit], ld3(S + l.gpos + 3 * hit), qmat(ldq(S + l.gquat + 4 * hit)),
+                           ld3(S + l.gsize + 3 * hit), cp + vec * best);
+        real shade = 0.4 + 0.6 * fmax(-dot(n, vec), 0.0);
+        for (int k = 0; k < 3; k++)
+          out[k] = (unsigned char)(255.0 * fmin(fmax(m.geom_rgba[4 * hit + k], 0.0), 1.0) * shade + 0.5);
+      }
+      img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2];
+    }
+  }
+}
+
 std::string g_create_error;
 
 }  // namespace
@@ -139,6 +189,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
   CK(hipMalloc(&e->d_mask, n_env));
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CK(hipFuncSetAttribute((const void*)mjrl_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 #undef CK
   if (launch_reset(e, nullptr)) return fail(6, e->err);
   he = hipStreamSynchronize(e->stream);
@@ -430,6 +481,30 @@ int mjrl_get_field(mjrl_env* e, const char* name, void* h_out, size_t nbytes) {
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   if (f.bytes) MJRL_HIP(e, hipMemcpy(h_out, f.ptr, f.bytes, hipMemcpyDeviceToHost));
   return 0;
+}
+
+int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
+  if (width <= 0 || height <= 0 || !d_rgb) MJRL_FAIL(e, 3, "render: bad arguments");
+  if (e->hm.ncam == 0) MJRL_FAIL(e, 3, "render: the level has no cameras");
+  size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
+  hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, e->qpos, e->n_env, width,
+                     height, d_rgb);
+  MJRL_HIP(e, hipGetLastError());
+  return 0;
+}
+
+int mjrl_render_host(mjrl_env* e, int width, int height, uint8_t* h_rgb) {
+  size_t n = (size_t)e->n_env * e->hm.ncam * width * height * 3;
+  uint8_t* d = nullptr;
+  MJRL_HIP(e, hipMalloc(&d, n ? n : 1));
+  int rc = mjrl_render_device(e, width, height, d);
+  if (!rc) {
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(h_rgb, d, n, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { e->err = hipGetErrorString(he); rc = 100 + (int)he; }
+  }
+  hipFree(d);
+  return rc;
 }
 
 int mjrl_set_query_cache(mjrl_env* e, int enabled) {

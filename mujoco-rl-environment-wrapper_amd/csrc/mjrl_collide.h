@@ -301,6 +301,27 @@ __device__ __forceinline__ real ray_geom(int type, V3 gp, const M3& gm, V3 gs, V
   return -1;
 }
 
+// outward surface normal of a geom at a point on its surface (shading of the ray-cast camera)
+__device__ __forceinline__ V3 geom_normal(int type, V3 gp, const M3& gm, V3 gs, V3 hit) {
+  V3 rel = hit - gp;
+  if (type == GEOM_PLANE) return col(gm, 2);
+  if (type == GEOM_SPHERE) return normalized(rel, 0);
+  if (type == GEOM_CAPSULE) {
+    V3 axis = col(gm, 2);
+    real h = fmin(fmax(dot(rel, axis), -gs.y), gs.y);
+    return normalized(rel - axis * h, 0);
+  }
+  V3 loc = mulT(gm, rel);
+  real ax = fabs(loc.x) / gs.x, ay = fabs(loc.y) / gs.y, az = fabs(loc.z) / gs.z;
+  int face = 0;
+  real best = ax;
+  if (ay > best) { best = ay; face = 1; }
+  if (az > best) { best = az; face = 2; }
+  real l = face == 0 ? loc.x : (face == 1 ? loc.y : loc.z);
+  V3 n = col(gm, face);
+  return l >= 0 ? n : n * -1.0;
+}
+
 }  // namespace mj
 
 #endif

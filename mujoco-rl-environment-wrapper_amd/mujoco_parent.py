@@ -387,7 +387,20 @@ class MuJoCoParent:
         return bool(hit[0]) if self.n_env == 1 else hit
 
     def get_camera_data(self, cam_object: str):
-        raise Exception("agent cameras need the ray-cast render entry, which this build does not provide yet")
+        """Images of all cameras of an agent, ``(ncam_agent, W, H, 3)`` uint8, or of one camera by name
+        (mujoco_parent.py:540-555); with several env copies a leading ``[numEnvs]`` axis is added.  Ray cast on
+        the device (mjrl_render_*), not OpenGL."""
+        width, height = self.sensor_resolution
+        names = self._compiled.names["camera"]
+        images = self._handle.render(width, height)            # [n_env, ncam, H, W, 3], rows bottom-up
+        images = images.reshape(self.n_env, len(names), width, height, 3)   # the reference's (W, H, 3) view of it
+        if cam_object in self.rgb_sensors:
+            picked = images[:, [names.index(c) for c in self.rgb_sensors[cam_object]]]
+        elif cam_object in names:
+            picked = images[:, names.index(cam_object)]
+        else:
+            raise Exception(f"{cam_object} is neither an agent with cameras (agentCameras must be set) nor a camera")
+        return picked[0] if self.n_env == 1 else picked
 
     def start_render(self):
         raise Exception("interactive rendering is out of scope of the batched stepper")

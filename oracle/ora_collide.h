@@ -352,4 +352,32 @@ static inline double ora_ray_geom(int type, const double* gpos, const double* gm
   }
 }
 
+/* outward surface normal of a geom at a point on its surface (for the ray-cast camera's shading) */
+static inline void ora_geom_normal(int type, const double* gpos, const double* gmat, const double* gsize,
+                                   const double* hit, double* n) {
+  double rel[3];
+  v3_sub(rel, hit, gpos);
+  if (type == ORA_GEOM_PLANE) { n[0] = gmat[2]; n[1] = gmat[5]; n[2] = gmat[8]; return; }
+  if (type == ORA_GEOM_SPHERE) { v3_copy(n, rel); v3_normalize(n); return; }
+  if (type == ORA_GEOM_CAPSULE) {
+    double axis[3] = {gmat[2], gmat[5], gmat[8]};
+    double h = v3_dot(rel, axis);
+    if (h > gsize[1]) h = gsize[1];
+    if (h < -gsize[1]) h = -gsize[1];
+    v3_addscl(n, rel, axis, -h);
+    v3_normalize(n);
+    return;
+  }
+  /* box: the face whose normalised coordinate is largest */
+  double loc[3], best = -1.0;
+  int face = 0;
+  m3_mulTv(loc, gmat, rel);
+  for (int k = 0; k < 3; k++) {
+    double a = fabs(loc[k]) / gsize[k];
+    if (a > best) { best = a; face = k; }
+  }
+  double sg = loc[face] >= 0 ? 1.0 : -1.0;
+  n[0] = sg * gmat[face]; n[1] = sg * gmat[3 + face]; n[2] = sg * gmat[6 + face];
+}
+
 #endif

@@ -844,6 +844,48 @@ void ora_reset(const ora_model* m, ora_data* d) {
   ora_forward(m, d);
 }
 
+/* ------------------------------------------------------------------ camera (config 5)
+ * Fixed body-mounted camera as a ray caster: the reference renders it with OpenGL (mujoco_parent.py:518-538,
+ * mjv_updateScene + mjr_render + mjr_readPixels); no renderer is available here, so the image model is this
+ * repo's own and pixel parity with the reference is UNPINNED.  Conventions kept from the reference: the camera
+ * looks along -z of its frame with +x right and +y up, vertical field of view fovy, uint8 RGB, rows stored
+ * bottom-up as glReadPixels returns them, shape (W, H, 3).  Shading: geom rgba (clamped to [0,1]) times
+ * (0.4 + 0.6 * max(0, n . -ray)) (a headlight), background black. */
+void ora_render(const ora_model* m, ora_data* d, int cam, int width, int height, unsigned char* out) {
+  ora_kinematics(m, d);
+  const double* cp = d->cam_xpos + 3 * cam;
+  const double* cm = d->cam_xmat + 9 * cam;
+  double t = tan(0.5 * m->cam_fovy[cam] * ORA_PI / 180.0), aspect = (double)width / (double)height;
+  for (int r = 0; r < height; r++)
+    for (int c = 0; c < width; c++) {
+      double lx = (2.0 * (c + 0.5) / width - 1.0) * t * aspect, ly = (2.0 * (r + 0.5) / height - 1.0) * t;
+      double loc[3] = {lx, ly, -1.0}, vec[3];
+      m3_mulv(vec, cm, loc);
+      v3_normalize(vec);
+      double best = -1.0;
+      int hit = -1;
+      for (int g = 0; g < m->ngeom; g++) {
+        if (m->geom_rgba[4 * g + 3] == 0) continue;
+        double x = ora_ray_geom(m->geom_type[g], d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, cp, vec);
+        if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
+      }
+      unsigned char* px = out + 3 * ((size_t)r * width + c);
+      if (hit < 0) { px[0] = px[1] = px[2] = 0; continue; }
+      double p[3], n[3];
+      v3_addscl(p, cp, vec, best);
+      ora_geom_normal(m->geom_type[hit], d->geom_xpos + 3 * hit, d->geom_xmat + 9 * hit, m->geom_size + 3 * hit, p, n);
+      double lambert = -v3_dot(n, vec);
+      if (lambert < 0) lambert = 0;
+      double shade = 0.4 + 0.6 * lambert;
+      for (int k = 0; k < 3; k++) {
+        double col = m->geom_rgba[4 * hit + k];
+        if (col > 1) col = 1;
+        if (col < 0) col = 0;
+        px[k] = (unsigned char)(255.0 * col * shade + 0.5);
+      }
+    }
+}
+
 /* ------------------------------------------------------------------ accessors for the test harness */
 typedef struct { const char* name; size_t offset; } field_t;
 #define F(name) {#name, offsetof(ora_data, name)}

@@ -48,6 +48,7 @@ def lib():
         L.ora_time.argtypes = [ctypes.c_void_p]
         L.ora_time.restype = ctypes.c_double
         L.ora_contact_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        L.ora_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.ora_model_size.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         L.ora_model_size.restype = ctypes.c_int
         _lib = L
@@ -129,6 +130,12 @@ class OracleEnv:
     @property
     def time(self):
         return lib().ora_time(self._d)
+
+    def render(self, cam: int, width: int = 64, height: int = 64):
+        """uint8 image (width, height, 3) of fixed camera ``cam`` at the current qpos (rows bottom-up)."""
+        out = np.zeros((height, width, 3), np.uint8)
+        lib().ora_render(self._m, self._d, cam, width, height, out.ctypes.data_as(ctypes.c_void_p))
+        return out.reshape(width, height, 3)
 
     def contacts(self):
         out = []

@@ -266,6 +266,39 @@ def test_fused_vocabulary_equals_the_host_plugin_loop():
     host.close()
 
 
+def test_agent_cameras_match_the_oracle_ray_caster():
+    """Config 5: body-mounted cameras, 64x64x3 uint8 (the input contract of vision/autoencoder.py:13).  Pixel parity
+    with the reference's OpenGL output is unpinned; the device ray caster is checked against the
+    oracle's on the same states, allowing isolated one-level differences on silhouette edges."""
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 3, "agentCameras": True})
+    env.reset()
+    oras = [OracleEnv(env._blob) for _ in range(3)]
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        action = {a: rng.uniform(-1, 1, (3, 8)) for a in AGENTS}
+        env.step(action)
+        for e, o in enumerate(oras):
+            for a in AGENTS:
+                o.ctrl[env.agents_action_index[a]] = action[a][e]
+            o.step()
+    images = env.get_camera_data("sender")
+    assert images.shape == (3, 1, 64, 64, 3) and images.dtype == np.uint8
+    assert env.get_camera_data("receiver_camera").shape == (3, 64, 64, 3)
+    for e, o in enumerate(oras):
+        o.qpos[:] = env._handle.get_field("qpos")[e]          # render the very same state
+        for cam, agent in enumerate(AGENTS):
+            ref = o.render(cam, 64, 64).astype(int)
+            got = env.get_camera_data(agent)[e, 0].astype(int)
+            differ = np.abs(ref - got).max(axis=-1) > 0
+            assert differ.mean() < 0.002 and np.abs(ref - got).max() <= 255
+            assert (got.sum(axis=-1) > 0).mean() > 0.2        # the image is not empty
+    one = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "agentCameras": True})
+    one.reset()
+    assert one.get_camera_data("sender").shape == (1, 64, 64, 3)     # the reference's (ncam, W, H, 3)
+    env.close()
+    one.close()
+
+
 def test_errors_are_reported_not_swallowed():
     model, packed, h = make("two_agent.xml", 2)
     with pytest.raises(Exception, match="unknown field"):
