@@ -30,7 +30,8 @@ const char* mjrl_last_error(const mjrl_env* env);
 
 /* Upload a compiled model (blob.py layout) and allocate state for n_env copies on device_id.
  * Replaces: mj.MjModel.from_xml_path + mj.MjData (mujoco_parent.py:126-127), once per copy.
- * All copies start at qpos0 with zero velocity (as after mj_resetData, mujoco_parent.py:349). */
+ * All copies start at qpos0 with zero velocity (as after mj_resetData, mujoco_parent.py:349).
+ * flags bit 0: turn off the longest-first dispatch (copies are then stepped by workgroup id == copy id). */
 int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out);
 void mjrl_destroy(mjrl_env* env);
 

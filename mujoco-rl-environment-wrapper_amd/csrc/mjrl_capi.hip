@@ -105,6 +105,10 @@ struct mjrl_env {
   int base_obs_dim = 0, n_extra = 0, n_op = 0, n_slot = 0;
   int32_t *d_prog_i = nullptr, *d_agent_body = nullptr, *d_obs_len = nullptr;
   double *d_prog_f = nullptr, *store = nullptr;
+  // longest-first dispatch: two generations of work buckets (read the previous launch's, fill the next one's)
+  int *lpt_count[2] = {nullptr, nullptr}, *lpt_list[2] = {nullptr, nullptr};
+  int lpt_cur = 0;
+  bool lpt_valid = false, lpt_enabled = true;
   // forward-pass frames kept for host-side plugin queries
   double* frames = nullptr;
   bool frames_valid = false;
@@ -140,7 +144,8 @@ void mjrl_destroy(mjrl_env* e) {
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_blob, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
-                  e->d_obs_len, e->d_prog_f, e->store, e->frames};
+                  e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_list[0],
+                  e->lpt_list[1]};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
@@ -154,7 +159,6 @@ static int launch_reset(mjrl_env* e, const unsigned char* d_mask) {
 }
 
 int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out) {
-  (void)flags;
   if (!blob || !out || n_env <= 0) { g_create_error = "mjrl_create: bad arguments"; return 1; }
   mjrl_env* e = new mjrl_env();
   auto fail = [&](int code, const std::string& msg) { g_create_error = msg; mjrl_destroy(e); return code; };
@@ -188,6 +192,11 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->sens, sizeof(double) * n_env * (m.nsensordata > 0 ? m.nsensordata : 1)));
   CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
   CK(hipMalloc(&e->d_mask, n_env));
+  e->lpt_enabled = !(flags & 1u);
+  for (int g = 0; g < 2; g++) {
+    CK(hipMalloc(&e->lpt_count[g], sizeof(int) * mj::LPT_BUCKETS));
+    CK(hipMalloc(&e->lpt_list[g], sizeof(int) * mj::LPT_BUCKETS * (size_t)n_env));
+  }
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 #undef CK
@@ -395,6 +404,15 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
   a.frames = e->frames;
   if (e->frames && skip_frames > 0) e->frames_valid = true;
+  if (e->lpt_enabled && !forward_only && !d_dbg) {
+    int in = e->lpt_cur, out = 1 - e->lpt_cur;
+    MJRL_HIP(e, hipMemsetAsync(e->lpt_count[out], 0, sizeof(int) * mj::LPT_BUCKETS, e->stream));
+    if (e->lpt_valid) { a.lpt_count_in = e->lpt_count[in]; a.lpt_list_in = e->lpt_list[in]; }
+    a.lpt_count_out = e->lpt_count[out];
+    a.lpt_list_out = e->lpt_list[out];
+    e->lpt_cur = out;
+    e->lpt_valid = true;
+  }
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
   hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, a);
   MJRL_HIP(e, hipGetLastError());

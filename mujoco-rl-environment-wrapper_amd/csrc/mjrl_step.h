@@ -109,7 +109,17 @@ struct StepArgs {
   // mujoco_parent.py:404-416, 472-475): [n_env][frame_doubles] = xpos | xquat | gpos | gquat | ncon | contact geoms.
   // The reference reads those after mj_step, i.e. as the forward pass inside the step left them (pre-integration).
   real* frames;
+  // Longest-first dispatch: a copy's solver work (rows x sweeps) in the previous step predicts this step's, and
+  // workgroups are dispatched in index order, so handing the heavy copies to the lowest workgroup ids keeps a straggler
+  // from starting last.  Each wave files its copy under a work bucket for the next launch (lpt_*_out) and picks its copy
+  // from the previous launch's buckets, heaviest bucket first (lpt_*_in; null = identity order).  Which workgroup steps a
+  // copy has no effect on the copy's result.
+  const int* lpt_count_in;     // [LPT_BUCKETS]
+  const int* lpt_list_in;      // [LPT_BUCKETS][n_env]
+  int* lpt_count_out;
+  int* lpt_list_out;
 };
+enum { LPT_BUCKETS = 16 };
 
 __host__ __device__ inline int frame_doubles(const DevModel& m) { return 7 * m.nbody + 7 * m.ngeom + 1 + 2 * m.nconmax; }
 
@@ -1093,7 +1103,17 @@ __device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK&
 // ------------------------------------------------------------------ one env copy, one step() call
 __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   const int L = wv::lane();
-  const int env = wv::env_index();
+  int env = wv::env_index();
+  if (a.lpt_count_in) {
+    // workgroup id -> copy: walk the buckets from the heaviest down
+    int rest = env, pick = -1;
+    for (int b = LPT_BUCKETS - 1; b >= 0 && pick < 0; b--) {
+      int c = a.lpt_count_in[b];
+      if (rest < c) pick = a.lpt_list_in[(size_t)b * a.n_env + rest];
+      rest -= c;
+    }
+    env = pick;
+  }
   Lay l;
   make_layout(m, l);
   LaneK K;
@@ -1249,6 +1269,15 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   }
   wv::sync();
   if (L == 0) a.timestep[env] = ts + 1;
+  if (a.lpt_count_out && L == 0) {
+    const int* I = (const int*)(S + l.ints);
+    unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
+    int b = 0;
+    while (work) { b++; work >>= 1; }
+    if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
+    int pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
+    a.lpt_list_out[(size_t)b * a.n_env + pos] = env;
+  }
 #undef MJ_FOR
 }
 

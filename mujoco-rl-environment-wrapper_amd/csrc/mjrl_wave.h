@@ -29,6 +29,8 @@ __device__ __forceinline__ int popc(unsigned long long x) { return __popcll(x); 
 // wave clock (s_memtime) and a device-scope counter add, for the diagnostic stage stamps only
 __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)clock64(); }
 __device__ __forceinline__ void atomic_add(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+// device-scope counter add returning the old value (work-bucket slots of the longest-first dispatch)
+__device__ __forceinline__ int atomic_add_int(int* p, int v) { return atomicAdd(p, v); }
 
 // 64-bit value moved with a DPP control word (two v_mov_b32_dpp); every lane reads a lane of its own row of 16
 template <int CTRL>
