@@ -204,7 +204,7 @@ class Handle:
         return out
 
     STAGES = ["load", "kin", "com", "crb", "factor", "geom", "collide", "vel", "smooth", "rows", "project", "pgs",
-              "sensors", "euler", "store"]
+              "sensors", "euler", "store", "pgs_warm", "pgs_lists", "pgs_sweeps"]
 
     def step_profile(self, skip_frames=1):
         out = np.zeros(len(self.STAGES), np.uint64)

@@ -12,9 +12,12 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void mjrl_step_kernel(DevModel m, mj::StepArgs a) {
+// The model descriptor (sizes + ~100 section pointers) is read through a pointer: passed by value it would sit in
+// SGPRs for the whole kernel and spill to VGPR lanes (2600 v_readlane/v_writelane in the ISA); behind a const
+// __restrict__ pointer every field is a scalar load at its point of use.
+__global__ __launch_bounds__(64) void mjrl_step_kernel(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
-  mj::env_step(m, a, lds);
+  mj::env_step(*mp, a, lds);
 }
 
 // masked reset of the HBM state (mj_resetData for the selected copies)
@@ -89,6 +92,7 @@ struct mjrl_env {
   DevModel hm{}, dm{};
   mj::Lay lay{};
   void* d_blob = nullptr;
+  DevModel* d_model = nullptr;     // device copy of `dm`
   int n_env = 0, device = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
@@ -142,7 +146,7 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   hipSetDevice(e->device);
-  void* ptrs[] = {e->d_blob, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  void* ptrs[] = {e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_list[0],
                   e->lpt_list[1]};
@@ -185,6 +189,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->d_blob, nbytes));
   CK(hipMemcpy(e->d_blob, blob, nbytes, hipMemcpyHostToDevice));
   mjrl_model_from_blob(&e->dm, e->h_blob.data(), nbytes, e->d_blob);
+  CK(hipMalloc(&e->d_model, sizeof(DevModel)));
+  CK(hipMemcpy(e->d_model, &e->dm, sizeof(DevModel), hipMemcpyHostToDevice));
   CK(hipMalloc(&e->qpos, sizeof(double) * n_env * m.nq));
   CK(hipMalloc(&e->qvel, sizeof(double) * n_env * m.nv));
   CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
@@ -341,6 +347,12 @@ int mjrl_size(const mjrl_env* e, const char* name) {
   if (!strcmp(name, "obs_dim")) return e->obs_dim;
   if (!strcmp(name, "n_agent")) return e->n_agent;
   if (!strcmp(name, "n_env")) return e->n_env;
+  if (!strcmp(name, "blocks_per_cu")) {      // what the runtime says about residency of the step kernel
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)mjrl_step_kernel, 64,
+                                                     (size_t)e->lay.total * sizeof(double)) != hipSuccess) return -1;
+    return n;
+  }
   if (!strcmp(name, "n_slot")) return e->n_slot;
   if (!strcmp(name, "n_extra_obs")) return e->n_extra;
   if (!strcmp(name, "lds_doubles")) return e->lay.total;
@@ -414,7 +426,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     e->lpt_valid = true;
   }
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
-  hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, a);
+  hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }

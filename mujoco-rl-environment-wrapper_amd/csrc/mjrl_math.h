@@ -59,8 +59,9 @@ __device__ __forceinline__ Quat qnormalized(Quat q) {
   return q;
 }
 __device__ __forceinline__ Quat axis_angle(V3 axis, real angle) {
-  real s = sin(0.5 * angle);
-  Quat q; q.w = cos(0.5 * angle); q.x = axis.x * s; q.y = axis.y * s; q.z = axis.z * s;
+  real s, c;
+  sincos(0.5 * angle, &s, &c);      // one argument reduction for both
+  Quat q; q.w = c; q.x = axis.x * s; q.y = axis.y * s; q.z = axis.z * s;
   return q;
 }
 
@@ -152,6 +153,10 @@ __device__ __forceinline__ real impedance(const real* solimp, real pos, real mar
   if (x == 0) return dmin;
   real y;
   if (power == 1) y = x;
+  else if (power == 2) {            // the default exponent: a square, not a call to pow
+    if (x <= mid) { real t = x / mid; y = t * t * mid; }
+    else { real t = (1 - x) / (1 - mid); y = 1 - t * t * (1 - mid); }
+  }
   else if (x <= mid) y = pow(x / mid, power) * mid;
   else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
   return dmin + y * (dmax - dmin);

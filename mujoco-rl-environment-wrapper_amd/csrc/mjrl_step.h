@@ -133,7 +133,7 @@ enum {
 };
 
 enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_VEL, ST_SMOOTH, ST_ROWS, ST_PROJECT, ST_PGS,
-       ST_SENSORS, ST_EULER, ST_STORE, N_STAMPS };
+       ST_SENSORS, ST_EULER, ST_STORE, ST_PGS_WARM, ST_PGS_LISTS, ST_PGS_SWEEPS, N_STAMPS };
 
 // The lane's own records of the model, fetched once per launch
 struct LaneK {
@@ -854,7 +854,14 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
 // multiply-add.  In the tree-row lane map a constraint row that touches one kinematic tree only involves that tree's
 // row of 16 lanes, so the trees sweep their own rows side by side (rows of different trees commute, the order inside
 // a tree is the solver's row order); a step with a row that couples two trees falls back to the serial sweep.
-__device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L) {
+__device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L,
+                                 unsigned long long* stamps, unsigned long long& t_prev) {
+#define MJ_SUBSTAMP(k)                                                     \
+  if (stamps) {                                                            \
+    unsigned long long t_now = wv::clock();                                \
+    if (L == 0) wv::atomic_add(stamps + (k), t_now - t_prev);              \
+    t_prev = t_now;                                                        \
+  }
   int* I = (int*)(S + l.ints);
   int nefc = I[I_NEFC];
   const int mydof = RK.dof;
@@ -880,6 +887,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     u = 0;
     for (int r = L; r < nefc; r += 64) S[l.row + ROW_STRIDE * r + ROW_F] = 0;
   }
+  MJ_SUBSTAMP(ST_PGS_WARM)
   // per-tree row lists (the work-item list of the collision stage is free again): slot[base_t + rank] = row
   const int mytree = L >> 4;
   int cnt_my = 0, base_my = 0, tmax = 0;
@@ -902,33 +910,46 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     }
   }
   wv::sync();
+  MJ_SUBSTAMP(ST_PGS_LISTS)
   real scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
   int iter = 0;
   if (m.rowmap && !cross) {
     const bool leader = (L & 15) == 0;
+    // software pipeline: the record of the tree's next row is fetched while the current row is processed
+    // (the row list is the same in every sweep; only the force F changes, and a row's F is rewritten by this
+    // tree's lanes alone)
+    struct Rec { int i; bool has; real bid, fi, Ri, bi, aii, ainv; };
+    auto fetch = [&](int sidx) {
+      Rec r;
+      r.has = sidx < cnt_my;
+      r.i = r.has ? I[l.i_item + base_my + sidx] : 0;
+      const real* R = S + l.row + ROW_STRIDE * r.i;
+      r.bid = (dof && r.has) ? S[l.J + l.ldj * r.i + mydof] : 0.0;
+      r.fi = R[ROW_F]; r.Ri = R[ROW_R]; r.bi = R[ROW_B]; r.aii = R[ROW_ARII]; r.ainv = R[ROW_ARINV];
+      return r;
+    };
+    Rec nxt = fetch(0);
     while (iter < m.iterations) {
       real imp = 0;
-      for (int s = 0; s < tmax; s++) {
-        bool has = s < cnt_my;
-        int i = has ? I[l.i_item + base_my + s] : 0;
-        const real* R = S + l.row + ROW_STRIDE * i;
-        real bid = (dof && has) ? S[l.J + l.ldj * i + mydof] : 0.0;
-        real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = R[ROW_ARINV];
-        real res = wv::sum16(bid * dinv * u) + Ri * fi + bi;
-        real fn = fi - res * ainv;
+      for (int sidx = 0; sidx < tmax; sidx++) {
+        Rec c = nxt;
+        nxt = fetch(sidx + 1 < tmax ? sidx + 1 : 0);
+        real res = wv::sum16(c.bid * dinv * u) + c.Ri * c.fi + c.bi;
+        real fn = c.fi - res * c.ainv;
         if (fn < 0) fn = 0;
-        real delta = fn - fi;
-        real change = 0.5 * delta * delta * aii + delta * res;
-        if (change > 1e-10 || !has) { fn = fi; delta = 0; change = 0; }
+        real delta = fn - c.fi;
+        real change = 0.5 * delta * delta * c.aii + delta * res;
+        if (change > 1e-10 || !c.has) { fn = c.fi; delta = 0; change = 0; }
         imp -= change;
-        u += delta * bid;
-        if (leader && has) S[l.row + ROW_STRIDE * i + ROW_F] = fn;
+        u += delta * c.bid;
+        if (leader && c.has) S[l.row + ROW_STRIDE * c.i + ROW_F] = fn;
+        if (nxt.i == c.i) nxt.fi = fn;      // the same row comes again (a tree with a single row)
       }
       iter++;
-      real improvement = wv::sum(leader ? imp : 0.0);
-      wv::sync();
+      real improvement = wv::rows4_sum(imp);
       if (improvement * scale < m.tolerance) break;
     }
+    wv::sync();
   } else {
     const int width = m.rowmap ? 64 : (m.nv <= 16 ? 16 : (m.nv <= 32 ? 32 : 64));
     while (iter < m.iterations) {
@@ -954,6 +975,8 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     }
   }
   if (L == 0) I[I_NITER] = iter;
+  MJ_SUBSTAMP(ST_PGS_SWEEPS)
+#undef MJ_SUBSTAMP
   // back to joint space: qfrc_constraint = L' u ; qacc = qacc_smooth + L^-1 D^-1 u
   if (m.rowmap) {
     // (L' u)_d = u_d + sum over descendants k of L[k][d] u_k: the backward-solve pattern with the ORIGINAL u
@@ -1169,7 +1192,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     if (a.dbg && a.dbg_stage == 1 && frame == a.skip_frames - 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     MJ_STAMP(ST_PROJECT)
-    stage_pgs(m, l, K, RK, S, L);
+    stage_pgs(m, l, K, RK, S, L, a.stamps, t_prev);
     MJ_STAMP(ST_PGS)
     stage_sensors(m, l, K, S, L);
     MJ_STAMP(ST_SENSORS)

@@ -63,6 +63,16 @@ __device__ __forceinline__ double bcast16(double v) { return dpp<0x150 + N>(v); 
 // all-reduce (sum) inside each row of 16 lanes only
 __device__ __forceinline__ double sum16(double v) { return sum_n(v, 16); }
 
+// sum of the values held by lanes 0, 16, 32 and 48 (one per row of 16), in every lane: v_readlane, no LDS traffic.
+// Association (r0 + r1) + (r2 + r3), the same as the xor butterfly gives for a value that is zero elsewhere.
+__device__ __forceinline__ double lane_value(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rows4_sum(double v) {
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
 // lane 0's value in every lane (v_readfirstlane: the result is wave-uniform)
 __device__ __forceinline__ double first(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));

@@ -445,6 +445,10 @@ static double impedance(const double* solimp, double pos, double margin) {
   if (x == 0) return dmin;
   double y;
   if (power == 1) y = x;
+  else if (power == 2) {                                       /* the default exponent: a plain square */
+    if (x <= mid) { double t = x / mid; y = t * t * mid; }
+    else { double t = (1 - x) / (1 - mid); y = 1 - t * t * (1 - mid); }
+  }
   else if (x <= mid) y = pow(x / mid, power) * mid;           /* a*x^p with a = 1/mid^(p-1) */
   else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);    /* 1 - b*(1-x)^p with b = 1/(1-mid)^(p-1) */
   return dmin + y * (dmax - dmin);
