@@ -122,7 +122,7 @@ int mjrl_step_debug(mjrl_env* env, const double* d_actions, int act_dim, int ski
 int mjrl_lds_offset(const mjrl_env* env, const char* region);
 /* Diagnostic: one step with per-stage wave-clock stamps; h_cycles[n] receives, per stage, the cycles summed
  * over all env copies (stage order: load kin com crb factor geom collide vel smooth rows project pgs sensors
- * euler store pgs_warm pgs_lists pgs_sweeps; "pgs" then holds the rest of the solver stage; n must be 18). */
+ * euler store pgs_warm pgs_lists pgs_sweeps; "pgs" then holds the rest of the solver stage; plus rows_limits rows_addr (then "rows" is the row build proper); n must be 20). */
 int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
                       unsigned long long* h_cycles, int n);
 

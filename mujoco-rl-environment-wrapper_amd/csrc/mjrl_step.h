@@ -133,7 +133,7 @@ enum {
 };
 
 enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_VEL, ST_SMOOTH, ST_ROWS, ST_PROJECT, ST_PGS,
-       ST_SENSORS, ST_EULER, ST_STORE, ST_PGS_WARM, ST_PGS_LISTS, ST_PGS_SWEEPS, N_STAMPS };
+       ST_SENSORS, ST_EULER, ST_STORE, ST_PGS_WARM, ST_PGS_LISTS, ST_PGS_SWEEPS, ST_ROWS_LIMITS, ST_ROWS_ADDR, N_STAMPS };
 
 // The lane's own records of the model, fetched once per launch
 struct LaneK {
@@ -656,7 +656,14 @@ __device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK
 // dump of the raw rows was requested) immediately projects it:  J <- J L^-1  by back substitution restricted to the
 // row's own dof chains, and AR_ii = sum_d B_id^2 / D_d + R_i.  A row only touches the dof chains of its (at most
 // two) bodies; the chains are read from the LDS structure tables.
-__device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int L, bool project) {
+__device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int L, bool project,
+                                  unsigned long long* stamps, unsigned long long& t_prev) {
+#define MJ_SUBSTAMP(k)                                                     \
+  if (stamps) {                                                            \
+    unsigned long long t_now = wv::clock();                                \
+    if (L == 0) wv::atomic_add(stamps + (k), t_now - t_prev);              \
+    t_prev = t_now;                                                        \
+  }
   int* I = (int*)(S + l.ints);
   const Tab T = make_tab(m, l, S);
   int ncon = I[I_NCON], warn = I[I_WARN];
@@ -682,6 +689,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     nlim += wv::popc(mask);
   }
   if (nlim > m.njmax) { nlim = m.njmax; warn |= 2; }
+  MJ_SUBSTAMP(ST_ROWS_LIMITS)
   // contacts: one lane per contact, pyramid addresses by prefix sums of the row counts (1, 2 or 4 rows each)
   {
     int rows = 0;
@@ -726,6 +734,8 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     if (L == 0) { I[I_NEFC] = total; I[I_NLIM] = nlim; I[I_WARN] = warn; }
   }
   wv::sync();
+  MJ_SUBSTAMP(ST_ROWS_ADDR)
+#undef MJ_SUBSTAMP
   int nefc = I[I_NEFC];
   for (int r = L; r < nefc; r += 64) {
     real* Jr = S + l.J + l.ldj * r;
@@ -738,10 +748,14 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     bool contact = id >= 0;
     // the row's dof chains: chain x = sparse-M row of dof lx, entries at ax .. ax + nx - 1 (descending dof ids)
     int a1 = 0, n1 = 0, a2 = 0, n2 = 0;
+    real lim_val = 0, c_mu = 0, c_sgn = 0;
+    int c_dim = 0;
+    V3 c_n = v3(0, 0, 0), c_tk = v3(0, 0, 0), c_off1 = v3(0, 0, 0), c_off2 = v3(0, 0, 0);
     if (!contact) {
       int it = -id - 1, j = it >> 1, side = (it & 1) ? 1 : -1;
       int dof = m.jnt_dofadr[j];
       Jr[dof] = -side;
+      lim_val = -side;
       rtree = T.dof_tree(dof);
       a2 = T.madr(dof); n2 = T.ddepth(dof) + 1;
       pos = R[ROW_F];
@@ -768,8 +782,10 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       int l1 = T.body_lastdof(b1), l2 = T.body_lastdof(b2);
       if (l1 >= 0) { a1 = T.madr(l1); n1 = T.ddepth(l1) + 1; }
       if (l2 >= 0) { a2 = T.madr(l2); n2 = T.ddepth(l2) + 1; }
+      c_n = n; c_tk = tk; c_mu = mu; c_sgn = sgn; c_dim = dim; c_off1 = off1; c_off2 = off2;
       int p1 = 0, p2 = 0;
-      int i1 = n1 > 0 ? T.colid(a1) : -1, i2 = n2 > 0 ? T.colid(a2) : -1;
+      // rows between two moving bodies walk the merged chains through LDS; one-chain rows are built in registers below
+      int i1 = (n1 > 0 && n2 > 0) ? T.colid(a1) : -1, i2 = (n1 > 0 && n2 > 0) ? T.colid(a2) : -1;
       while (i1 >= 0 || i2 >= 0) {
         int i = i1 > i2 ? i1 : i2;
         V3 ca = ld3(S + l.cdof + 6 * i), cl = ld3(S + l.cdof + 6 * i + 3);
@@ -794,10 +810,40 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       solimp = simp;
       contact = dim > 1;
     }
-    // velocity, smooth acceleration and warm-start acceleration along the row: ascending over the union of the two
-    // chains (every other entry of the row is zero, so this is the full ascending dot product)
+    // One-chain rows (every limit row, every contact with a static geom): the row lives in registers, indexed by the
+    // position along the chain (t = 0 deepest dof ... nc-1 tree root); all loops are unrolled to the chain-depth cap.
+    const bool single = (n1 == 0 || n2 == 0);
+    const int ac = n2 ? a2 : a1, nc = n2 ? n2 : n1;
+    real Bv[MAX_DOF_DEPTH];
+    int cd[MAX_DOF_DEPTH];
     real vel = 0, ja = 0, jw = 0;
-    {
+    if (single) {
+#pragma unroll
+      for (int t = 0; t < MAX_DOF_DEPTH; t++) { cd[t] = t < nc ? T.colid(ac + t) : 0; Bv[t] = 0; }
+      if (id < 0) {
+        Bv[0] = lim_val;
+      } else {
+        V3 offc = n2 ? c_off2 : c_off1;
+#pragma unroll
+        for (int t = 0; t < MAX_DOF_DEPTH; t++) {
+          if (t < nc) {
+            V3 ca = ld3(S + l.cdof + 6 * cd[t]), cl = ld3(S + l.cdof + 6 * cd[t] + 3);
+            V3 colv = cl + cross(ca, offc);
+            if (!n2) colv = v3(0, 0, 0) - colv;
+            real jn = dot(c_n, colv);
+            Bv[t] = c_dim == 1 ? jn : jn + c_sgn * c_mu * dot(c_tk, colv);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = MAX_DOF_DEPTH - 1; t >= 0; t--) {      // ascending dof id
+        if (t < nc) {
+          vel += Bv[t] * S[l.qvel + cd[t]];
+          ja += Bv[t] * S[l.qaccs + cd[t]];
+          jw += Bv[t] * S[l.warm + cd[t]];
+        }
+      }
+    } else {
       int p1 = n1 - 1, p2 = n2 - 1;
       int i1 = p1 >= 0 ? T.colid(a1 + p1) : 1 << 20, i2 = p2 >= 0 ? T.colid(a2 + p2) : 1 << 20;
       while (p1 >= 0 || p2 >= 0) {
@@ -824,10 +870,32 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     R[ROW_B] = ja - aref;
     R[ROW_F] = jar < 0 ? -Dr * jar : 0.0;
     I[l.i_rowtree + r] = rtree;
-    if (!project) continue;
+    if (!project) {
+      if (single && id >= 0) {
+#pragma unroll
+        for (int t = 0; t < MAX_DOF_DEPTH; t++) if (t < nc) Jr[cd[t]] = Bv[t];
+      }
+      continue;
+    }
     // J <- J L^-1 restricted to the chains: descending over the union, each dof pushes its value to its ancestors
     real acc = 0;
-    {
+    if (single) {
+      // position t has depth nc-1-t; its ancestors are positions t+1 .. nc-1, the factor entries L[k][.] follow
+      // the diagonal of row k in the sparse layout
+#pragma unroll
+      for (int t = 0; t < MAX_DOF_DEPTH; t++) {
+        if (t < nc) {
+          real v = Bv[t];
+          acc += v * v * S[l.Dinv + cd[t]];
+          int adr = T.madr(cd[t]);
+#pragma unroll
+          for (int sft = 1; sft < MAX_DOF_DEPTH; sft++)
+            if (t + sft < nc && v != 0.0) Bv[(t + sft) & (MAX_DOF_DEPTH - 1)] -= v * S[l.LD + adr + sft];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < MAX_DOF_DEPTH; t++) if (t < nc) Jr[cd[t]] = Bv[t];
+    } else {
       int p1 = 0, p2 = 0;
       int i1 = n1 > 0 ? T.colid(a1) : -1, i2 = n2 > 0 ? T.colid(a2) : -1;
       while (i1 >= 0 || i2 >= 0) {
@@ -1187,11 +1255,10 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     stage_smooth(m, l, K, RK, S, L);
     MJ_STAMP(ST_SMOOTH)
     // (a raw-row debug dump keeps J unprojected; such a launch is for inspection only)
-    stage_rows(m, l, S, L, !(a.dbg && a.dbg_stage == 1));
+    stage_rows(m, l, S, L, !(a.dbg && a.dbg_stage == 1), a.stamps, t_prev);
     MJ_STAMP(ST_ROWS)
     if (a.dbg && a.dbg_stage == 1 && frame == a.skip_frames - 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
-    MJ_STAMP(ST_PROJECT)
     stage_pgs(m, l, K, RK, S, L, a.stamps, t_prev);
     MJ_STAMP(ST_PGS)
     stage_sensors(m, l, K, S, L);

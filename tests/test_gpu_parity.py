@@ -299,6 +299,32 @@ def test_agent_cameras_match_the_oracle_ray_caster():
     one.close()
 
 
+def test_wrappers():
+    from mjrl_amd.wrappers import BatchedVectorEnv, GymnasiumWrapper
+    single = MuJoCoRL({"xmlPath": levels.level_path("single_agent.xml"), "agents": ["sender"], "maxSteps": 5})
+    gym_env = GymnasiumWrapper(single, "sender")
+    obs, infos = gym_env.reset()
+    assert obs.shape == gym_env.observation_space.shape == (1 + 15 + 14,)
+    out = gym_env.step(gym_env.action_space.sample())
+    assert out[0].shape == obs.shape and out[1] == 0 and out[2] is False and out[3] is False and out[4] == {}
+    with pytest.raises(Exception, match="too many agents"):
+        GymnasiumWrapper(MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS}), "sender")
+    single.close()
+    vec = BatchedVectorEnv(MuJoCoRL({"xmlPath": levels.level_path("single_agent.xml"), "agents": ["sender"],
+                                     "numEnvs": 7, "maxSteps": 5}))
+    obs, _ = vec.reset()
+    assert obs.shape == (7, 30)
+    first = obs.copy()
+    for step in range(1, 8):
+        obs, rew, term, trunc, info = vec.step(np.zeros((7, 8)))
+        assert obs.shape == (7, 30) and rew.shape == (7,) and not term.any()
+        if step == 6:                      # the horizon: every copy truncated, reset, fresh observation returned
+            assert trunc.all() and np.allclose(obs, first) and "final_observation" in info
+        else:
+            assert not trunc.any()
+    vec.close()
+
+
 def test_errors_are_reported_not_swallowed():
     model, packed, h = make("two_agent.xml", 2)
     with pytest.raises(Exception, match="unknown field"):
