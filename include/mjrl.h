@@ -126,6 +126,14 @@ int mjrl_lds_offset(const mjrl_env* env, const char* region);
 int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
                       unsigned long long* h_cycles, int n);
 
+/* Attach a model-specialised build of the step kernel: a gfx950 code object made from csrc/mjrl_spec_kernel.hip with
+ * the model's sizes as compile-time constants (kernel_cache.py drives hipcc --genco and caches the result next to the
+ * library).  The code object carries the sizes it was built for; a mismatch with this batch's model is an error and
+ * leaves the generic kernel in place.  path == NULL detaches.  The arithmetic is the generic kernel's, operation for
+ * operation, so results are bit-identical; only address computation, loop structure and register use change.
+ * (No counterpart in the reference: MuJoCo's C step is shape-generic; this is the GPU build's stand-in for a JIT.) */
+int mjrl_load_kernel(mjrl_env* env, const char* path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
-    "mjrl_render_device", "mjrl_render_host",
+    "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel",
 ]
 
 _lib = None
@@ -63,6 +63,7 @@ def load():
     L.mjrl_set_query_cache.argtypes = [vp, ci]
     L.mjrl_render_device.argtypes = [vp, ci, ci, vp]
     L.mjrl_render_host.argtypes = [vp, ci, ci, vp]
+    L.mjrl_load_kernel.argtypes = [vp, ctypes.c_char_p]
     _lib = L
     return L
 
@@ -81,13 +82,26 @@ def _host_ptr(arr):
 class Handle:
     """Owns one ``mjrl_env`` (one GPU, n_env copies of one model)."""
 
-    def __init__(self, blob: bytes, n_env: int, device_id: int = 0):
+    def __init__(self, blob: bytes, n_env: int, device_id: int = 0, specialize: bool | None = None):
         self._lib = load()
         self._h = ctypes.c_void_p()
         rc = self._lib.mjrl_create(blob, len(blob), int(n_env), int(device_id), 0, ctypes.byref(self._h))
         if rc:
             raise Exception(f"mjrl_create failed ({rc}): {self._lib.mjrl_last_error(None).decode()}")
         self.n_env = int(n_env)
+        self.kernel = "generic"
+        if specialize is None:
+            specialize = os.environ.get("MJRL_SPECIALIZE", "1") != "0"
+        if specialize:
+            from . import kernel_cache
+            path = kernel_cache.code_object(blob)
+            if path is not None:
+                self.load_kernel(path)
+
+    def load_kernel(self, path: str | None):
+        """Attach a model-specialised step kernel (``kernel_cache.code_object``); ``None`` returns to the generic one."""
+        self._check(self._lib.mjrl_load_kernel(self._h, path.encode() if path else None))
+        self.kernel = "specialised" if path else "generic"
 
     def _check(self, rc):
         if rc:

@@ -91,6 +91,8 @@ struct mjrl_env {
   std::vector<char> h_blob;
   DevModel hm{}, dm{};
   mj::Lay lay{};
+  hipModule_t spec_module = nullptr;     // model-specialised step kernel, if one was attached (mjrl_load_kernel)
+  hipFunction_t spec_fn = nullptr;
   void* d_blob = nullptr;
   DevModel* d_model = nullptr;     // device copy of `dm`
   int n_env = 0, device = 0;
@@ -151,6 +153,7 @@ void mjrl_destroy(mjrl_env* e) {
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_list[0],
                   e->lpt_list[1]};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (e->spec_module) hipModuleUnload(e->spec_module);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -407,27 +410,78 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   }
   a.gather = e->d_gather; a.obs_dim = e->obs_dim; a.obs = d_obs;
   a.reward = d_reward; a.term = d_term; a.trunc = d_trunc;
-  a.max_steps = e->max_steps; a.skip_frames = skip_frames; a.n_env = e->n_env;
-  a.dbg = d_dbg; a.dbg_stage = dbg_stage;
+  a.max_steps = e->max_steps; a.n_env = e->n_env;
+  a.dbg_stage = dbg_stage;
   a.forward_only = forward_only;
   a.stamps = d_stamps;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
   a.agent_body = e->d_agent_body; a.agent_obs_len = e->d_obs_len; a.store = e->store;
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
-  a.frames = e->frames;
   if (e->frames && skip_frames > 0) e->frames_valid = true;
-  if (e->lpt_enabled && !forward_only && !d_dbg) {
-    int in = e->lpt_cur, out = 1 - e->lpt_cur;
-    MJRL_HIP(e, hipMemsetAsync(e->lpt_count[out], 0, sizeof(int) * mj::LPT_BUCKETS, e->stream));
-    if (e->lpt_valid) { a.lpt_count_in = e->lpt_count[in]; a.lpt_list_in = e->lpt_list[in]; }
-    a.lpt_count_out = e->lpt_count[out];
-    a.lpt_list_out = e->lpt_list[out];
-    e->lpt_cur = out;
-    e->lpt_valid = true;
+  size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
+  // The kernel advances one physics frame; a step of skipFrames frames (mujoco_parent.py:333-336) is that many launches
+  // on the stream.  The action scatter belongs to the first, everything after the physics (frame cache, debug dump,
+  // counters, observations, plugin ops) to the last.
+  const int launches = skip_frames > 0 ? skip_frames : 1;
+  for (int f = 0; f < launches; f++) {
+    const bool last = f == launches - 1;
+    a.skip_frames = skip_frames > 0 ? 1 : 0;
+    a.more_frames = last ? 0 : 1;
+    if (f > 0) a.scatter = nullptr;
+    a.dbg = last ? d_dbg : nullptr;
+    a.frames = last ? e->frames : nullptr;
+    a.lpt_count_in = nullptr; a.lpt_list_in = nullptr; a.lpt_count_out = nullptr; a.lpt_list_out = nullptr;
+    if (e->lpt_enabled && !forward_only && !d_dbg) {
+      int in = e->lpt_cur, out = 1 - e->lpt_cur;
+      MJRL_HIP(e, hipMemsetAsync(e->lpt_count[out], 0, sizeof(int) * mj::LPT_BUCKETS, e->stream));
+      if (e->lpt_valid) { a.lpt_count_in = e->lpt_count[in]; a.lpt_list_in = e->lpt_list[in]; }
+      a.lpt_count_out = e->lpt_count[out];
+      a.lpt_list_out = e->lpt_list[out];
+      e->lpt_cur = out;
+      e->lpt_valid = true;
+    }
+    if (e->spec_fn) {
+      const void* image = e->d_blob;        // the specialised kernel derives every section from the image base
+      void* params[] = {(void*)&image, (void*)&a};
+      MJRL_HIP(e, hipModuleLaunchKernel(e->spec_fn, e->n_env, 1, 1, 64, 1, 1, (unsigned)lds_bytes, e->stream, params, nullptr));
+    } else {
+      hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
+      MJRL_HIP(e, hipGetLastError());
+    }
+  }
+  return 0;
+}
+
+int mjrl_load_kernel(mjrl_env* e, const char* path) {
+  if (!e) return 1;
+  MJRL_HIP(e, hipSetDevice(e->device));
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (e->spec_module) { hipModuleUnload(e->spec_module); e->spec_module = nullptr; e->spec_fn = nullptr; }
+  if (!path) return 0;                      // back to the generic kernel
+  hipModule_t mod = nullptr;
+  if (hipModuleLoad(&mod, path) != hipSuccess) MJRL_FAIL(e, 6, "load_kernel: cannot load code object %s", path);
+  hipFunction_t fn = nullptr;
+  hipDeviceptr_t d_sizes = nullptr;
+  size_t nb = 0;
+  if (hipModuleGetFunction(&fn, mod, "mjrl_step_kernel_spec") != hipSuccess ||
+      hipModuleGetGlobal(&d_sizes, &nb, mod, "mjrl_spec_sizes") != hipSuccess || nb != sizeof(int) * MJRL_NSIZES) {
+    hipModuleUnload(mod);
+    MJRL_FAIL(e, 6, "load_kernel: %s does not export mjrl_step_kernel_spec / mjrl_spec_sizes", path);
+  }
+  int built[MJRL_NSIZES];
+  const int32_t* want = (const int32_t*)(e->h_blob.data() + 8);
+  if (hipMemcpy(built, d_sizes, nb, hipMemcpyDeviceToHost) != hipSuccess || memcmp(built, want, nb) != 0) {
+    hipModuleUnload(mod);
+    MJRL_FAIL(e, 6, "load_kernel: %s was built for a different model shape", path);
   }
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
-  hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
-  MJRL_HIP(e, hipGetLastError());
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+    hipModuleUnload(mod);
+    MJRL_FAIL(e, 5, "load_kernel: cannot raise the dynamic LDS limit to %zu bytes", lds_bytes);
+  }
+  e->spec_module = mod;
+  e->spec_fn = fn;
   return 0;
 }
 

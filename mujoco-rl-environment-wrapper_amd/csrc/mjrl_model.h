@@ -10,21 +10,63 @@
 
 #include "mjrl_layout.h"
 
+// Section pointers always hold HBM addresses.  The device pass says so in the type (address space 1): a pointer
+// loaded from the struct would otherwise be generic, and every table read a flat_load that also ties up the LDS
+// counter (lgkmcnt) -- each LDS wait would then drain the table prefetches in flight.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MJRL_GLOBAL __attribute__((address_space(1)))
+#else
+#define MJRL_GLOBAL
+#endif
+
+// A model-specialised build of the step kernel (mjrl_spec_kernel.hip, one code object per model shape) defines
+// MJRL_SPEC and one MJRL_SPEC_<size> per size field: there `m.nv` and friends are compile-time constants, so the LDS
+// layout folds into instruction offsets, level/tree loops unroll and model-shape branches disappear.  The struct
+// keeps the generic layout (the runtime copy of each size stays in place under <name>_rt).
 struct DevModel {
+#ifdef MJRL_SPEC
+#define X(name) int name##_rt; static constexpr int name = MJRL_SPEC_##name;
+#else
 #define X(name) int name;
+#endif
   MJRL_SIZE_FIELDS(X)
 #undef X
 #define X(name) double name;
   MJRL_OPT_FIELDS(X)
 #undef X
-#define X(name, count) const double* name;
+#define X(name, count) const double MJRL_GLOBAL* name;
   MJRL_F64_FIELDS(X)
 #undef X
-#define X(name, count) const int32_t* name;
+#define X(name, count) const int32_t MJRL_GLOBAL* name;
   MJRL_I32_FIELDS(X)
 #undef X
 };
 
+#ifdef MJRL_SPEC
+// The specialised kernel builds its descriptor in registers from the image's base address alone: with the sizes
+// known at compile time every section pointer is base + constant, so no descriptor field is ever loaded (the generic
+// kernel pays a scalar load for the pointer and then the table read that depends on it).
+__device__ __forceinline__ void mjrl_model_from_base(DevModel* m, const char MJRL_GLOBAL* b) {
+  const double MJRL_GLOBAL* op = (const double MJRL_GLOBAL*)(b + 8 + 4 * MJRL_NSIZES);
+  int k = 0;
+#define X(name) m->name = op[k++];
+  MJRL_OPT_FIELDS(X)
+#undef X
+  size_t off = 8 + 4 * MJRL_NSIZES + 8 * MJRL_NOPTS;
+  constexpr int nq = DevModel::nq, nv = DevModel::nv, nu = DevModel::nu, nbody = DevModel::nbody, njnt = DevModel::njnt,
+                ngeom = DevModel::ngeom, nsite = DevModel::nsite, ncam = DevModel::ncam, nsensor = DevModel::nsensor,
+                npair = DevModel::npair, nM = DevModel::nM, ndesc = DevModel::ndesc, nchild = DevModel::nchild,
+                ntree = DevModel::ntree, nfactor = DevModel::nfactor, ntab = DevModel::ntab;
+  (void)nfactor; (void)ntab; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
+  (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
+#define X(name, count) m->name = (const double MJRL_GLOBAL*)(b + off); off += 8 * (size_t)(count);
+  MJRL_F64_FIELDS(X)
+#undef X
+#define X(name, count) m->name = (const int32_t MJRL_GLOBAL*)(b + off); off += 4 * (size_t)(((count) + 1) & ~1);
+  MJRL_I32_FIELDS(X)
+#undef X
+}
+#else
 // Point a DevModel at the sections of a blob held at `base` (host or device address; only the
 // header words are dereferenced, and those come from `host_blob`).  Returns 0 on success.
 static inline int mjrl_model_from_blob(DevModel* m, const void* host_blob, size_t nbytes, const void* base) {
@@ -50,13 +92,14 @@ static inline int mjrl_model_from_blob(DevModel* m, const void* host_blob, size_
       ntree = m->ntree, nfactor = m->nfactor, ntab = m->ntab;
   (void)nfactor; (void)ntab; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
   (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
-#define X(name, count) m->name = (const double*)(b + off); off += 8 * (size_t)(count);
+#define X(name, count) m->name = (const double MJRL_GLOBAL*)(b + off); off += 8 * (size_t)(count);
   MJRL_F64_FIELDS(X)
 #undef X
-#define X(name, count) m->name = (const int32_t*)(b + off); off += 4 * (size_t)(((count) + 1) & ~1);
+#define X(name, count) m->name = (const int32_t MJRL_GLOBAL*)(b + off); off += 4 * (size_t)(((count) + 1) & ~1);
   MJRL_I32_FIELDS(X)
 #undef X
   return off == nbytes ? 0 : 4;
 }
+#endif
 
 #endif

@@ -1,0 +1,22 @@
+// Model-specialised build of the step kernel: the same source as libmjrl_hip.so's generic kernel, compiled with the
+// model's sizes as constants (MJRL_SPEC_HEADER names the generated header of MJRL_SPEC_<size> defines).  Built into
+// a code object per model shape (hipcc --genco) and attached to an env batch with mjrl_load_kernel().
+#include <hip/hip_runtime.h>
+
+#define MJRL_SPEC 1
+#include MJRL_SPEC_HEADER
+#include "mjrl_step.h"
+
+// the sizes this code object was built for, checked against the model by mjrl_load_kernel
+extern "C" __device__ const int mjrl_spec_sizes[MJRL_NSIZES] = {
+#define X(name) MJRL_SPEC_##name,
+    MJRL_SIZE_FIELDS(X)
+#undef X
+};
+
+extern "C" __global__ __launch_bounds__(64) void mjrl_step_kernel_spec(const char* __restrict__ image, mj::StepArgs a) {
+  extern __shared__ double lds[];
+  DevModel m;
+  mjrl_model_from_base(&m, (const char MJRL_GLOBAL*)image);
+  mj::env_step(m, a, lds);
+}

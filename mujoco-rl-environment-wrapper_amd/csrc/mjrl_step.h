@@ -91,7 +91,9 @@ struct StepArgs {
   real* obs;                 // [n_env][n_agent][obs_dim], may be null
   real* reward;              // [n_env][n_agent], may be null
   unsigned char *term, *trunc;   // [n_env][n_agent], may be null
-  int max_steps, skip_frames, n_env;
+  int max_steps, n_env;
+  int skip_frames;           // physics frames in THIS launch: 0 or 1 (the host loops over the step's skipFrames)
+  int more_frames;           // 1: further launches of the same step follow -- no counters, observations or plugin ops yet
   // debug dump of the env's whole LDS image after the forward pass of the last substep
   real* dbg;                 // [n_env][lay.total], may be null
   int dbg_stage;             // 0: end of forward pass; 1: right after the constraint rows are built
@@ -1226,7 +1228,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   stage_constants(m, l, S, L);
   wv::sync();
   // scatter the physical part of every agent's action (mujoco_parent.py:323-332)
-  if (a.actions) {
+  if (a.actions && a.scatter) {
     MJ_FOR(it, a.n_agent * a.act_dim) {
       int idx = a.scatter[it];
       if (idx >= 0) {
@@ -1237,7 +1239,11 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     wv::sync();
   }
   MJ_STAMP(ST_LOAD)
-  for (int frame = 0; frame < a.skip_frames; frame++) {
+  // One physics frame per launch (the host issues skip_frames launches, mjrl_capi.hip launch_step).  A frame loop
+  // in here would make everything a frame computes from the lane id, the lane constants and the model loop-invariant:
+  // hoisted, those hundreds of masks and addresses stay live for the whole kernel and spill (340 VGPRs with AGPR
+  // spill space against 218 without the loop).  Between launches the state round-trips through HBM, 2.5 KB per copy.
+  if (a.skip_frames) {
     stage_kinematics(m, l, K, S, L);
     MJ_STAMP(ST_KIN)
     stage_com_inertia(m, l, K, S, L);
@@ -1257,15 +1263,15 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     // (a raw-row debug dump keeps J unprojected; such a launch is for inspection only)
     stage_rows(m, l, S, L, !(a.dbg && a.dbg_stage == 1), a.stamps, t_prev);
     MJ_STAMP(ST_ROWS)
-    if (a.dbg && a.dbg_stage == 1 && frame == a.skip_frames - 1)
+    if (a.dbg && a.dbg_stage == 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     stage_pgs(m, l, K, RK, S, L, a.stamps, t_prev);
     MJ_STAMP(ST_PGS)
     stage_sensors(m, l, K, S, L);
     MJ_STAMP(ST_SENSORS)
-    if (a.dbg && a.dbg_stage == 0 && frame == a.skip_frames - 1)
+    if (a.dbg && a.dbg_stage == 0)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
-    if (a.frames && frame == a.skip_frames - 1) {
+    if (a.frames) {
       real* F = a.frames + (size_t)env * frame_doubles(m);
       const int* I = (const int*)(S + l.ints);
       MJ_FOR(i, 3 * m.nbody) F[i] = S[l.xpos + i];
@@ -1306,7 +1312,16 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   }
   MJ_STAMP(ST_STORE)
 #undef MJ_STAMP
-  if (a.forward_only) return;
+  if (a.lpt_count_out && L == 0) {
+    const int* I = (const int*)(S + l.ints);
+    unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
+    int b = 0;
+    while (work) { b++; work >>= 1; }
+    if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
+    int pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
+    a.lpt_list_out[(size_t)b * a.n_env + pos] = env;
+  }
+  if (a.forward_only || a.more_frames) return;
   // truncation is evaluated before the counter moves (mujoco_rl.py:279,288)
   int ts = a.timestep[env];
   MJ_FOR(ag, a.n_agent) {
@@ -1359,15 +1374,6 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   }
   wv::sync();
   if (L == 0) a.timestep[env] = ts + 1;
-  if (a.lpt_count_out && L == 0) {
-    const int* I = (const int*)(S + l.ints);
-    unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
-    int b = 0;
-    while (work) { b++; work >>= 1; }
-    if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
-    int pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
-    a.lpt_list_out[(size_t)b * a.n_env + pos] = env;
-  }
 #undef MJ_FOR
 }
 

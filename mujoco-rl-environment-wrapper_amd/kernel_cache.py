@@ -1,0 +1,91 @@
+"""Model-specialised step kernels.
+
+The generic ``mjrl_step_kernel`` in libmjrl_hip.so takes every size of the model at run time, so each wave spends a
+good part of a step on address arithmetic and keeps the LDS layout in (spilled) scalar registers.  For a given model
+shape the same source is rebuilt with the sizes as compile-time constants (``csrc/mjrl_spec_kernel.hip``,
+``hipcc --genco``) and attached with ``mjrl_load_kernel``.  Code objects are cached in-tree under ``csrc/_spec/``,
+keyed by the sizes and a digest of the kernel sources, so a prebuilt cache travels with the tree.
+
+The reference has nothing like this (MuJoCo's C step is shape-generic); it is the stand-in for a tracing compiler.
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import os
+import shutil
+import struct
+import subprocess
+import tempfile
+
+from . import blob as _blob
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+CACHE = os.path.join(CSRC, "_spec")
+SOURCES = ["mjrl_spec_kernel.hip", "mjrl_step.h", "mjrl_collide.h", "mjrl_math.h", "mjrl_wave.h", "mjrl_model.h",
+           "mjrl_layout.h"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-value"]
+
+
+def blob_sizes(blob: bytes) -> dict:
+    n = len(_blob.SIZE_FIELDS)
+    magic, version = struct.unpack_from("<ii", blob, 0)
+    if magic != _blob.MAGIC or version != _blob.VERSION:
+        raise ValueError("not a model blob of this layout version")
+    return dict(zip(_blob.SIZE_FIELDS, struct.unpack_from(f"<{n}i", blob, 8)))
+
+
+def _source_digest() -> str:
+    h = hashlib.sha1()
+    for name in SOURCES:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:12]
+
+
+def spec_header(sizes: dict) -> str:
+    return "".join(f"#define MJRL_SPEC_{k} {int(sizes[k])}\n" for k in _blob.SIZE_FIELDS)
+
+
+def object_path(sizes: dict) -> str:
+    key = hashlib.sha1(spec_header(sizes).encode()).hexdigest()[:16]
+    return os.path.join(CACHE, f"step_{key}_{_source_digest()}.hsaco")
+
+
+def hipcc() -> str | None:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def code_object(blob: bytes, build: bool = True) -> str | None:
+    """Path of the code object for this blob's shape; built on a cache miss when hipcc is present, else None."""
+    sizes = blob_sizes(blob)
+    path = object_path(sizes)
+    if os.path.exists(path):
+        return path
+    cc = hipcc()
+    if not build or cc is None:
+        return None
+    os.makedirs(CACHE, exist_ok=True)
+    with tempfile.TemporaryDirectory(dir=CACHE) as tmp:
+        hdr = os.path.join(tmp, "spec.h")
+        with open(hdr, "w") as f:
+            f.write(spec_header(sizes))
+        out = os.path.join(tmp, "step.hsaco")
+        cmd = [cc, "--genco", *FLAGS, f'-DMJRL_SPEC_HEADER="{hdr}"', "-I", CSRC,
+               os.path.join(CSRC, "mjrl_spec_kernel.hip"), "-o", out]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"specialised kernel build failed:\n{' '.join(cmd)}\n{res.stderr[-4000:]}")
+        os.replace(out, path)     # atomic: concurrent ranks race benignly
+    shape = os.path.basename(path).rsplit("_", 1)[0]
+    for stale in glob.glob(os.path.join(CACHE, shape + "_*.hsaco")):     # same shape, older kernel sources
+        if stale != path:
+            try:
+                os.remove(stale)
+            except OSError:
+                pass
+    return path

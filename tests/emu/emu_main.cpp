@@ -116,11 +116,21 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.reward = reward; a.term = term; a.trunc = trunc;
   a.prog_i = prog_i; a.prog_f = prog_f; a.n_op = forward_only ? 0 : n_op; a.n_slot = n_slot;
   a.agent_body = agent_body; a.agent_obs_len = agent_obs_len; a.store = store;
-  a.max_steps = max_steps; a.skip_frames = skip_frames; a.n_env = 1;
+  a.max_steps = max_steps; a.n_env = 1;
   a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;
   emu::cur_env = 0;
-  for (int s = 0; s < nsteps; s++)
-    if (emu::run_wave(m, a, lds.data())) return 2;
+  // one frame per wave run, like the launches of launch_step in mjrl_capi.hip
+  for (int s = 0; s < nsteps; s++) {
+    int launches = skip_frames > 0 ? skip_frames : 1;
+    for (int f = 0; f < launches; f++) {
+      mj::StepArgs b = a;
+      b.skip_frames = skip_frames > 0 ? 1 : 0;
+      b.more_frames = f < launches - 1;
+      if (f > 0) b.scatter = nullptr;
+      if (b.more_frames) { b.dbg = nullptr; b.frames = nullptr; }
+      if (emu::run_wave(m, b, lds.data())) return 2;
+    }
+  }
   return 0;
 }
 }

@@ -343,3 +343,31 @@ def test_errors_are_reported_not_swallowed():
 def test_smoke_entry():
     import __graft_entry__ as entry
     entry.smoke()
+
+
+def test_specialised_kernel_is_bit_identical_to_the_generic_one():
+    """The per-model-shape build of the step kernel (kernel_cache / mjrl_load_kernel) is the same arithmetic."""
+    from mjrl_amd import kernel_cache
+    n_env = 16
+    model = mjcf.compile_mjcf(levels.level_path("two_agent_3sensors.xml"))
+    packed = blob.pack(model)
+    spec, gen = _capi.Handle(packed, n_env, specialize=True), _capi.Handle(packed, n_env, specialize=False)
+    assert spec.kernel == "specialised" and gen.kernel == "generic"
+    spec.reset(); gen.reset()
+    rng = np.random.default_rng(11)
+    for t in range(240):
+        ctrl = rng.uniform(-1, 1, (n_env, model.nu))
+        frames = 3 if t % 40 == 7 else 1           # a multi-frame step is several launches of the one-frame kernel
+        for h in (spec, gen):
+            h.set_field("ctrl", ctrl)
+            h.step_host(None, frames)
+    # (a query without the frame cache is a forward pass, which refreshes the warm start: ask both batches)
+    assert spec.query("ncon").max() > 0 and gen.query("ncon").max() > 0
+    for field in ("qpos", "qvel", "qacc_warmstart", "sensordata", "timestep"):
+        assert np.array_equal(spec.get_field(field), gen.get_field(field)), field
+    # a code object built for another shape is refused and the generic kernel stays in place
+    other = kernel_cache.code_object(blob.pack(mjcf.compile_mjcf(levels.level_path("single_agent.xml"))))
+    with pytest.raises(Exception, match="different model shape"):
+        gen.load_kernel(other)
+    assert gen.kernel == "generic"
+    gen.step_host(None, 1)
