@@ -18,7 +18,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 10
+VERSION = 11
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
@@ -63,7 +63,7 @@ I32_FIELDS = [
     ("body_subtreenum", "nbody"), ("tree_dofadr", "ntree"), ("tree_dofnum", "ntree"),
     ("desc_row", "ndesc"), ("M_coldiag", "nM"), ("dof_actid", "nv"),
     ("factor_sched", "nfactor"), ("row_dof", "64"), ("solve_b", "1024"), ("solve_f", "1024"), ("dof_lane", "nv"),
-    ("lds_tab", "ntab"), ("pair_word", "npair"), ("pair_reach", "npair"),
+    ("lds_tab", "ntab"), ("pair_word", "npair"), ("pair_reach", "npair"), ("dof_descmask", "nv*2"),
 ]
 
 

@@ -141,7 +141,7 @@ struct mjrl_env {
 
 extern "C" {
 
-const char* mjrl_version(void) { return "mjrl-hip 0.3 (blob layout 10, gfx950)"; }
+const char* mjrl_version(void) { return "mjrl-hip 0.4 (blob layout 11, gfx950)"; }
 
 const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 
@@ -177,6 +177,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     return fail(3, "mjrl_create: the model must fit one wavefront (1 <= nv <= 64; nbody, njnt, ngeom <= 64)");
   if (m.maxdofdepth + 1 > mj::MAX_DOF_DEPTH) return fail(3, "mjrl_create: kinematic chains deeper than 8 dofs are not supported");
   if (m.nconmax > 64 || m.nconmax < 1) return fail(3, "mjrl_create: nconmax must be in 1..64");
+  if (m.njmax > 511 || m.njmax < 1) return fail(3, "mjrl_create: njmax must be in 1..511");
   if (m.pair_kmax != 1 && m.pair_kmax != 2 && m.pair_kmax != 4 && m.pair_kmax != 8) return fail(3, "mjrl_create: bad pair_kmax");
   if (m.integrator != 0) return fail(3, "mjrl_create: only the Euler integrator is implemented");
   mj::make_layout(m, e->lay);
@@ -370,7 +371,7 @@ int mjrl_lds_offset(const mjrl_env* e, const char* region) {
 #define R(name) if (!strcmp(region, #name)) return l.name;
   R(qpos) R(qvel) R(ctrl) R(warm) R(xpos) R(xquat) R(xanchor) R(xaxis) R(com) R(cinert) R(crb) R(cdof) R(cdofdot)
   R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gquat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
-  R(sens) R(ints) R(total) R(i_item) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid)
+  R(sens) R(ints) R(total) R(i_item) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid) R(i_rowinfo)
 #undef R
   return -1;
 }

@@ -31,6 +31,16 @@ enum { ROW_R = 0, ROW_B = 1, ROW_F = 2, ROW_ARII = 3, ROW_ARINV = 4, ROW_STRIDE 
 // integer header of the int region
 enum { I_NCON = 0, I_NEFC = 1, I_NLIM = 2, I_NITER = 3, I_WARN = 4, I_NITEM = 5, I_HEAD = 8 };
 enum { MAX_DOF_DEPTH = 8 };
+// A constraint row is stored in JW doubles, in one of two forms.
+// Tree-local (models in the tree-row lane map, rows inside one kinematic tree -- all rows of the solver's parallel
+// path): slot i is the tree's i-th dof, i.e. the slot a lane reads is its position in its row of 16 lanes.
+// Compact (rows that couple two trees; every row of a model outside the lane map): a row touches the dofs of at most
+// two ancestor chains (the bodies of a contact), at most MAX_DOF_DEPTH dofs each; slots 0..7 follow the primary chain
+// from its deepest dof up to the tree root, slots 8..15 the secondary chain where it is not also the primary one.
+// The row's chain code says which dofs those are: bits 0-5 deepest dof of the primary chain, 6-8 its depth, 9-15 one
+// plus the deepest dof of the secondary chain (0: none), 16-18 its depth.
+// Bits 19-22 of a row's info word hold the kinematic tree of the row plus 2 (0: the row couples two trees).
+enum { JW = 2 * MAX_DOF_DEPTH, CHAIN_BITS = 19 };
 
 // LDS layout of one env copy, offsets in doubles from the env's base.  The block `u` is shared by two
 // lifetimes: {xanchor, xaxis, cinert, crb} live from the kinematics to the end of the bias forces,
@@ -40,8 +50,8 @@ struct Lay {
       x, qfc, qacc, con, sens, gsize, tab, ints, u, total;
   int xanchor, xaxis, cinert, crb;   // inside u, first lifetime
   int J, row;                        // inside u, second lifetime
-  int ldj;                           // row stride of J (odd -> conflict-free column walks)
-  int i_item, i_cong1, i_cong2, i_conadr, i_rowid, i_rowtree;   // offsets inside the int region (in ints)
+  int ldj;                           // row stride of J (= JW, the compact row width)
+  int i_item, i_cong1, i_cong2, i_conadr, i_rowid, i_rowinfo;   // offsets inside the int region (in ints)
 };
 
 __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
@@ -62,13 +72,13 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   l.i_cong2 = ni; ni += m.nconmax;
   l.i_conadr = ni; ni += m.nconmax;
   l.i_rowid = ni; ni += m.njmax;
-  l.i_rowtree = ni; ni += m.njmax;
+  l.i_rowinfo = ni; ni += m.njmax;
   REG(ints, (ni + 1) / 2)
   l.u = o;
   l.xanchor = o; l.xaxis = l.xanchor + 3 * m.njnt; l.cinert = l.xaxis + 3 * m.njnt; l.crb = l.cinert + 10 * m.nbody;
   int first = 6 * m.njnt + 20 * m.nbody;
   if (!m.has_accel) { l.cdofdot = o + first; l.cacc = l.cdofdot + 6 * m.nv; first += 6 * m.nv + 6 * m.nbody; }
-  l.ldj = (m.nv | 1);
+  l.ldj = JW;
   l.J = o; l.row = l.J + l.ldj * m.njmax;
   int second = l.ldj * m.njmax + ROW_STRIDE * m.njmax;
   o += first > second ? first : second;
@@ -199,11 +209,24 @@ __device__ __forceinline__ float int_as_float(int v) {
 // the factor entries it multiplies in each step of the register-resident triangular solves.
 struct RowK {
   int dof;
+  int depth;                    // of the lane's dof
+  unsigned long long below;     // the dof itself and every dof below it, one bit per dof
   int eb[16], ef[16];
 };
 
+// slot of the lane's dof in a compact constraint row with chain code `chain`, -1 if the row does not touch the dof
+__device__ __forceinline__ int row_slot(int chain, unsigned long long below, int depth) {
+  int xp = chain & 63, dp = (chain >> 6) & 7, xq1 = (chain >> 9) & 127, dq = (chain >> 16) & 7;
+  bool in_p = (below >> xp) & 1ull;
+  bool in_q = xq1 != 0 && ((below >> ((xq1 - 1) & 63)) & 1ull);
+  return in_p ? dp - depth : (in_q ? MAX_DOF_DEPTH + dq - depth : -1);
+}
+
 __device__ inline void load_row_constants(const DevModel& m, int L, RowK& r) {
   r.dof = m.rowmap ? m.row_dof[L] : (L < m.nv ? L : -1);
+  int d = r.dof >= 0 ? r.dof : 0;
+  r.depth = m.dof_depth[d];
+  r.below = r.dof >= 0 ? ((unsigned long long)(unsigned)m.dof_descmask[2 * d + 1] << 32) | (unsigned)m.dof_descmask[2 * d] : 0ull;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     r.eb[k] = m.rowmap ? m.solve_b[k * 64 + L] : -1;
@@ -740,9 +763,8 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
 #undef MJ_SUBSTAMP
   int nefc = I[I_NEFC];
   for (int r = L; r < nefc; r += 64) {
-    real* Jr = S + l.J + l.ldj * r;
+    real* Jr = S + l.J + JW * r;
     real* R = S + l.row + ROW_STRIDE * r;
-    for (int k = 0; k < m.nv; k++) Jr[k] = 0;
     int id = I[l.i_rowid + r], rtree = -1;
     real pos, margin, diag, mu0 = 0;
     const real *solref, *solimp;
@@ -753,13 +775,23 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     real lim_val = 0, c_mu = 0, c_sgn = 0;
     int c_dim = 0;
     V3 c_n = v3(0, 0, 0), c_tk = v3(0, 0, 0), c_off1 = v3(0, 0, 0), c_off2 = v3(0, 0, 0);
+    bool local = false;       // tree-local form (see JW)
+    int adr0 = 0;             // first dof of the row's tree: the root of any of its chains
+    // slot of dof i in a two-chain row.  Compact form: on chain 2 (primary) its position from the deepest dof, else
+    // 8 + the position on chain 1
+    auto slot = [&](int i) {
+      if (local) return i - adr0;
+      int dp = T.ddepth(i), t2 = n2 - 1 - dp;
+      return (t2 >= 0 && T.colid(a2 + t2) == i) ? t2 : MAX_DOF_DEPTH + (n1 - 1 - dp);
+    };
     if (!contact) {
       int it = -id - 1, j = it >> 1, side = (it & 1) ? 1 : -1;
       int dof = m.jnt_dofadr[j];
-      Jr[dof] = -side;
       lim_val = -side;
       rtree = T.dof_tree(dof);
       a2 = T.madr(dof); n2 = T.ddepth(dof) + 1;
+      local = m.rowmap != 0;
+      adr0 = T.colid(a2 + n2 - 1);
       pos = R[ROW_F];
       margin = m.jnt_margin[j];
       diag = m.dof_invweight0[dof];
@@ -785,6 +817,9 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       if (l1 >= 0) { a1 = T.madr(l1); n1 = T.ddepth(l1) + 1; }
       if (l2 >= 0) { a2 = T.madr(l2); n2 = T.ddepth(l2) + 1; }
       c_n = n; c_tk = tk; c_mu = mu; c_sgn = sgn; c_dim = dim; c_off1 = off1; c_off2 = off2;
+      local = m.rowmap != 0 && rtree >= 0;
+      if (n2 > 0) adr0 = T.colid(a2 + n2 - 1); else if (n1 > 0) adr0 = T.colid(a1 + n1 - 1);
+      if (local) for (int k = 0; k < JW; k++) Jr[k] = 0;
       int p1 = 0, p2 = 0;
       // rows between two moving bodies walk the merged chains through LDS; one-chain rows are built in registers below
       int i1 = (n1 > 0 && n2 > 0) ? T.colid(a1) : -1, i2 = (n1 > 0 && n2 > 0) ? T.colid(a2) : -1;
@@ -795,7 +830,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
         if (i2 == i) { colv = cl + cross(ca, off2); p2++; i2 = p2 < n2 ? T.colid(a2 + p2) : -1; }
         if (i1 == i) { colv = colv - (cl + cross(ca, off1)); p1++; i1 = p1 < n1 ? T.colid(a1 + p1) : -1; }
         real jn = dot(n, colv);
-        Jr[i] = dim == 1 ? jn : jn + sgn * mu * dot(tk, colv);
+        Jr[slot(i)] = dim == 1 ? jn : jn + sgn * mu * dot(tk, colv);
       }
       pos = C[CON_DIST];
       margin = C[CON_INCL];
@@ -816,6 +851,15 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     // position along the chain (t = 0 deepest dof ... nc-1 tree root); all loops are unrolled to the chain-depth cap.
     const bool single = (n1 == 0 || n2 == 0);
     const int ac = n2 ? a2 : a1, nc = n2 ? n2 : n1;
+    // the row's info word: chain code | (tree + 2) << CHAIN_BITS
+    {
+      int xp = nc ? T.colid(ac) : 0, dp = nc ? nc - 1 : 0;
+      int chain = xp | (dp << 6);
+      if (!single) chain |= ((T.colid(a1) + 1) << 9) | ((n1 - 1) << 16);
+      I[l.i_rowinfo + r] = chain | ((rtree + 2) << CHAIN_BITS);
+      if (nc == 0) Jr[0] = 0;      // (a row between two fixed bodies touches no dof)
+      if (local && id < 0) for (int k = 0; k < JW; k++) Jr[k] = 0;     // (contact rows were cleared above)
+    }
     real Bv[MAX_DOF_DEPTH];
     int cd[MAX_DOF_DEPTH];
     real vel = 0, ja = 0, jw = 0;
@@ -852,7 +896,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
         int i = i1 < i2 ? i1 : i2;
         if (i1 == i) { p1--; i1 = p1 >= 0 ? T.colid(a1 + p1) : 1 << 20; }
         if (i2 == i) { p2--; i2 = p2 >= 0 ? T.colid(a2 + p2) : 1 << 20; }
-        real jk = Jr[i];
+        real jk = Jr[slot(i)];
         vel += jk * S[l.qvel + i];
         ja += jk * S[l.qaccs + i];
         jw += jk * S[l.warm + i];
@@ -871,11 +915,10 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     R[ROW_R] = Rr;
     R[ROW_B] = ja - aref;
     R[ROW_F] = jar < 0 ? -Dr * jar : 0.0;
-    I[l.i_rowtree + r] = rtree;
     if (!project) {
-      if (single && id >= 0) {
+      if (single) {
 #pragma unroll
-        for (int t = 0; t < MAX_DOF_DEPTH; t++) if (t < nc) Jr[cd[t]] = Bv[t];
+        for (int t = 0; t < MAX_DOF_DEPTH; t++) if (t < nc) Jr[local ? cd[t] - adr0 : t] = Bv[t];
       }
       continue;
     }
@@ -896,7 +939,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
         }
       }
 #pragma unroll
-      for (int t = 0; t < MAX_DOF_DEPTH; t++) if (t < nc) Jr[cd[t]] = Bv[t];
+      for (int t = 0; t < MAX_DOF_DEPTH; t++) if (t < nc) Jr[local ? cd[t] - adr0 : t] = Bv[t];
     } else {
       int p1 = 0, p2 = 0;
       int i1 = n1 > 0 ? T.colid(a1) : -1, i2 = n2 > 0 ? T.colid(a2) : -1;
@@ -904,11 +947,11 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
         int k = i1 > i2 ? i1 : i2;
         if (i1 == k) { p1++; i1 = p1 < n1 ? T.colid(a1 + p1) : -1; }
         if (i2 == k) { p2++; i2 = p2 < n2 ? T.colid(a2 + p2) : -1; }
-        real v = Jr[k];
+        real v = Jr[slot(k)];
         acc += v * v * S[l.Dinv + k];
         if (v != 0.0) {
           int adr = T.madr(k), depth = T.ddepth(k);
-          for (int t = 1; t <= depth; t++) Jr[T.colid(adr + t)] -= v * S[l.LD + adr + t];
+          for (int t = 1; t <= depth; t++) Jr[slot(T.colid(adr + t))] -= v * S[l.LD + adr + t];
         }
       }
     }
@@ -936,6 +979,12 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   int nefc = I[I_NEFC];
   const int mydof = RK.dof;
   const bool dof = mydof >= 0;
+  // the lane's coefficient in row r with info word `info` (0 where the row does not touch the lane's dof)
+  auto coef = [&](int r, int info) -> real {
+    int rt = (info >> CHAIN_BITS) - 2;
+    int sl = (m.rowmap && rt >= 0) ? (rt == (L >> 4) ? (L & 15) : -1) : row_slot(info, RK.below, RK.depth);
+    return (dof && sl >= 0) ? S[l.J + JW * r + sl] : 0.0;
+  };
   real dinv = dof ? S[l.Dinv + mydof] : 0.0;
   real u = 0;
   if (nefc == 0) {
@@ -946,7 +995,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   }
   // warm start: keep the forces implied by last step's acceleration only if they beat f = 0
   if (dof)
-    for (int r = 0; r < nefc; r++) u += S[l.J + l.ldj * r + mydof] * S[l.row + ROW_STRIDE * r + ROW_F];
+    for (int r = 0; r < nefc; r++) u += coef(r, I[l.i_rowinfo + r]) * S[l.row + ROW_STRIDE * r + ROW_F];
   real part = 0.5 * dinv * u * u;
   for (int r = L; r < nefc; r += 64) {
     const real* R = S + l.row + ROW_STRIDE * r;
@@ -968,7 +1017,8 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       int cnt = 0;
       for (int base = 0; base < nefc; base += 64) {
         int r = base + L;
-        int rt = r < nefc ? I[l.i_rowtree + r] : -1;
+        int info = r < nefc ? I[l.i_rowinfo + r] : (1 << CHAIN_BITS);
+        int rt = (info >> CHAIN_BITS) - 2;
         unsigned long long mask = wv::ballot(rt == t);
         if (rt == t) I[l.i_item + total + cnt + wv::popc(mask & ((1ull << L) - 1ull))] = r;
         cnt += wv::popc(mask);
@@ -994,7 +1044,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       r.has = sidx < cnt_my;
       r.i = r.has ? I[l.i_item + base_my + sidx] : 0;
       const real* R = S + l.row + ROW_STRIDE * r.i;
-      r.bid = (dof && r.has) ? S[l.J + l.ldj * r.i + mydof] : 0.0;
+      r.bid = (dof && r.has) ? S[l.J + JW * r.i + (L & 15)] : 0.0;      // tree-local rows: the lane's own slot
       r.fi = R[ROW_F]; r.Ri = R[ROW_R]; r.bi = R[ROW_B]; r.aii = R[ROW_ARII]; r.ainv = R[ROW_ARINV];
       return r;
     };
@@ -1026,7 +1076,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       real improvement = 0;
       for (int i = 0; i < nefc; i++) {
         const real* R = S + l.row + ROW_STRIDE * i;
-        real bid = dof ? S[l.J + l.ldj * i + mydof] : 0.0;
+        real bid = coef(i, I[l.i_rowinfo + i]);
         real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = R[ROW_ARINV];
         // reduce over the lanes that hold dofs, then hand lane 0's sum to the whole wave
         real res = wv::first(wv::sum_n(bid * dinv * u, width)) + Ri * fi + bi;

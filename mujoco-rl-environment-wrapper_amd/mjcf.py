@@ -360,13 +360,15 @@ SUPPORTED_PAIRS = {
 }
 
 
-def compile_mjcf(xml_path: str, nconmax: int | None = None, njmax: int | None = None) -> Model:
+def compile_mjcf(xml_path: str, nconmax: int | None = None, njmax: int | None = None, lane_map: bool = True) -> Model:
     with open(xml_path, "r") as fh:
         text = fh.read()
-    return compile_mjcf_string(text, xml_path=xml_path, nconmax=nconmax, njmax=njmax)
+    return compile_mjcf_string(text, xml_path=xml_path, nconmax=nconmax, njmax=njmax, lane_map=lane_map)
 
 
-def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None) -> Model:
+def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None, lane_map: bool = True) -> Model:
+    """``lane_map=False`` withholds the tree-row lane map even from a model that qualifies for it (a model with more
+    than four trees or more than 16 dofs in a tree never gets it): the kernels then take their general paths."""
     c = _Compiler(text)
     c.walk()
     m = Model(xml_path=xml_path)
@@ -495,6 +497,16 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
     A["dof_descnum"] = np.array([len(x) for x in desc], np.int32)
     A["desc_Madr"] = np.array([a for x in desc for a in x], np.int32)
     A["desc_row"] = M_rowid[A["desc_Madr"]] if A["desc_Madr"].size else np.zeros(0, np.int32)
+    # 64-bit set per dof: the dof itself and every dof below it (low word, high word); dof a lies on the ancestor
+    # chain of dof x exactly when bit x of a's set is on -- the test the compact constraint rows are read with
+    mask = np.zeros(nv, np.uint64)
+    for d in range(nv):
+        k = d
+        while k >= 0:
+            mask[k] |= np.uint64(1) << np.uint64(d)
+            k = dof_parentid[k]
+    A["dof_descmask"] = np.stack([(mask & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+                                  (mask >> np.uint64(32)).astype(np.uint32)], axis=1).reshape(-1).view(np.int32)
     A["M_coldiag"] = dof_Madr[M_colid] if nM else np.zeros(0, np.int32)   # address of the diagonal of each entry's column
     m.ndesc = int(A["desc_Madr"].size)
     m.maxdofdepth = int(dof_depth.max()) if nv else 0
@@ -676,11 +688,11 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None)
     m.njmax = int(njmax) if njmax is not None else n_limited + 4 * m.nconmax
 
     _set_const(m)
-    _kernel_schedules(m)
+    _kernel_schedules(m, lane_map)
     return m
 
 
-def _kernel_schedules(m: Model):
+def _kernel_schedules(m: Model, lane_map: bool = True):
     """Lane schedules the step kernel replays instead of decoding the tree structure on the fly.
 
     * ``factor_sched[pass][kk][lane]``: the L'DL elimination eliminates the kk-th dof of up to two trees per pass
@@ -724,7 +736,7 @@ def _kernel_schedules(m: Model):
     A["factor_sched"] = sched.astype(np.uint32).view(np.int32).reshape(-1)
     m.nfactor = int(A["factor_sched"].size)
 
-    rowmap = int(ntree >= 1 and ntree <= 4 and m.maxtreedof <= 16)
+    rowmap = int(lane_map and ntree >= 1 and ntree <= 4 and m.maxtreedof <= 16)
     m.rowmap = rowmap
     row_dof = np.full(64, -1, np.int32)
     solve_b = np.full((16, 64), -1, np.int32)

@@ -63,9 +63,31 @@ class LdsImage:
     def warn(self): return int(self.ints[4])
 
     def J(self):
-        ldj = self._off("ldj") if self._off("ldj") > 0 else (self.model.nv | 1)
-        o = self._off("J")
-        return self.image[o:o + ldj * self.model.njmax].reshape(self.model.njmax, ldj)[:, :self.model.nv]
+        """The constraint rows expanded from their stored forms (mjrl_step.h, JW: tree-local or compact chains)."""
+        m = self.model
+        ldj, o, info_at = self._off("ldj"), self._off("J"), self._off("i_rowinfo")
+        rows = self.image[o:o + ldj * m.njmax].reshape(m.njmax, ldj)
+        parent = m.dof_parentid
+        dense = np.zeros((m.njmax, m.nv))
+        for r in range(self.nefc):
+            info = int(self.ints[info_at + r])
+            tree = (info >> 19) - 2
+            if m.rowmap and tree >= 0:          # slot i = the tree's i-th dof
+                a, n = int(m.tree_dofadr[tree]), int(m.tree_dofnum[tree])
+                dense[r, a:a + n] = rows[r, :n]
+                continue
+            xp, xq1 = info & 63, (info >> 9) & 127
+            seen = set()
+            d, t = xp, 0
+            while d >= 0:                       # primary chain: slots 0.. from the deepest dof up
+                dense[r, d] = rows[r, t]; seen.add(d)
+                d, t = int(parent[d]), t + 1
+            d, t = xq1 - 1, 0
+            while xq1 and d >= 0:               # secondary chain: slots 8.., shared ancestors live on the primary one
+                if d not in seen:
+                    dense[r, d] = rows[r, 8 + t]
+                d, t = int(parent[d]), t + 1
+        return dense
 
     def contact_geoms(self):
         a, b = self._off("i_cong1"), self._off("i_cong2")

@@ -92,7 +92,7 @@ int emu_lds_offset(const void* blob, size_t nbytes, const char* region) {
 #define R(name) if (!strcmp(region, #name)) return l.name;
   R(qpos) R(qvel) R(ctrl) R(warm) R(xpos) R(xquat) R(xanchor) R(xaxis) R(com) R(cinert) R(crb) R(cdof) R(cdofdot)
   R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gquat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
-  R(sens) R(ints) R(total) R(ldj) R(i_item) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid)
+  R(sens) R(ints) R(total) R(ldj) R(i_item) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid) R(i_rowinfo)
 #undef R
   return -1;
 }

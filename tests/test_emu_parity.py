@@ -209,3 +209,86 @@ def test_fused_plugin_ops_follow_the_reference_loop_order():
         assert list(program["term"].astype(bool)) == dones
         assert program["trunc"].all() == (step >= 20)
     assert any(dones) and not all(dones)      # the threshold separates the two agents
+
+
+def _rows_couple_two_chains(model, ora):
+    """(rows between two trees, rows between two moving bodies of one tree) among the oracle's current contacts"""
+    tree, gbody = model.body_treeid, model.geom_bodyid
+    cross = same = 0
+    for c in ora.contacts():
+        t1, t2 = int(tree[gbody[c["geom1"]]]), int(tree[gbody[c["geom2"]]])
+        if t1 >= 0 and t2 >= 0:
+            cross += t1 != t2
+            same += t1 == t2
+    return cross, same
+
+
+def test_rows_between_two_moving_bodies():
+    """Contacts whose two bodies both carry dofs build their rows from two ancestor chains: agent against agent
+    (two kinematic trees, the solver's serial fallback) and leg against leg of one agent (chains that share the
+    torso dofs).  Both states are posed by hand: random play rarely produces them."""
+    model, ora, emu = pair("two_agent.xml")
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == 0]
+    assert len(free) == 2
+    a0, a1 = (int(model.jnt_qposadr[j]) for j in free)
+    # agent 1 dropped onto agent 0
+    q = model.qpos0.copy()
+    q[a1:a1 + 3] = q[a0:a0 + 3] + np.array([0.15, 0.1, 0.55])
+    ora.qpos[:] = q; emu.qpos[:] = q
+    seen_cross = 0
+    for k in range(60):
+        img = emu.step(); ora.step()
+        cross, _ = _rows_couple_two_chains(model, ora)
+        seen_cross += cross
+        assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter), k
+    assert seen_cross > 0
+    assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
+    # legs of one agent folded into each other (hinge angles outside their ranges: the limit rows push back)
+    model, ora, emu = pair("two_agent.xml")
+    rng = np.random.default_rng(3)
+    hinge_q = [int(model.jnt_qposadr[j]) for j in range(model.njnt) if model.jnt_type[j] == 3]
+    found = None
+    for trial in range(200):
+        q = model.qpos0.copy()
+        q[hinge_q] = rng.uniform(-2.5, 2.5, len(hinge_q))
+        q[a0 + 2] += 1.0; q[a1 + 2] += 1.0          # in the air: only self-contacts
+        ora.qpos[:] = q; ora.qvel[:] = 0
+        ora.forward()
+        if _rows_couple_two_chains(model, ora)[1] > 0:
+            found = q
+            break
+    assert found is not None
+    ora.qpos[:] = found; emu.qpos[:] = found
+    img = emu.step(dbg_stage=1); ora.step()
+    n = ora.nefc
+    assert img.nefc == n and np.allclose(img.J()[:n], ora.efc_J[:n], atol=1e-12)      # raw two-chain rows
+    model, ora, emu = pair("two_agent.xml")
+    ora.qpos[:] = found; emu.qpos[:] = found
+    seen_same = 0
+    for k in range(40):
+        img = emu.step(); ora.step()
+        seen_same += _rows_couple_two_chains(model, ora)[1]
+        assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter), k
+    assert seen_same > 0
+    assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
+
+
+def test_general_paths_without_the_lane_map():
+    """A model outside the tree-row lane map (more than four trees, or a tree with more than 16 dofs) stores every
+    constraint row in the compact chain form, solves with the level-parallel LDS routines and sweeps the rows
+    serially.  The lane map is withheld from the two-agent level to run exactly those paths."""
+    model, ora, emu = pair("two_agent.xml", lane_map=False)
+    assert model.rowmap == 0
+    rng = np.random.default_rng(21)
+    for k in range(260):
+        ctrl = rng.uniform(-1, 1, model.nu)
+        ora.ctrl[:] = ctrl; emu.ctrl[:] = ctrl
+        img = emu.step(); ora.step()
+        assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter), k
+    assert ora.ncon > 0
+    assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
+    ctrl = rng.uniform(-1, 1, model.nu)
+    ora.ctrl[:] = ctrl; emu.ctrl[:] = ctrl
+    img = emu.step(dbg_stage=1); ora.step()
+    n = ora.nefc
+    assert n >= 4 and np.allclose(img.J()[:n], ora.efc_J[:n], atol=1e-12)
