@@ -25,9 +25,9 @@ enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
 enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_RANGEFINDER = 2, SENS_FRAMEXAXIS = 3 };
 
 // per-contact record in LDS (doubles)
-enum { CON_DIST = 0, CON_POS = 1, CON_FRAME = 4, CON_INCL = 13, CON_MU = 14, CON_STRIDE = 16 };
+enum { CON_DIST = 0, CON_POS = 1, CON_FRAME = 4, CON_INCL = 13, CON_MU = 14, CON_STRIDE = 15 };
 // per-row record in LDS (doubles); ROW_F doubles as the constraint position until the row is built
-enum { ROW_R = 0, ROW_B = 1, ROW_F = 2, ROW_ARII = 3, ROW_ARINV = 4, ROW_STRIDE = 5 };
+enum { ROW_R = 0, ROW_B = 1, ROW_F = 2, ROW_ARII = 3, ROW_STRIDE = 4 };
 // integer header of the int region
 enum { I_NCON = 0, I_NEFC = 1, I_NLIM = 2, I_NITER = 3, I_WARN = 4, I_NITEM = 5, I_HEAD = 8 };
 enum { MAX_DOF_DEPTH = 8 };
@@ -42,16 +42,22 @@ enum { MAX_DOF_DEPTH = 8 };
 // Bits 19-22 of a row's info word hold the kinematic tree of the row plus 2 (0: the row couples two trees).
 enum { JW = 2 * MAX_DOF_DEPTH, CHAIN_BITS = 19 };
 
-// LDS layout of one env copy, offsets in doubles from the env's base.  The block `u` is shared by two
-// lifetimes: {xanchor, xaxis, cinert, crb} live from the kinematics to the end of the bias forces,
-// {J, row} from the constraint-row build to the sensors.
+// LDS layout of one env copy, offsets in doubles from the env's base.  Its size decides how many copies a CU holds
+// at once (160 KiB / size) and with that how much of the step's latency is hidden, so everything with a short life
+// shares storage.  The block `u` serves two lifetimes: {cinert + a scratch area} from the kinematics to the end of
+// the bias forces, {J, row} from the constraint-row build to the sensors.  The scratch area in turn holds, one after
+// the other: {xanchor, xaxis} (kinematics .. joint axes), {crb} (composite inertias), {gsize, work items} (geoms ..
+// collision) and {body forces in the crb slots, cvel, cdofdot, cacc} (velocity stage .. bias forces; a model with an
+// accelerometer re-reads the last three after the solve and keeps them outside `u`).
 struct Lay {
   int qpos, qvel, ctrl, warm, xpos, xquat, com, cdof, cdofdot, cvel, cacc, M, LD, Dinv, gpos, gquat, bias, smooth, qaccs,
       x, qfc, qacc, con, sens, gsize, tab, ints, u, total;
   int xanchor, xaxis, cinert, crb;   // inside u, first lifetime
   int J, row;                        // inside u, second lifetime
   int ldj;                           // row stride of J (= JW, the compact row width)
-  int i_item, i_cong1, i_cong2, i_conadr, i_rowid, i_rowinfo;   // offsets inside the int region (in ints)
+  // offsets from the int region's base, in ints.  i_item (collision work items) points into the scratch area of `u`;
+  // i_rowid holds the row ids during the row build and the solver's per-tree row lists afterwards
+  int i_item, i_cong1, i_cong2, i_conadr, i_rowid, i_rowinfo;
 };
 
 __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
@@ -59,15 +65,15 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
 #define REG(name, n) l.name = o; o += (n);
   REG(qpos, m.nq) REG(qvel, m.nv) REG(ctrl, m.nu) REG(warm, m.nv)
   REG(xpos, 3 * m.nbody) REG(xquat, 4 * m.nbody) REG(com, 3 * (m.ntree + 1))
-  REG(cdof, 6 * m.nv) REG(cvel, 6 * m.nbody)
-  if (m.has_accel) { REG(cdofdot, 6 * m.nv) REG(cacc, 6 * m.nbody) }   // the accelerometer re-reads them after the solve
+  REG(cdof, 6 * m.nv)
+  if (m.has_accel) { REG(cvel, 6 * m.nbody) REG(cdofdot, 6 * m.nv) REG(cacc, 6 * m.nbody) }
   REG(M, m.nM) REG(LD, m.nM) REG(Dinv, m.nv)
   REG(gpos, 3 * m.ngeom) REG(gquat, 4 * m.ngeom)
-  REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(x, m.nv) REG(qfc, m.nv) REG(qacc, m.nv)
+  REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(qfc, m.nv) REG(qacc, m.nv)
+  l.x = l.bias;      // solver / integrator temporary: the bias forces are dead once qfrc_smooth exists
   REG(con, CON_STRIDE * m.nconmax) REG(sens, m.nsensordata + 1)
-  REG(gsize, 3 * m.ngeom) REG(tab, (m.ntab + 3) / 4)     // model constants staged once per launch
+  REG(tab, (m.ntab + 3) / 4)     // structure tables staged once per launch
   int ni = I_HEAD;
-  l.i_item = ni; ni += m.nitemmax;
   l.i_cong1 = ni; ni += m.nconmax;
   l.i_cong2 = ni; ni += m.nconmax;
   l.i_conadr = ni; ni += m.nconmax;
@@ -75,9 +81,20 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   l.i_rowinfo = ni; ni += m.njmax;
   REG(ints, (ni + 1) / 2)
   l.u = o;
-  l.xanchor = o; l.xaxis = l.xanchor + 3 * m.njnt; l.cinert = l.xaxis + 3 * m.njnt; l.crb = l.cinert + 10 * m.nbody;
-  int first = 6 * m.njnt + 20 * m.nbody;
-  if (!m.has_accel) { l.cdofdot = o + first; l.cacc = l.cdofdot + 6 * m.nv; first += 6 * m.nv + 6 * m.nbody; }
+  l.cinert = o;
+  const int sb = o + 10 * m.nbody;
+  l.xanchor = sb; l.xaxis = sb + 3 * m.njnt;
+  l.crb = sb;
+  l.gsize = sb; l.i_item = 2 * (sb + 3 * m.ngeom - l.ints);
+  int scratch = 6 * m.njnt;
+  if (10 * m.nbody > scratch) scratch = 10 * m.nbody;
+  if (3 * m.ngeom + (m.nitemmax + 1) / 2 > scratch) scratch = 3 * m.ngeom + (m.nitemmax + 1) / 2;
+  if (!m.has_accel) {
+    // (the bias-force recursion keeps its per-body forces in the crb slots, so the velocities start after those)
+    l.cvel = sb + 10 * m.nbody; l.cdofdot = l.cvel + 6 * m.nbody; l.cacc = l.cdofdot + 6 * m.nv;
+    if (22 * m.nbody + 6 * m.nv > scratch) scratch = 22 * m.nbody + 6 * m.nv;
+  }
+  int first = 10 * m.nbody + scratch;
   l.ldj = JW;
   l.J = o; l.row = l.J + l.ldj * m.njmax;
   int second = l.ldj * m.njmax + ROW_STRIDE * m.njmax;
@@ -196,7 +213,6 @@ __device__ inline Tab make_tab(const DevModel& m, const Lay& l, const real* S) {
 __device__ inline void stage_constants(const DevModel& m, const Lay& l, real* S, int L) {
   unsigned short* t = (unsigned short*)(S + l.tab);
   for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned short)m.lds_tab[i];
-  for (int i = L; i < 3 * m.ngeom; i += 64) S[l.gsize + i] = m.geom_size[i];
 }
 
 __device__ __forceinline__ float int_as_float(int v) {
@@ -288,13 +304,13 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const 
   if (L > 0 && L < m.nbody) {
     q = ldq(S + l.xquat + 4 * L);
     xi = ld3(S + l.xpos + 3 * L) + rot(q, ld3(m.body_ipos + 3 * L));
-    st3(S + l.crb + 10 * L, xi * K.b_mass);
+    st3(S + l.cinert + 10 * L, xi * K.b_mass);     // (scratch until the sums are taken; cinert is written after)
   }
   wv::sync();
   if (L < 3 * m.ntree) {
     int t = L / 3, k = L % 3, root = m.tree_rootbody[t], n = m.body_subtreenum[root];
     real acc = 0;
-    for (int c = root; c < root + n; c++) acc += S[l.crb + 10 * c + k];
+    for (int c = root; c < root + n; c++) acc += S[l.cinert + 10 * c + k];
     real mass = m.body_subtreemass[root];
     S[l.com + 3 * t + k] = mass < MJ_MINVAL ? S[l.xpos + 3 * root + k] : acc / mass;
   }
@@ -468,6 +484,9 @@ __device__ inline void stage_geoms(const DevModel& m, const Lay& l, real* S, int
     st3(S + l.gpos + 3 * L, ld3(S + l.xpos + 3 * b) + rot(bq, ld3(m.geom_pos + 3 * L)));
     stq(S + l.gquat + 4 * L, qmul(bq, ldq(m.geom_quat + 4 * L)));
   }
+  // the geom sizes go next to the work items of the collision stage (scratch area of `u`, free since the composite
+  // inertias were consumed); the loads were issued above the frame arithmetic
+  for (int i = L; i < 3 * m.ngeom; i += 64) S[l.gsize + i] = m.geom_size[i];
   wv::sync();
 }
 
@@ -957,7 +976,6 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     }
     real aii = acc + Rr;
     R[ROW_ARII] = aii;
-    R[ROW_ARINV] = 1.0 / aii;
   }
   wv::sync();
 }
@@ -1007,7 +1025,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     for (int r = L; r < nefc; r += 64) S[l.row + ROW_STRIDE * r + ROW_F] = 0;
   }
   MJ_SUBSTAMP(ST_PGS_WARM)
-  // per-tree row lists (the work-item list of the collision stage is free again): slot[base_t + rank] = row
+  // per-tree row lists (in the row-id array, which the finished row build no longer needs): list[base_t + rank] = row
   const int mytree = L >> 4;
   int cnt_my = 0, base_my = 0, tmax = 0;
   bool cross = false;
@@ -1020,7 +1038,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
         int info = r < nefc ? I[l.i_rowinfo + r] : (1 << CHAIN_BITS);
         int rt = (info >> CHAIN_BITS) - 2;
         unsigned long long mask = wv::ballot(rt == t);
-        if (rt == t) I[l.i_item + total + cnt + wv::popc(mask & ((1ull << L) - 1ull))] = r;
+        if (rt == t) I[l.i_rowid + total + cnt + wv::popc(mask & ((1ull << L) - 1ull))] = r;
         cnt += wv::popc(mask);
         if (t == 0) cross |= wv::ballot(rt == -2) != 0ull;
       }
@@ -1042,10 +1060,11 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     auto fetch = [&](int sidx) {
       Rec r;
       r.has = sidx < cnt_my;
-      r.i = r.has ? I[l.i_item + base_my + sidx] : 0;
+      r.i = r.has ? I[l.i_rowid + base_my + sidx] : 0;
       const real* R = S + l.row + ROW_STRIDE * r.i;
       r.bid = (dof && r.has) ? S[l.J + JW * r.i + (L & 15)] : 0.0;      // tree-local rows: the lane's own slot
-      r.fi = R[ROW_F]; r.Ri = R[ROW_R]; r.bi = R[ROW_B]; r.aii = R[ROW_ARII]; r.ainv = R[ROW_ARINV];
+      r.fi = R[ROW_F]; r.Ri = R[ROW_R]; r.bi = R[ROW_B]; r.aii = R[ROW_ARII];
+      r.ainv = 1.0 / r.aii;       // one row ahead of its use, off the sweep's dependent chain
       return r;
     };
     Rec nxt = fetch(0);
@@ -1077,7 +1096,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       for (int i = 0; i < nefc; i++) {
         const real* R = S + l.row + ROW_STRIDE * i;
         real bid = coef(i, I[l.i_rowinfo + i]);
-        real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = R[ROW_ARINV];
+        real fi = R[ROW_F], Ri = R[ROW_R], bi = R[ROW_B], aii = R[ROW_ARII], ainv = 1.0 / aii;
         // reduce over the lanes that hold dofs, then hand lane 0's sum to the whole wave
         real res = wv::first(wv::sum_n(bid * dinv * u, width)) + Ri * fi + bi;
         real fn = fi - res * ainv;

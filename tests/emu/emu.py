@@ -16,7 +16,7 @@ REGION_SHAPES = {
     "xanchor": ("njnt", 3), "xaxis": ("njnt", 3), "cinert": ("nbody", 10), "crb": ("nbody", 10), "cdof": ("nv", 6),
     "cdofdot": ("nv", 6), "cvel": ("nbody", 6), "cacc": ("nbody", 6), "M": ("nM",), "LD": ("nM",), "Dinv": ("nv",),
     "gpos": ("ngeom", 3), "gquat": ("ngeom", 4), "bias": ("nv",), "smooth": ("nv",), "qaccs": ("nv",), "x": ("nv",),
-    "qfc": ("nv",), "qacc": ("nv",), "con": ("nconmax", 16), "row": ("njmax", 5), "sens": ("nsensordata",),
+    "qfc": ("nv",), "qacc": ("nv",), "con": ("nconmax", 15), "row": ("njmax", 4), "sens": ("nsensordata",),
 }
 
 
