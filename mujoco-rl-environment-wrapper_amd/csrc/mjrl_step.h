@@ -1051,7 +1051,78 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   MJ_SUBSTAMP(ST_PGS_LISTS)
   real scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
   int iter = 0;
-  if (m.rowmap && !cross) {
+  if (m.rowmap && !cross && tmax <= 16) {
+    // Residual form, all in registers: with at most 16 rows per tree, lane k of a tree's 16 lanes owns the tree's
+    // k-th row -- its force f_k, its row of AR = B D^-1 B' + diag(R) and its residual r_k = (AR f)_k + b_k.  A
+    // Gauss-Seidel step on row k is a handful of operations in lane k, one DPP broadcast of the force change and one
+    // multiply-add per lane (r_j += AR_jk * delta): no reduction and no LDS access inside the sweeps.  The trees
+    // step through their rows side by side.
+    const int kme = L & 15;
+    const bool has_row = kme < cnt_my;
+    const int myrow = has_row ? I[l.i_rowid + base_my + kme] : 0;
+    real* Rm = S + l.row + ROW_STRIDE * myrow;
+    real fi = has_row ? Rm[ROW_F] : 0.0, bi = has_row ? Rm[ROW_B] : 0.0, Ri = has_row ? Rm[ROW_R] : 0.0;
+    const real aii = has_row ? Rm[ROW_ARII] : 1.0;
+    const real ainv = 1.0 / aii;
+    const int adr0 = wv::bcast16i<0>(mydof);            // first dof of the lane's tree
+    const int tn = wv::popc((wv::ballot(dof) >> (L & 48)) & 0xFFFFull);     // dofs in the lane's tree
+    real W[16], A[16];
+#pragma unroll
+    for (int d = 0; d < 16; d++)
+      W[d] = (has_row && d < tn) ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      real acc = 0;
+      if (k < tmax) {
+        const int rk = k < cnt_my ? I[l.i_rowid + base_my + k] : 0;
+        const real* Bk = S + l.J + JW * rk;
+#pragma unroll
+        for (int d = 0; d < 16; d++) acc += W[d] * Bk[d];
+        if (k >= cnt_my) acc = 0;
+        if (k == kme) acc += Ri;
+      }
+      A[k] = acc;
+    }
+    real r = bi;
+#define MJ_RINIT(KK) if (KK < tmax) r += A[KK] * wv::bcast16<KK>(fi);
+    MJ_RINIT(0) MJ_RINIT(1) MJ_RINIT(2) MJ_RINIT(3) MJ_RINIT(4) MJ_RINIT(5) MJ_RINIT(6) MJ_RINIT(7)
+    MJ_RINIT(8) MJ_RINIT(9) MJ_RINIT(10) MJ_RINIT(11) MJ_RINIT(12) MJ_RINIT(13) MJ_RINIT(14) MJ_RINIT(15)
+#undef MJ_RINIT
+    while (iter < m.iterations) {
+      real imp = 0;
+#define MJ_GSTEP(KK)                                                                  \
+      if (KK < tmax) {                                                                \
+        real fn = fi - r * ainv;                                                      \
+        if (fn < 0) fn = 0;                                                           \
+        real delta = fn - fi;                                                         \
+        real change = 0.5 * delta * delta * aii + delta * r;                          \
+        bool act = kme == KK && has_row && !(change > 1e-10);                         \
+        if (!act) { delta = 0; change = 0; fn = fi; }                                 \
+        fi = fn;                                                                      \
+        imp -= change;                                                                \
+        r += A[KK] * wv::bcast16<KK>(delta);                                          \
+      }
+      MJ_GSTEP(0) MJ_GSTEP(1) MJ_GSTEP(2) MJ_GSTEP(3) MJ_GSTEP(4) MJ_GSTEP(5) MJ_GSTEP(6) MJ_GSTEP(7)
+      MJ_GSTEP(8) MJ_GSTEP(9) MJ_GSTEP(10) MJ_GSTEP(11) MJ_GSTEP(12) MJ_GSTEP(13) MJ_GSTEP(14) MJ_GSTEP(15)
+#undef MJ_GSTEP
+      iter++;
+      real improvement = wv::rows4_sum(wv::sum16(imp));
+      if (improvement * scale < m.tolerance) break;
+    }
+    if (has_row) Rm[ROW_F] = fi;
+    // u = B' f for the lane's dof
+    u = 0;
+#define MJ_USTEP(KK)                                                                  \
+    if (KK < tmax) {                                                                  \
+      real fk = wv::bcast16<KK>(fi);                                                  \
+      const int rk = KK < cnt_my ? I[l.i_rowid + base_my + KK] : 0;                   \
+      if (dof && KK < cnt_my) u += S[l.J + JW * rk + kme] * fk;                       \
+    }
+    MJ_USTEP(0) MJ_USTEP(1) MJ_USTEP(2) MJ_USTEP(3) MJ_USTEP(4) MJ_USTEP(5) MJ_USTEP(6) MJ_USTEP(7)
+    MJ_USTEP(8) MJ_USTEP(9) MJ_USTEP(10) MJ_USTEP(11) MJ_USTEP(12) MJ_USTEP(13) MJ_USTEP(14) MJ_USTEP(15)
+#undef MJ_USTEP
+    wv::sync();
+  } else if (m.rowmap && !cross) {
     const bool leader = (L & 15) == 0;
     // software pipeline: the record of the tree's next row is fetched while the current row is processed
     // (the row list is the same in every sweep; only the force F changes, and a row's F is rewritten by this

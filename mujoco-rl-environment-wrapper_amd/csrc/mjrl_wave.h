@@ -60,6 +60,9 @@ __device__ __forceinline__ double sum(double v) { return sum_n(v, 64); }
 template <int N>
 __device__ __forceinline__ double bcast16(double v) { return dpp<0x150 + N>(v); }
 
+template <int N>
+__device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, false); }
+
 // all-reduce (sum) inside each row of 16 lanes only
 __device__ __forceinline__ double sum16(double v) { return sum_n(v, 16); }
 

@@ -57,6 +57,8 @@ inline double sum(double v) { return sum_n(v, 64); }
 inline double first(double v) { return shfl(v, 0); }   // lane 0's value in every lane
 template <int N>
 inline double bcast16(double v) { return shfl(v, (lane() & ~15) + N); }   // lane N of the caller's row of 16
+template <int N>
+inline int bcast16i(int v) { return shfl(v, (lane() & ~15) + N); }   // lane N of the caller's row of 16
 inline double sum16(double v) { return sum_n(v, 16); }
 inline double rows4_sum(double v) { return (shfl(v, 0) + shfl(v, 16)) + (shfl(v, 32) + shfl(v, 48)); }
 inline double min_pos(double v) {
