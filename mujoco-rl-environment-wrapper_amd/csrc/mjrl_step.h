@@ -1047,6 +1047,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       tmax = cnt > tmax ? cnt : tmax;
     }
   }
+  tmax = wv::first_int(tmax);       // uniform by construction (ballot counts)
   wv::sync();
   MJ_SUBSTAMP(ST_PGS_LISTS)
   real scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
@@ -1071,40 +1072,79 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     for (int d = 0; d < 16; d++)
       W[d] = (has_row && d < tn) ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;
 #pragma unroll
+    for (int k = 0; k < 16; k++) A[k] = 0;
+#pragma unroll
     for (int k = 0; k < 16; k++) {
+      if (k >= tmax) break;
       real acc = 0;
-      if (k < tmax) {
+      {
         const int rk = k < cnt_my ? I[l.i_rowid + base_my + k] : 0;
         const real* Bk = S + l.J + JW * rk;
+        real p0 = 0, p1 = 0, p2 = 0, p3 = 0;      // four partial sums: the 16 terms form chains of 4
 #pragma unroll
-        for (int d = 0; d < 16; d++) acc += W[d] * Bk[d];
+        for (int d = 0; d < 16; d += 4) {
+          p0 += W[d] * Bk[d]; p1 += W[d + 1] * Bk[d + 1]; p2 += W[d + 2] * Bk[d + 2]; p3 += W[d + 3] * Bk[d + 3];
+        }
+        acc = (p0 + p1) + (p2 + p3);
         if (k >= cnt_my) acc = 0;
         if (k == kme) acc += Ri;
       }
       A[k] = acc;
     }
     real r = bi;
-#define MJ_RINIT(KK) if (KK < tmax) r += A[KK] * wv::bcast16<KK>(fi);
-    MJ_RINIT(0) MJ_RINIT(1) MJ_RINIT(2) MJ_RINIT(3) MJ_RINIT(4) MJ_RINIT(5) MJ_RINIT(6) MJ_RINIT(7)
-    MJ_RINIT(8) MJ_RINIT(9) MJ_RINIT(10) MJ_RINIT(11) MJ_RINIT(12) MJ_RINIT(13) MJ_RINIT(14) MJ_RINIT(15)
+#define MJ_RINIT(KK) if (KK >= tmax) break; r += A[KK] * wv::bcast16<KK>(fi);
+    do {
+      MJ_RINIT(0) MJ_RINIT(1) MJ_RINIT(2) MJ_RINIT(3) MJ_RINIT(4) MJ_RINIT(5) MJ_RINIT(6) MJ_RINIT(7)
+      MJ_RINIT(8) MJ_RINIT(9) MJ_RINIT(10) MJ_RINIT(11) MJ_RINIT(12) MJ_RINIT(13) MJ_RINIT(14) MJ_RINIT(15)
+    } while (0);
 #undef MJ_RINIT
+    const real haii = 0.5 * aii;
     while (iter < m.iterations) {
-      real imp = 0;
+      // The sweep is bound by instruction issue, so a row step carries the minimum: multiply, subtract, max, subtract,
+      // broadcast, and in the row's own lane a capture of the new force and of the residual it was computed from.
+      // What the reference does per step besides -- the cost change 0.5 d^2 A_kk + d r_k, summed into the sweep's
+      // improvement, and the guard that refuses a step which would raise the cost (change > 1e-10) -- is evaluated
+      // once per sweep from the captured values.  Exact arithmetic never raises the cost; a sweep in which rounding
+      // did is redone from its starting point with guarded steps.
+      const real f_start = fi, r_start = r;
+      real rs = r;
+      // (one scalar test per step that falls through while rows remain, one taken branch at the end of the rows;
+      // the tests are made on per-sweep copies the optimiser cannot see through, or it would precompute 32 masks)
+      const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
+#define MJ_FSTEP(KK)                                                                  \
+        if (KK >= tmax_s) break;                                                      \
+        {                                                                             \
+          real fn = fmax(fi - r * ainv, 0.0);                                         \
+          real db = wv::bcast16<KK>(fn - fi);                                         \
+          if (kme_s == KK) { fi = fn; rs = r; }                                       \
+          r += A[KK] * db;                                                            \
+        }
+      do {
+        MJ_FSTEP(0) MJ_FSTEP(1) MJ_FSTEP(2) MJ_FSTEP(3) MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7)
+        MJ_FSTEP(8) MJ_FSTEP(9) MJ_FSTEP(10) MJ_FSTEP(11) MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
+      } while (0);
+#undef MJ_FSTEP
+      const real dsweep = fi - f_start;
+      const real csweep = dsweep * dsweep * haii + dsweep * rs;
+      real imp = -csweep;
+      const bool refused = csweep > 1e-10;
+      if (wv::ballot(refused)) {
+        fi = f_start; r = r_start; imp = 0;
 #define MJ_GSTEP(KK)                                                                  \
-      if (KK < tmax) {                                                                \
-        real fn = fi - r * ainv;                                                      \
-        if (fn < 0) fn = 0;                                                           \
-        real delta = fn - fi;                                                         \
-        real change = 0.5 * delta * delta * aii + delta * r;                          \
-        bool act = kme == KK && has_row && !(change > 1e-10);                         \
-        if (!act) { delta = 0; change = 0; fn = fi; }                                 \
-        fi = fn;                                                                      \
-        imp -= change;                                                                \
-        r += A[KK] * wv::bcast16<KK>(delta);                                          \
-      }
-      MJ_GSTEP(0) MJ_GSTEP(1) MJ_GSTEP(2) MJ_GSTEP(3) MJ_GSTEP(4) MJ_GSTEP(5) MJ_GSTEP(6) MJ_GSTEP(7)
-      MJ_GSTEP(8) MJ_GSTEP(9) MJ_GSTEP(10) MJ_GSTEP(11) MJ_GSTEP(12) MJ_GSTEP(13) MJ_GSTEP(14) MJ_GSTEP(15)
+        if (KK < tmax) {                                                              \
+          real fn = fmax(fi - r * ainv, 0.0);                                         \
+          real delta = fn - fi;                                                       \
+          real change = delta * delta * haii + delta * r;                             \
+          bool act = kme == KK && has_row && !(change > 1e-10);                       \
+          if (!act) { delta = 0; change = 0; fn = fi; }                               \
+          fi = fn;                                                                    \
+          imp -= change;                                                              \
+          r += A[KK] * wv::bcast16<KK>(delta);                                        \
+        }
+        MJ_GSTEP(0) MJ_GSTEP(1) MJ_GSTEP(2) MJ_GSTEP(3) MJ_GSTEP(4) MJ_GSTEP(5) MJ_GSTEP(6) MJ_GSTEP(7)
+        MJ_GSTEP(8) MJ_GSTEP(9) MJ_GSTEP(10) MJ_GSTEP(11) MJ_GSTEP(12) MJ_GSTEP(13) MJ_GSTEP(14) MJ_GSTEP(15)
 #undef MJ_GSTEP
+      }
       iter++;
       real improvement = wv::rows4_sum(wv::sum16(imp));
       if (improvement * scale < m.tolerance) break;
@@ -1113,13 +1153,16 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     // u = B' f for the lane's dof
     u = 0;
 #define MJ_USTEP(KK)                                                                  \
-    if (KK < tmax) {                                                                  \
-      real fk = wv::bcast16<KK>(fi);                                                  \
-      const int rk = KK < cnt_my ? I[l.i_rowid + base_my + KK] : 0;                   \
-      if (dof && KK < cnt_my) u += S[l.J + JW * rk + kme] * fk;                       \
-    }
-    MJ_USTEP(0) MJ_USTEP(1) MJ_USTEP(2) MJ_USTEP(3) MJ_USTEP(4) MJ_USTEP(5) MJ_USTEP(6) MJ_USTEP(7)
-    MJ_USTEP(8) MJ_USTEP(9) MJ_USTEP(10) MJ_USTEP(11) MJ_USTEP(12) MJ_USTEP(13) MJ_USTEP(14) MJ_USTEP(15)
+      if (KK >= tmax) break;                                                          \
+      {                                                                               \
+        real fk = wv::bcast16<KK>(fi);                                                \
+        const int rk = KK < cnt_my ? I[l.i_rowid + base_my + KK] : 0;                 \
+        if (dof && KK < cnt_my) u += S[l.J + JW * rk + kme] * fk;                     \
+      }
+    do {
+      MJ_USTEP(0) MJ_USTEP(1) MJ_USTEP(2) MJ_USTEP(3) MJ_USTEP(4) MJ_USTEP(5) MJ_USTEP(6) MJ_USTEP(7)
+      MJ_USTEP(8) MJ_USTEP(9) MJ_USTEP(10) MJ_USTEP(11) MJ_USTEP(12) MJ_USTEP(13) MJ_USTEP(14) MJ_USTEP(15)
+    } while (0);
 #undef MJ_USTEP
     wv::sync();
   } else if (m.rowmap && !cross) {

@@ -82,6 +82,16 @@ __device__ __forceinline__ double first(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// The same value with its origin hidden from the optimiser (no instruction).  Used at the top of a hot loop on the
+// values its per-step conditions derive from: hoisted out of the loop those conditions become one 64-bit lane mask
+// each, too many for the scalar registers, and come back through v_readlane at every use.
+__device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
+
+// lane 0's int in a scalar register: tells the compiler that a value it could not prove wave-uniform is uniform, so
+// that conditions on it become scalar branches instead of per-lane masks
+__device__ __forceinline__ int first_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ double min_pos(double v) {   // minimum over the wave, every lane gets it
 #pragma unroll
   for (int mask = 1; mask < 64; mask <<= 1) v = fmin(v, shfl_xor(v, mask));

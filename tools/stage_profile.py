@@ -1,4 +1,6 @@
-"""Per-stage cycle shares of the step kernel on a settled, contact-rich batch (diagnostic)."""
+"""Per-stage cycle shares of the step kernel in the bench regime (a new random action every step), after `settle`
+steps.  Use a small batch (64 or 256 copies): every stamp is an atomic add on one address, and in a full launch the
+waves queue on it, which inflates the stages that wait on global loads (diagnostic)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,19 +9,19 @@ import __graft_entry__ as entry
 entry.load_package()
 from mjrl_amd import mjcf, levels, blob, _capi
 name = sys.argv[1] if len(sys.argv) > 1 else "two_agent.xml"
-n_env = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+n_env = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 settle = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 m = mjcf.compile_mjcf(levels.level_path(name))
 h = _capi.Handle(blob.pack(m), n_env)
 h.reset()
 rng = np.random.default_rng(0)
 for t in range(settle):
-    if t % 10 == 0:
-        h.set_field("ctrl", rng.uniform(-1, 1, (n_env, m.nu)))
+    h.set_field("ctrl", rng.uniform(-1, 1, (n_env, m.nu)))
     h.step_device(None, 0, 1)
 h.sync()
 tot = {}
 for _ in range(5):
+    h.set_field("ctrl", rng.uniform(-1, 1, (n_env, m.nu)))
     prof = h.step_profile()
     for k, v in prof.items():
         tot[k] = tot.get(k, 0) + v
