@@ -1382,13 +1382,16 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   int env = wv::env_index();
   if (a.lpt_count_in) {
     // workgroup id -> copy: walk the buckets from the heaviest down
-    int rest = env, pick = -1;
+    int rest = env, pick = -1, bucket = 0;
     for (int b = LPT_BUCKETS - 1; b >= 0 && pick < 0; b--) {
       int c = a.lpt_count_in[b];
-      if (rest < c) pick = a.lpt_list_in[(size_t)b * a.n_env + rest];
+      if (rest < c) { pick = a.lpt_list_in[(size_t)b * a.n_env + rest]; bucket = b; }
       rest -= c;
     }
     env = pick;
+    // The launch ends with its slowest copy, and a copy with hundreds of solver row steps is one long dependent
+    // chain: its wave gets issue priority over the waves that share its SIMD (they fill the gaps it leaves).
+    wv::set_priority(bucket >= 10 ? 3 : (bucket == 9 ? 2 : (bucket == 8 ? 1 : 0)));
   }
   Lay l;
   make_layout(m, l);

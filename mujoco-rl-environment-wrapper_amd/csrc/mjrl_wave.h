@@ -88,6 +88,14 @@ __device__ __forceinline__ double first(double v) {
 __device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
 
+// issue priority of this wave among the waves of its SIMD (0 lowest .. 3 highest); p is wave-uniform
+__device__ __forceinline__ void set_priority(int p) {
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 // lane 0's int in a scalar register: tells the compiler that a value it could not prove wave-uniform is uniform, so
 // that conditions on it become scalar branches instead of per-lane masks
 __device__ __forceinline__ int first_int(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -1,4 +1,4 @@
-// Cost of one row step of the register PGS (mjrl_step.h) and of its parts, dependent chains, one wave per SIMD.
+// Cost of one row step of the register PGS (mjrl_step.h) and of its parts: dependent chains, one wave per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define N 1024
@@ -9,33 +9,36 @@ __device__ __forceinline__ double dpp(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+#define STEP_FULL(KK, AK) { double fn = fmax(fi - r * ainv, 0.0); double db = dpp<0x150 + KK>(fn - fi); if (kme == KK) { fi = fn; rs = r; } r += AK * db; }
+#define STEP_NORS(KK, AK) { double fn = fmax(fi - r * ainv, 0.0); double db = dpp<0x150 + KK>(fn - fi); if (kme == KK) { fi = fn; } r += AK * db; }
+#define STEP_BARE(KK, AK) { double fn = fmax(fi - r * ainv, 0.0); double db = dpp<0x150 + KK>(fn - fi); fi = fn; r += AK * db; }
 __global__ __launch_bounds__(64) void probe(double* out, long long* cyc) {
-  int L = threadIdx.x, kme = L & 15;
-  double fi = out[L], r = out[L] + 0.25, ainv = 0.7, haii = 0.71, a3 = 0.01, a5 = 0.02, imp = 0;
-  bool refused = false;
+  int L = threadIdx.x;
+  int kme = L & 15;
+  asm volatile("" : "+v"(kme));
+  double fi = out[L], r = out[L] + 0.25, ainv = 0.7, a3 = 0.01, a5 = 0.02, a7 = 0.015, a9 = 0.005, rs = 0;
   long long t0, t1;
-  // 1: row_newbcast alone, dependent (bcast + add)
   t0 = clock64();
-  for (int i = 0; i < N; i++) { r = r * 0.999 + dpp<0x153>(r); }
+  for (int i = 0; i < N / 4; i++) { STEP_FULL(3, a3) STEP_FULL(5, a5) STEP_FULL(7, a7) STEP_FULL(9, a9) }
   t1 = clock64(); if (L == 0) cyc[0] = t1 - t0;
-  // 2: the unguarded step, two steps per iteration (lanes 3 and 5)
   t0 = clock64();
-  for (int i = 0; i < N / 2; i++) {
-    { double fn = fmax(fi - r * ainv, 0.0); double delta = fn - fi; double change = delta * delta * haii + delta * r;
-      r += a3 * dpp<0x153>(delta); if (kme == 3) { fi = fn; imp -= change; refused |= change > 1e-10; } }
-    { double fn = fmax(fi - r * ainv, 0.0); double delta = fn - fi; double change = delta * delta * haii + delta * r;
-      r += a5 * dpp<0x155>(delta); if (kme == 5) { fi = fn; imp -= change; refused |= change > 1e-10; } }
-  }
+  for (int i = 0; i < N / 4; i++) { STEP_NORS(3, a3) STEP_NORS(5, a5) STEP_NORS(7, a7) STEP_NORS(9, a9) }
   t1 = clock64(); if (L == 0) cyc[1] = t1 - t0;
-  // 3: fmax chain
   t0 = clock64();
-  for (int i = 0; i < N; i++) r = fmax(r * 0.999, 0.001);
+  for (int i = 0; i < N / 4; i++) { STEP_BARE(3, a3) STEP_BARE(5, a5) STEP_BARE(7, a7) STEP_BARE(9, a9) }
   t1 = clock64(); if (L == 0) cyc[2] = t1 - t0;
-  // 4: compare + select chain
+  // the u-form step of the pipelined path for comparison: 16-lane reduction per row
+  double u = fi, bid = 0.3, dinv = 0.9;
   t0 = clock64();
-  for (int i = 0; i < N; i++) { double x = r * 0.999; if (x < 0.001) x = 0.001; r = x; }
+  for (int i = 0; i < N; i++) {
+    double v = bid * dinv * u;
+    v += dpp<0xB1>(v); v += dpp<0x4E>(v); v += dpp<0x141>(v); v += dpp<0x140>(v);
+    double res = v + 0.1 * fi + 0.01;
+    double fn = fmax(fi - res * ainv, 0.0);
+    double delta = fn - fi; fi = fn; u += delta * bid;
+  }
   t1 = clock64(); if (L == 0) cyc[3] = t1 - t0;
-  out[L] = r + fi + imp + refused;
+  out[L] = r + fi + rs + u;
 }
 int main() {
   double* out; long long* cyc;
@@ -46,7 +49,7 @@ int main() {
   for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(probe, dim3(1024), dim3(64), 0, 0, out, cyc);
   hipDeviceSynchronize();
   long long hc[8]; hipMemcpy(hc, cyc, sizeof(hc), hipMemcpyDeviceToHost);
-  const char* names[] = {"row_newbcast f64 + mul + add (dependent)", "unguarded row step", "mul + fmax", "mul + compare + select"};
-  for (int k = 0; k < 4; k++) printf("%-44s %8.1f cycles\n", names[k], (double)hc[k] / N);
+  const char* names[] = {"row step (captures f and r in the row's lane)", "row step, f captured only", "row step, no capture (chain only)", "u-form step (sum16 reduction)"};
+  for (int k = 0; k < 4; k++) printf("%-48s %8.1f cycles\n", names[k], (double)hc[k] / N);
   return 0;
 }

@@ -8,15 +8,16 @@ entry.load_package()
 from mjrl_amd import mjcf, levels, blob, _capi
 m = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
 packed = blob.pack(m)
-for n_env in [64, 256, 512, 1024, 1280, 2048, 4096, 8192]:
+start = int(sys.argv[1]) if len(sys.argv) > 1 else 50       # first timed step of the episode (50: free fall, 400: contacts)
+for n_env in [64, 256, 512, 1024, 1536, 2048, 3072, 4096, 6144, 8192]:
     h = _capi.Handle(packed, n_env)
     h.reset()
     rng = np.random.default_rng(0)
-    # same physical regime for every size: the first 150 steps of an episode, timed over steps 50..150
-    for t in range(150):
-        if t % 10 == 0:
+    # same physical regime for every size: 100 steps of an episode from step `start`
+    for t in range(start + 100):
+        if t % 10 == 0 or t >= start - 20:
             h.set_field("ctrl", rng.uniform(-1, 1, (n_env, m.nu)))
-        if t == 50:
+        if t == start:
             h.sync(); t0 = time.perf_counter()
         h.step_device(None, 0, 1)
     h.sync()
