@@ -193,7 +193,8 @@ def main():
                        "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv, "obs_dim": obs_dim},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mjrl_step_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
+                         "kernel": "mjrl_step_kernel_spec" if env._handle.kernel == "specialised" else "mjrl_step_kernel",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
         }
         if world == 1 and not args.no_cpu_baseline:
             scatter = np.array([env.agents_action_index[a] for a in AGENTS])

@@ -81,9 +81,12 @@ __device__ __forceinline__ bool sphere_box(V3 sp, real r, V3 bp, const M3& bm, V
       real pen = s[k] - fabs(l[k]);
       if (pen < bestpen) { bestpen = pen; best = k; }
     }
-    real sg = l[best] >= 0 ? 1.0 : -1.0;
+    // (selects instead of l[best] / cl[best]: a run-time index would put the three arrays in scratch memory)
+    real lb = best == 0 ? l[0] : (best == 1 ? l[1] : l[2]), sb = best == 0 ? s[0] : (best == 1 ? s[1] : s[2]);
+    real sg = lb >= 0 ? 1.0 : -1.0;
     nout = v3(best == 0 ? sg : 0.0, best == 1 ? sg : 0.0, best == 2 ? sg : 0.0);
-    cl[best] = sg * s[best];
+    real face = sg * sb;
+    cl[0] = best == 0 ? face : cl[0]; cl[1] = best == 1 ? face : cl[1]; cl[2] = best == 2 ? face : cl[2];
     d = -bestpen;
   }
   c.dist = d - r;
@@ -188,6 +191,9 @@ __device__ __forceinline__ bool capsule_capsule(V3 p1, const M3& m1, V3 s1, V3 p
 // evaluate work item k of a (type-ordered) geom pair
 __device__ __forceinline__ bool collide_item(int t1, int t2, V3 p1, const M3& m1, V3 s1, V3 p2, const M3& m2, V3 s2,
                                              real margin, int k, RawCon& c) {
+  // (defined on every path: with the record undefined where no routine writes it, the compiler kept it in scratch
+  // memory instead of registers)
+  c.dist = 0; c.pos = v3(0, 0, 0); c.n = v3(0, 0, 0); c.t = v3(0, 0, 0);
   if (t1 == GEOM_PLANE) {
     V3 pn = col(m1, 2);
     if (t2 == GEOM_SPHERE) return plane_sphere(p1, pn, p2, s2.x, margin, c);

@@ -786,8 +786,7 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     real* R = S + l.row + ROW_STRIDE * r;
     int id = I[l.i_rowid + r], rtree = -1;
     real pos, margin, diag, mu0 = 0;
-    const real *solref, *solimp;
-    real sref[2], simp[5];
+    real sref[2], simp[5];      // solver parameters of the row, by value (a pointer into a local array would pin it to scratch memory)
     bool contact = id >= 0;
     // the row's dof chains: chain x = sparse-M row of dof lx, entries at ax .. ax + nx - 1 (descending dof ids)
     int a1 = 0, n1 = 0, a2 = 0, n2 = 0;
@@ -814,8 +813,8 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       pos = R[ROW_F];
       margin = m.jnt_margin[j];
       diag = m.dof_invweight0[dof];
-      solref = m.jnt_solref + 2 * j;
-      solimp = m.jnt_solimp + 5 * j;
+      for (int k = 0; k < 2; k++) sref[k] = m.jnt_solref[2 * j + k];
+      for (int k = 0; k < 5; k++) simp[k] = m.jnt_solimp[5 * j + k];
     } else {
       int c = id >> 3, sub = id & 7;
       const real* C = S + l.con + CON_STRIDE * c;
@@ -862,8 +861,6 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       else mix = s1 < MJ_MINVAL ? 0.0 : 1.0;
       for (int k = 0; k < 2; k++) sref[k] = mix * m.geom_solref[2 * g1 + k] + (1 - mix) * m.geom_solref[2 * g2 + k];
       for (int k = 0; k < 5; k++) simp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
-      solref = sref;
-      solimp = simp;
       contact = dim > 1;
     }
     // One-chain rows (every limit row, every contact with a static geom): the row lives in registers, indexed by the
@@ -921,9 +918,9 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
         jw += jk * S[l.warm + i];
       }
     }
-    real imp = impedance(solimp, pos, margin);
-    real dmax = fmin(fmax(solimp[1], MJ_MINIMP), MJ_MAXIMP);
-    real timeconst = fmax(solref[0], 2 * m.timestep), dampratio = solref[1];
+    real imp = impedance(simp, pos, margin);
+    real dmax = fmin(fmax(simp[1], MJ_MINIMP), MJ_MAXIMP);
+    real timeconst = fmax(sref[0], 2 * m.timestep), dampratio = sref[1];
     real Kc = 1.0 / fmax(MJ_MINVAL, dmax * dmax * timeconst * timeconst * dampratio * dampratio);
     real Bc = 2.0 / fmax(MJ_MINVAL, dmax * timeconst);
     real Rr = fmax(MJ_MINVAL, (1 - imp) / imp * diag);
@@ -1329,7 +1326,9 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
       }
     } else {
       int c = type - SENS_FRAMEXAXIS;
-      if (L == 0) st3(S + l.sens + adr, col(sm, c));
+      // (a select, not col(sm, c): a run-time column index would put the matrix in scratch memory)
+      V3 axis = c == 0 ? col(sm, 0) : (c == 1 ? col(sm, 1) : col(sm, 2));
+      if (L == 0) st3(S + l.sens + adr, axis);
     }
   }
   wv::sync();
