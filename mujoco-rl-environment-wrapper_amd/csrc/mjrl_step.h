@@ -401,16 +401,21 @@ __device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, i
       int kkadr = w & 1023, ijt = (w >> 10) & 1023, a = (w >> 20) & 7, t = (w >> 23) & 7;
       int ki = kkadr + 1 + a;
       real tmp = 0, val = 0;
+      // the pivot D_kk is final when its step starts (only deeper dofs update it), so its reciprocal is taken from the
+      // same read as the row scaling: the two divisions overlap and the step needs no second LDS round trip.  (The
+      // schedule word carries the pivot's address in every lane of the tree, also in lanes without a pair.)
+      real dkk = S[ld + kkadr];
       if (valid) {
-        tmp = S[ld + ki] / S[ld + kkadr];
+        tmp = S[ld + ki] / dkk;
         val = S[ld + ijt] - tmp * S[ld + ki + t];
       }
+      real rkk = 1.0 / dkk;
       wv::sync();
       if (valid) {
         S[ld + ijt] = val;
         if (t == 0) S[ld + ki] = tmp;
       }
-      if (live && p == 0) S[dinv + adr0 + kk] = 1.0 / S[ld + kkadr];
+      if (live && p == 0) S[dinv + adr0 + kk] = rkk;
       wv::sync();
     }
   }
@@ -1143,7 +1148,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
 #undef MJ_GSTEP
       }
       iter++;
-      real improvement = wv::rows4_sum(wv::sum16(imp));
+      real improvement = wv::rows_sum(wv::sum16(imp), m.ntree);
       if (improvement * scale < m.tolerance) break;
     }
     if (has_row) Rm[ROW_F] = fi;

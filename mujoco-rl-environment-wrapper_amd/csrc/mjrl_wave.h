@@ -75,6 +75,13 @@ __device__ __forceinline__ double lane_value(double v, int src) {
 __device__ __forceinline__ double rows4_sum(double v) {
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
+// the same when only the first `rows` rows of 16 lanes can hold non-zero values (x + 0 is exact, so the sums agree
+// bit for bit); `rows` is wave-uniform, a constant in the model-specialised kernel
+__device__ __forceinline__ double rows_sum(double v, int rows) {
+  if (rows <= 1) return lane_value(v, 0);
+  if (rows == 2) return lane_value(v, 0) + lane_value(v, 16);
+  return rows4_sum(v);
+}
 
 // lane 0's value in every lane (v_readfirstlane: the result is wave-uniform)
 __device__ __forceinline__ double first(double v) {

@@ -65,6 +65,11 @@ template <int N>
 inline int bcast16i(int v) { return shfl(v, (lane() & ~15) + N); }   // lane N of the caller's row of 16
 inline double sum16(double v) { return sum_n(v, 16); }
 inline double rows4_sum(double v) { return (shfl(v, 0) + shfl(v, 16)) + (shfl(v, 32) + shfl(v, 48)); }
+inline double rows_sum(double v, int rows) {
+  if (rows <= 1) return shfl(v, 0);
+  if (rows == 2) return shfl(v, 0) + shfl(v, 16);
+  return rows4_sum(v);
+}
 inline double min_pos(double v) {
   for (int mask = 1; mask < 64; mask <<= 1) v = std::fmin(v, shfl_xor(v, mask));
   return v;

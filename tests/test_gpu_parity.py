@@ -371,3 +371,63 @@ def test_specialised_kernel_is_bit_identical_to_the_generic_one():
         gen.load_kernel(other)
     assert gen.kernel == "generic"
     gen.step_host(None, 1)
+
+
+def test_general_paths_and_two_chain_rows_on_the_gpu():
+    """The paths random play rarely reaches, through the C-ABI: a model without the tree-row lane map (compact rows,
+    level-parallel LDS solves, serial sweeps) and hand-posed states whose contacts join two moving bodies -- agent on
+    agent (two kinematic trees) and leg on leg inside one agent (ancestor chains that share the torso dofs)."""
+    # no lane map
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"), lane_map=False)
+    packed = blob.pack(model)
+    n_env = 4
+    h = _capi.Handle(packed, n_env)
+    h.reset()
+    oras = [OracleEnv(packed) for _ in range(n_env)]
+    rng = np.random.default_rng(8)
+    for _ in range(260):
+        ctrl = rng.uniform(-1, 1, (n_env, model.nu))
+        h.set_field("ctrl", ctrl)
+        h.step_host(None, 1)
+        for e, o in enumerate(oras):
+            o.ctrl[:] = ctrl[e]
+            o.step()
+    assert max(o.ncon for o in oras) > 0 and not h.query("warn").any()
+    assert rel(h.get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
+    assert rel(h.get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
+    # posed states with two-chain rows
+    model, packed, h = make("two_agent.xml", 2)
+    tree, gbody = model.body_treeid, model.geom_bodyid
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == 0]
+    a0, a1 = (int(model.jnt_qposadr[j]) for j in free)
+    hinge_q = [int(model.jnt_qposadr[j]) for j in range(model.njnt) if model.jnt_type[j] == 3]
+    stacked = model.qpos0.copy()
+    stacked[a1:a1 + 3] = stacked[a0:a0 + 3] + np.array([0.15, 0.1, 0.55])      # agent 1 dropped onto agent 0
+    probe, folded = OracleEnv(packed), None
+    rng = np.random.default_rng(3)
+    for _ in range(200):                                                       # legs folded into each other, in the air
+        q = model.qpos0.copy()
+        q[hinge_q] = rng.uniform(-2.5, 2.5, len(hinge_q))
+        q[a0 + 2] += 1.0; q[a1 + 2] += 1.0
+        probe.qpos[:] = q; probe.qvel[:] = 0
+        probe.forward()
+        if any(tree[gbody[c["geom1"]]] == tree[gbody[c["geom2"]]] >= 0 for c in probe.contacts()):
+            folded = q
+            break
+    assert folded is not None
+    start = np.stack([stacked, folded])
+    h.set_field("qpos", start)
+    oras = [OracleEnv(packed) for _ in range(2)]
+    seen = [0, 0]
+    for e, o in enumerate(oras):
+        o.qpos[:] = start[e]
+    for _ in range(60):
+        h.step_host(None, 1)
+        for e, o in enumerate(oras):
+            o.step()
+            for c in o.contacts():
+                t1, t2 = int(tree[gbody[c["geom1"]]]), int(tree[gbody[c["geom2"]]])
+                seen[e] += (t1 >= 0 and t2 >= 0 and ((t1 != t2) if e == 0 else (t1 == t2)))
+    assert seen[0] > 0 and seen[1] > 0
+    assert rel(h.get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
+    assert rel(h.get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
