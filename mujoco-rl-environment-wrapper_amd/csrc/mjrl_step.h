@@ -103,6 +103,11 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   l.total = o;
 }
 
+// stage clock of a wave (diagnostic launches only): time of the last stamp, and in lane k the cycles of stage k so far
+struct Stamps {
+  unsigned long long prev, mine;
+};
+
 // Arguments of one step call, shared by every env copy
 struct StepArgs {
   // state in HBM, [n_env][n] row-major
@@ -168,6 +173,7 @@ enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_V
 struct LaneK {
   // lane as body
   int b_parent, b_depth, b_tree, b_dofadr, b_dofnum, b_jntadr, b_jntnum, b_subnum;
+  int b_jnttype;      // type of the body's first joint (-1: none)
   real b_mass;
   // lane as dof
   int d_parent, d_Madr, d_depth, d_body, d_descadr, d_descnum, d_act;
@@ -180,6 +186,7 @@ __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
   k.b_parent = m.body_parentid[b]; k.b_depth = isb ? m.body_depth[b] : -1; k.b_tree = m.body_treeid[b];
   k.b_dofadr = m.body_dofadr[b]; k.b_dofnum = isb ? m.body_dofnum[b] : 0; k.b_jntadr = m.body_jntadr[b];
   k.b_jntnum = isb ? m.body_jntnum[b] : 0; k.b_subnum = m.body_subtreenum[b]; k.b_mass = m.body_mass[b];
+  k.b_jnttype = k.b_jntnum > 0 ? m.jnt_type[k.b_jntadr] : -1;
   k.d_parent = m.dof_parentid[d]; k.d_Madr = m.dof_Madr[d]; k.d_depth = isd ? m.dof_depth[d] : -1;
   k.d_body = m.dof_bodyid[d]; k.d_descadr = m.dof_descadr[d]; k.d_descnum = isd ? m.dof_descnum[d] : 0;
   k.d_act = isd ? m.dof_actid[d] : -1; k.d_damping = m.dof_damping[d]; k.d_armature = m.dof_armature[d];
@@ -257,9 +264,27 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
     Quat q; q.w = 1; q.x = q.y = q.z = 0;
     stq(S + l.xquat, q);
   }
-  // everything that does not depend on the parent's frame is fetched before the level loop
-  V3 bpos = ld3(m.body_pos + 3 * (L < m.nbody ? L : 0));
-  Quat bquat = ldq(m.body_quat + 4 * (L < m.nbody ? L : 0));
+  // Everything that does not depend on the parent's frame is done before the level loop, for all bodies at once: the
+  // body's offset, and for its first joint (the only one of most bodies) the constants and the joint's own motion --
+  // the rotation quaternion of a hinge (one sincos for the whole wave instead of one per tree level), the normalised
+  // quaternion of a free joint.
+  const bool isb = L < m.nbody;
+  V3 bpos = ld3(m.body_pos + 3 * (isb ? L : 0));
+  Quat bquat = ldq(m.body_quat + 4 * (isb ? L : 0));
+  const int j0 = K.b_jntadr;
+  const bool hasj = K.b_jntnum > 0;
+  const int jt0 = K.b_jnttype, qa0 = hasj ? m.jnt_qposadr[j0] : 0;
+  V3 jaxis0 = hasj ? ld3(m.jnt_axis + 3 * j0) : v3(0, 0, 1), jpos0 = hasj ? ld3(m.jnt_pos + 3 * j0) : v3(0, 0, 0);
+  real q0 = 0;
+  V3 fpos = v3(0, 0, 0);
+  Quat jq; jq.w = 1; jq.x = jq.y = jq.z = 0;
+  if (jt0 == JNT_FREE) {
+    fpos = ld3(S + l.qpos + qa0);
+    jq = qnormalized(ldq(S + l.qpos + qa0 + 3));
+  } else if (hasj) {
+    q0 = S[l.qpos + qa0] - m.qpos0[qa0];
+    if (jt0 == JNT_HINGE) jq = axis_angle(jaxis0, q0);
+  }
   wv::sync();
   for (int lev = 1; lev <= m.maxdepth; lev++) {
     if (K.b_depth == lev) {
@@ -267,7 +292,26 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
       Quat pq = ldq(S + l.xquat + 4 * p);
       V3 pos = ld3(S + l.xpos + 3 * p) + rot(pq, bpos);
       Quat quat = qmul(pq, bquat);
-      for (int k = 0; k < K.b_jntnum; k++) {
+      if (hasj) {
+        if (jt0 == JNT_FREE) {
+          pos = fpos;
+          quat = jq;
+          st3(S + l.xanchor + 3 * j0, pos);
+          st3(S + l.xaxis + 3 * j0, rot(quat, jaxis0));
+        } else {
+          V3 anchor = pos + rot(quat, jpos0);
+          V3 axis = rot(quat, jaxis0);
+          st3(S + l.xanchor + 3 * j0, anchor);
+          st3(S + l.xaxis + 3 * j0, axis);
+          if (jt0 == JNT_HINGE) {
+            quat = qmul(quat, jq);
+            pos = anchor - rot(quat, jpos0);
+          } else {
+            pos = pos + axis * q0;
+          }
+        }
+      }
+      for (int k = 1; k < K.b_jntnum; k++) {           // further joints of the same body (rare)
         int j = K.b_jntadr + k, qa = m.jnt_qposadr[j];
         V3 jaxis = ld3(m.jnt_axis + 3 * j), jpos = ld3(m.jnt_pos + 3 * j);
         if (m.jnt_type[j] == JNT_FREE) {
@@ -593,16 +637,16 @@ __device__ inline void stage_velocity(const DevModel& m, const Lay& l, const Lan
     if (!with_acc) for (int r = 0; r < 6; r++) S[l.crb + r] = 0;
   }
   wv::sync();
+  real cvel[6] = {0, 0, 0, 0, 0, 0}, cacc[6] = {0, 0, 0, 0, 0, 0};     // the lane's body, kept for the force pass below
   for (int lev = 1; lev <= m.maxdepth; lev++) {
     if (K.b_depth == lev) {
       int b = L, p = K.b_parent;
-      real cvel[6], cacc[6];
       for (int r = 0; r < 6; r++) { cvel[r] = S[l.cvel + 6 * p + r]; cacc[r] = S[l.cacc + 6 * p + r]; }
       int da = K.b_dofadr;
       if (!with_acc) {
         for (int k = 0; k < K.b_jntnum; k++) {
           int j = K.b_jntadr + k;
-          if (m.jnt_type[j] == JNT_FREE) {
+          if ((k == 0 ? K.b_jnttype : m.jnt_type[j]) == JNT_FREE) {
             for (int t = 0; t < 3; t++) {
               for (int r = 0; r < 6; r++) {
                 S[l.cdofdot + 6 * (da + t) + r] = 0;
@@ -639,19 +683,21 @@ __device__ inline void stage_velocity(const DevModel& m, const Lay& l, const Lan
           if (with_acc) cacc[r] += S[l.cdof + 6 * (da + t) + r] * S[l.qacc + da + t];
         }
       for (int r = 0; r < 6; r++) S[l.cacc + 6 * b + r] = cacc[r];
-      if (!with_acc) {
-        // body force  I*a + v x* (I*v)   (crb's rows are free again: they hold the body forces)
-        real ci[10], t1[6], t2[6], t3[6];
-        for (int k = 0; k < 10; k++) ci[k] = S[l.cinert + 10 * b + k];
-        inert_mul(t1, ci, cacc);
-        inert_mul(t2, ci, cvel);
-        cross_force(t3, cvel, t2);
-        for (int r = 0; r < 6; r++) S[l.crb + 10 * b + r] = t1[r] + t3[r];
-      }
     }
     wv::sync();
   }
   if (with_acc) return;
+  // body force  I*a + v x* (I*v), every body at once from the velocities and accelerations its lane still holds
+  // (crb's rows are free again: they hold the body forces)
+  if (L > 0 && L < m.nbody) {
+    real ci[10], t1[6], t2[6], t3[6];
+    for (int k = 0; k < 10; k++) ci[k] = S[l.cinert + 10 * L + k];
+    inert_mul(t1, ci, cacc);
+    inert_mul(t2, ci, cvel);
+    cross_force(t3, cvel, t2);
+    for (int r = 0; r < 6; r++) S[l.crb + 10 * L + r] = t1[r] + t3[r];
+  }
+  wv::sync();
   // force transmitted by each dof-carrying body = sum of the body forces over its subtree; project on its dofs
   if (L > 0 && L < m.nbody && K.b_dofnum > 0) {
     real f[6];
@@ -706,12 +752,12 @@ __device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK
 // row's own dof chains, and AR_ii = sum_d B_id^2 / D_d + R_i.  A row only touches the dof chains of its (at most
 // two) bodies; the chains are read from the LDS structure tables.
 __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int L, bool project,
-                                  unsigned long long* stamps, unsigned long long& t_prev) {
+                                  Stamps* stamps) {
 #define MJ_SUBSTAMP(k)                                                     \
   if (stamps) {                                                            \
     unsigned long long t_now = wv::clock();                                \
-    if (L == 0) wv::atomic_add(stamps + (k), t_now - t_prev);              \
-    t_prev = t_now;                                                        \
+    if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
+    stamps->prev = t_now;                                                  \
   }
   int* I = (int*)(S + l.ints);
   const Tab T = make_tab(m, l, S);
@@ -988,12 +1034,12 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
 // row of 16 lanes, so the trees sweep their own rows side by side (rows of different trees commute, the order inside
 // a tree is the solver's row order); a step with a row that couples two trees falls back to the serial sweep.
 __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L,
-                                 unsigned long long* stamps, unsigned long long& t_prev) {
+                                 Stamps* stamps) {
 #define MJ_SUBSTAMP(k)                                                     \
   if (stamps) {                                                            \
     unsigned long long t_now = wv::clock();                                \
-    if (L == 0) wv::atomic_add(stamps + (k), t_now - t_prev);              \
-    t_prev = t_now;                                                        \
+    if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
+    stamps->prev = t_now;                                                  \
   }
   int* I = (int*)(S + l.ints);
   int nefc = I[I_NEFC];
@@ -1403,12 +1449,17 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   load_lane_constants(m, L, K);
   RowK RK;
   load_row_constants(m, L, RK);
-  unsigned long long t_prev = a.stamps ? wv::clock() : 0ull;
+  // diagnostic stage clock: lane k accumulates the cycles of stage k in a register and adds them to the batch totals
+  // when the wave is done -- nothing of the measurement touches memory while a stage is being timed
+  Stamps clock_state;
+  clock_state.prev = a.stamps ? wv::clock() : 0ull;
+  clock_state.mine = 0;
+  Stamps* const stamps = a.stamps ? &clock_state : nullptr;
 #define MJ_STAMP(k)                                                        \
-  if (a.stamps) {                                                          \
+  if (stamps) {                                                            \
     unsigned long long t_now = wv::clock();                                \
-    if (L == 0) wv::atomic_add(a.stamps + (k), t_now - t_prev);            \
-    t_prev = t_now;                                                        \
+    if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
+    stamps->prev = t_now;                                                  \
   }
 #define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
   // state in
@@ -1451,11 +1502,11 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     stage_smooth(m, l, K, RK, S, L);
     MJ_STAMP(ST_SMOOTH)
     // (a raw-row debug dump keeps J unprojected; such a launch is for inspection only)
-    stage_rows(m, l, S, L, !(a.dbg && a.dbg_stage == 1), a.stamps, t_prev);
+    stage_rows(m, l, S, L, !(a.dbg && a.dbg_stage == 1), stamps);
     MJ_STAMP(ST_ROWS)
     if (a.dbg && a.dbg_stage == 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
-    stage_pgs(m, l, K, RK, S, L, a.stamps, t_prev);
+    stage_pgs(m, l, K, RK, S, L, stamps);
     MJ_STAMP(ST_PGS)
     stage_sensors(m, l, K, S, L);
     MJ_STAMP(ST_SENSORS)
@@ -1502,6 +1553,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   }
   MJ_STAMP(ST_STORE)
 #undef MJ_STAMP
+  if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
   if (a.lpt_count_out && L == 0) {
     const int* I = (const int*)(S + l.ints);
     unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
