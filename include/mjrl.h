@@ -120,9 +120,11 @@ int mjrl_render_host(mjrl_env* env, int width, int height, uint8_t* h_rgb);
 int mjrl_step_debug(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames, int stage,
                     double* h_dump, size_t nbytes);
 int mjrl_lds_offset(const mjrl_env* env, const char* region);
-/* Diagnostic: one step with per-stage wave-clock stamps; h_cycles[n] receives, per stage, the cycles summed
- * over all env copies (stage order: load kin com crb factor geom collide vel smooth rows project pgs sensors
- * euler store pgs_warm pgs_lists pgs_sweeps; "pgs" then holds the rest of the solver stage; plus rows_limits rows_addr (then "rows" is the row build proper); n must be 20). */
+/* Diagnostic: one step with per-stage wave-clock stamps; h_cycles[n] receives, per stage, the cycles summed over all
+ * env copies.  Stage order: load kin com crb factor geom collide vel smooth rows project pgs sensors euler store
+ * pgs_warm pgs_lists pgs_sweeps rows_limits rows_addr pgs_setup.  The last six are parts of "rows" and "pgs"
+ * (which then hold the remainder: the row build proper; the solver's return to joint space); for the register solver
+ * pgs_setup is the AR build and pgs_sweeps the sweeps alone.  n must be 21. */
 int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
                       unsigned long long* h_cycles, int n);
 

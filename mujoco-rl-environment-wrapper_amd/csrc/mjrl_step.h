@@ -167,7 +167,8 @@ enum {
 };
 
 enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_VEL, ST_SMOOTH, ST_ROWS, ST_PROJECT, ST_PGS,
-       ST_SENSORS, ST_EULER, ST_STORE, ST_PGS_WARM, ST_PGS_LISTS, ST_PGS_SWEEPS, ST_ROWS_LIMITS, ST_ROWS_ADDR, N_STAMPS };
+       ST_SENSORS, ST_EULER, ST_STORE, ST_PGS_WARM, ST_PGS_LISTS, ST_PGS_SWEEPS, ST_ROWS_LIMITS, ST_ROWS_ADDR, ST_PGS_SETUP,
+       N_STAMPS };
 
 // The lane's own records of the model, fetched once per launch
 struct LaneK {
@@ -1146,6 +1147,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       MJ_RINIT(8) MJ_RINIT(9) MJ_RINIT(10) MJ_RINIT(11) MJ_RINIT(12) MJ_RINIT(13) MJ_RINIT(14) MJ_RINIT(15)
     } while (0);
 #undef MJ_RINIT
+    MJ_SUBSTAMP(ST_PGS_SETUP)
     const real haii = 0.5 * aii;
     while (iter < m.iterations) {
       // The sweep is bound by instruction issue, so a row step carries the minimum: multiply, subtract, max, subtract,
@@ -1175,9 +1177,12 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       const real dsweep = fi - f_start;
       const real csweep = dsweep * dsweep * haii + dsweep * rs;
       real imp = -csweep;
-      const bool refused = csweep > 1e-10;
-      if (wv::ballot(refused)) {
-        fi = f_start; r = r_start; imp = 0;
+      iter++;
+      real improvement = wv::rows_sum(wv::sum16(imp), m.ntree);
+      // one branch for the two rare outcomes (a condition computed by the vector unit costs ~80 cycles to branch on)
+      if (wv::ballot(csweep > 1e-10 || improvement * scale < m.tolerance)) {
+        if (!wv::ballot(csweep > 1e-10)) break;            // converged
+        fi = f_start; r = r_start; imp = 0;                // some step raised the cost: redo the sweep, guarded
 #define MJ_GSTEP(KK)                                                                  \
         if (KK < tmax) {                                                              \
           real fn = fmax(fi - r * ainv, 0.0);                                         \
@@ -1192,11 +1197,11 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
         MJ_GSTEP(0) MJ_GSTEP(1) MJ_GSTEP(2) MJ_GSTEP(3) MJ_GSTEP(4) MJ_GSTEP(5) MJ_GSTEP(6) MJ_GSTEP(7)
         MJ_GSTEP(8) MJ_GSTEP(9) MJ_GSTEP(10) MJ_GSTEP(11) MJ_GSTEP(12) MJ_GSTEP(13) MJ_GSTEP(14) MJ_GSTEP(15)
 #undef MJ_GSTEP
+        improvement = wv::rows_sum(wv::sum16(imp), m.ntree);
+        if (improvement * scale < m.tolerance) break;
       }
-      iter++;
-      real improvement = wv::rows_sum(wv::sum16(imp), m.ntree);
-      if (improvement * scale < m.tolerance) break;
     }
+    MJ_SUBSTAMP(ST_PGS_SWEEPS)
     if (has_row) Rm[ROW_F] = fi;
     // u = B' f for the lane's dof
     u = 0;

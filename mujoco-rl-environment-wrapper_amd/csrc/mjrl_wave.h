@@ -35,9 +35,11 @@ __device__ __forceinline__ int atomic_add_int(int* p, int v) { return atomicAdd(
 // 64-bit value moved with a DPP control word (two v_mov_b32_dpp); every lane reads a lane of its own row of 16
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
+  // every control word used here reads a lane that exists (permutations inside a row of 16, row_newbcast), so the
+  // "old" operand never shows: passing 0 with bound_ctrl spares the two copies of the source a tied operand costs
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -61,7 +63,7 @@ template <int N>
 __device__ __forceinline__ double bcast16(double v) { return dpp<0x150 + N>(v); }
 
 template <int N>
-__device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + N, 0xF, 0xF, false); }
+__device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, true); }
 
 // all-reduce (sum) inside each row of 16 lanes only
 __device__ __forceinline__ double sum16(double v) { return sum_n(v, 16); }

@@ -27,6 +27,21 @@ __global__ __launch_bounds__(64) void probe(double* out, long long* cyc) {
   t0 = clock64();
   for (int i = 0; i < N / 4; i++) { STEP_BARE(3, a3) STEP_BARE(5, a5) STEP_BARE(7, a7) STEP_BARE(9, a9) }
   t1 = clock64(); if (L == 0) cyc[2] = t1 - t0;
+  // with the early-exit test of the real sweep in front of every step (tmax uniform, unknown to the compiler)
+  int tmax = (int)out[0] + 4;
+  tmax = __builtin_amdgcn_readfirstlane(tmax);
+  t0 = clock64();
+  for (int i = 0; i < N / 4; i++) {
+    do {
+      if (0 >= tmax) break; STEP_FULL(3, a3)
+      if (1 >= tmax) break; STEP_FULL(5, a5)
+      if (2 >= tmax) break; STEP_FULL(7, a7)
+      if (3 >= tmax) break; STEP_FULL(9, a9)
+      if (4 >= tmax) break; STEP_FULL(10, a9)
+      if (5 >= tmax) break; STEP_FULL(11, a9)
+    } while (0);
+  }
+  t1 = clock64(); if (L == 0) cyc[4] = t1 - t0;
   // the u-form step of the pipelined path for comparison: 16-lane reduction per row
   double u = fi, bid = 0.3, dinv = 0.9;
   t0 = clock64();
@@ -49,7 +64,7 @@ int main() {
   for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(probe, dim3(1024), dim3(64), 0, 0, out, cyc);
   hipDeviceSynchronize();
   long long hc[8]; hipMemcpy(hc, cyc, sizeof(hc), hipMemcpyDeviceToHost);
-  const char* names[] = {"row step (captures f and r in the row's lane)", "row step, f captured only", "row step, no capture (chain only)", "u-form step (sum16 reduction)"};
-  for (int k = 0; k < 4; k++) printf("%-48s %8.1f cycles\n", names[k], (double)hc[k] / N);
+  const char* names[] = {"row step (captures f and r in the row's lane)", "row step, f captured only", "row step, no capture (chain only)", "u-form step (sum16 reduction)", "row step behind an early-exit test (4 of 6 run)"};
+  for (int k = 0; k < 5; k++) printf("%-48s %8.1f cycles\n", names[k], (double)hc[k] / N);
   return 0;
 }
