@@ -1060,20 +1060,6 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     wv::sync();
     return;
   }
-  // warm start: keep the forces implied by last step's acceleration only if they beat f = 0
-  if (dof)
-    for (int r = 0; r < nefc; r++) u += coef(r, I[l.i_rowinfo + r]) * S[l.row + ROW_STRIDE * r + ROW_F];
-  real part = 0.5 * dinv * u * u;
-  for (int r = L; r < nefc; r += 64) {
-    const real* R = S + l.row + ROW_STRIDE * r;
-    part += 0.5 * R[ROW_R] * R[ROW_F] * R[ROW_F] + R[ROW_F] * R[ROW_B];
-  }
-  real cost = wv::sum(part);
-  if (cost > 0) {
-    u = 0;
-    for (int r = L; r < nefc; r += 64) S[l.row + ROW_STRIDE * r + ROW_F] = 0;
-  }
-  MJ_SUBSTAMP(ST_PGS_WARM)
   // per-tree row lists (in the row-id array, which the finished row build no longer needs): list[base_t + rank] = row
   const int mytree = L >> 4;
   int cnt_my = 0, base_my = 0, tmax = 0;
@@ -1099,9 +1085,27 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   tmax = wv::first_int(tmax);       // uniform by construction (ballot counts)
   wv::sync();
   MJ_SUBSTAMP(ST_PGS_LISTS)
+  const bool in_registers = m.rowmap && !cross && tmax <= 16;
+  if (!in_registers) {
+    // warm start: keep the forces implied by last step's acceleration only if they beat f = 0
+    if (dof)
+      for (int r = 0; r < nefc; r++) u += coef(r, I[l.i_rowinfo + r]) * S[l.row + ROW_STRIDE * r + ROW_F];
+    real part = 0.5 * dinv * u * u;
+    for (int r = L; r < nefc; r += 64) {
+      const real* R = S + l.row + ROW_STRIDE * r;
+      part += 0.5 * R[ROW_R] * R[ROW_F] * R[ROW_F] + R[ROW_F] * R[ROW_B];
+    }
+    real cost = wv::sum(part);
+    if (cost > 0) {
+      u = 0;
+      for (int r = L; r < nefc; r += 64) S[l.row + ROW_STRIDE * r + ROW_F] = 0;
+    }
+    wv::sync();
+  }
+  MJ_SUBSTAMP(ST_PGS_WARM)
   real scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
   int iter = 0;
-  if (m.rowmap && !cross && tmax <= 16) {
+  if (in_registers) {
     // Residual form, all in registers: with at most 16 rows per tree, lane k of a tree's 16 lanes owns the tree's
     // k-th row -- its force f_k, its row of AR = B D^-1 B' + diag(R) and its residual r_k = (AR f)_k + b_k.  A
     // Gauss-Seidel step on row k is a handful of operations in lane k, one DPP broadcast of the force change and one
@@ -1122,24 +1126,26 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       W[d] = (has_row && d < tn) ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++) A[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k >= tmax) break;
-      real acc = 0;
-      {
-        const int rk = k < cnt_my ? I[l.i_rowid + base_my + k] : 0;
-        const real* Bk = S + l.J + JW * rk;
-        real p0 = 0, p1 = 0, p2 = 0, p3 = 0;      // four partial sums: the 16 terms form chains of 4
-#pragma unroll
-        for (int d = 0; d < 16; d += 4) {
-          p0 += W[d] * Bk[d]; p1 += W[d + 1] * Bk[d + 1]; p2 += W[d + 2] * Bk[d + 2]; p3 += W[d + 3] * Bk[d + 3];
-        }
-        acc = (p0 + p1) + (p2 + p3);
-        if (k >= cnt_my) acc = 0;
-        if (k == kme) acc += Ri;
+    // row k of the tree is owned by lane k of the tree's 16 lanes: its id comes over DPP, not from the list in LDS
+#define MJ_ASTEP(KK)                                                                  \
+      if (KK >= tmax) break;                                                          \
+      {                                                                               \
+        const real* Bk = S + l.J + JW * wv::bcast16i<KK>(myrow);                      \
+        real p0 = 0, p1 = 0, p2 = 0, p3 = 0;      /* four partial sums: the 16 terms form chains of 4 */ \
+        _Pragma("unroll")                                                             \
+        for (int d = 0; d < 16; d += 4) {                                             \
+          p0 += W[d] * Bk[d]; p1 += W[d + 1] * Bk[d + 1]; p2 += W[d + 2] * Bk[d + 2]; p3 += W[d + 3] * Bk[d + 3]; \
+        }                                                                             \
+        real acc = (p0 + p1) + (p2 + p3);                                             \
+        if (KK >= cnt_my) acc = 0;                                                    \
+        if (KK == kme) acc += Ri;                                                     \
+        A[KK] = acc;                                                                  \
       }
-      A[k] = acc;
-    }
+    do {
+      MJ_ASTEP(0) MJ_ASTEP(1) MJ_ASTEP(2) MJ_ASTEP(3) MJ_ASTEP(4) MJ_ASTEP(5) MJ_ASTEP(6) MJ_ASTEP(7)
+      MJ_ASTEP(8) MJ_ASTEP(9) MJ_ASTEP(10) MJ_ASTEP(11) MJ_ASTEP(12) MJ_ASTEP(13) MJ_ASTEP(14) MJ_ASTEP(15)
+    } while (0);
+#undef MJ_ASTEP
     real r = bi;
 #define MJ_RINIT(KK) if (KK >= tmax) break; r += A[KK] * wv::bcast16<KK>(fi);
     do {
@@ -1147,6 +1153,13 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       MJ_RINIT(8) MJ_RINIT(9) MJ_RINIT(10) MJ_RINIT(11) MJ_RINIT(12) MJ_RINIT(13) MJ_RINIT(14) MJ_RINIT(15)
     } while (0);
 #undef MJ_RINIT
+    // warm start: keep last step's forces only if they beat f = 0; cost(f) = 1/2 f'AR f + f'b = 1/2 f'(r + b)
+    {
+      real cost = wv::rows_sum(wv::sum16(0.5 * fi * (r + bi)), m.ntree);
+      const bool cold = cost > 0;
+      fi = cold ? 0.0 : fi;
+      r = cold ? bi : r;
+    }
     MJ_SUBSTAMP(ST_PGS_SETUP)
     const real haii = 0.5 * aii;
     while (iter < m.iterations) {
@@ -1209,7 +1222,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       if (KK >= tmax) break;                                                          \
       {                                                                               \
         real fk = wv::bcast16<KK>(fi);                                                \
-        const int rk = KK < cnt_my ? I[l.i_rowid + base_my + KK] : 0;                 \
+        const int rk = wv::bcast16i<KK>(myrow);                                       \
         if (dof && KK < cnt_my) u += S[l.J + JW * rk + kme] * fk;                     \
       }
     do {
