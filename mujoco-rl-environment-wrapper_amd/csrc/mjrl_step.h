@@ -1171,11 +1171,12 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       // did is redone from its starting point with guarded steps.
       const real f_start = fi, r_start = r;
       real rs = r;
-      // (one scalar test per step that falls through while rows remain, one taken branch at the end of the rows;
-      // the tests are made on per-sweep copies the optimiser cannot see through, or it would precompute 32 masks)
+      // (row steps past the last row are no-ops -- their lanes hold f = r = 0 and a zero column of AR -- so the exit
+      // test, a scalar compare and a branch that costs about a third of a step, is made once per group of steps:
+      // groups of two for the first four rows, of four after that; the tests are made on per-sweep copies the
+      // optimiser cannot see through, or it would precompute a lane mask per step and spill them)
       const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
 #define MJ_FSTEP(KK)                                                                  \
-        if (KK >= tmax_s) break;                                                      \
         {                                                                             \
           real fn = fmax(fi - r * ainv, 0.0);                                         \
           real db = wv::bcast16<KK>(fn - fi);                                         \
@@ -1183,8 +1184,15 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
           r += A[KK] * db;                                                            \
         }
       do {
-        MJ_FSTEP(0) MJ_FSTEP(1) MJ_FSTEP(2) MJ_FSTEP(3) MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7)
-        MJ_FSTEP(8) MJ_FSTEP(9) MJ_FSTEP(10) MJ_FSTEP(11) MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
+        MJ_FSTEP(0) MJ_FSTEP(1)
+        if (2 >= tmax_s) break;
+        MJ_FSTEP(2) MJ_FSTEP(3)
+        if (4 >= tmax_s) break;
+        MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7)
+        if (8 >= tmax_s) break;
+        MJ_FSTEP(8) MJ_FSTEP(9) MJ_FSTEP(10) MJ_FSTEP(11)
+        if (12 >= tmax_s) break;
+        MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
       } while (0);
 #undef MJ_FSTEP
       const real dsweep = fi - f_start;
