@@ -1348,6 +1348,18 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
   bool need_acc = false;
   for (int s = 0; s < m.nsensor; s++) need_acc |= (m.sensor_type[s] == SENS_ACCELEROMETER);
   if (need_acc) stage_velocity(m, l, K, S, L, true);
+  // the lane's geom as a ray target, fetched once for all rangefinders
+  bool any_ray = false;
+  for (int s = 0; s < m.nsensor; s++) any_ray |= (m.sensor_type[s] == SENS_RANGEFINDER);
+  int rg_body = -1, rg_type = -1;
+  real rg_rb = 0;
+  V3 rg_pos = v3(0, 0, 0), rg_size = v3(0, 0, 0);
+  M3 rg_mat = qmat(ldq(S + l.gquat));
+  if (any_ray && L < m.ngeom && m.geom_rgba[4 * L + 3] != 0) {
+    rg_body = m.geom_bodyid[L]; rg_type = m.geom_type[L]; rg_rb = m.geom_rbound[L];
+    rg_pos = ld3(S + l.gpos + 3 * L); rg_size = ld3(m.geom_size + 3 * L);
+    rg_mat = qmat(ldq(S + l.gquat + 4 * L));
+  }
   for (int s = 0; s < m.nsensor; s++) {
     int site = m.sensor_objid[s], adr = m.sensor_adr[s], body = m.site_bodyid[site], type = m.sensor_type[s];
     real cutoff = m.sensor_cutoff[s];
@@ -1357,9 +1369,16 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
     if (type == SENS_RANGEFINDER) {
       V3 vec = col(sm, 2);
       real best = 1e300;
-      if (L < m.ngeom && m.geom_bodyid[L] != body && m.geom_rgba[4 * L + 3] != 0) {
-        real x = ray_geom(m.geom_type[L], ld3(S + l.gpos + 3 * L), qmat(ldq(S + l.gquat + 4 * L)), ld3(m.geom_size + 3 * L),
-                          sp, vec);
+      if (rg_type >= 0 && rg_body != body) {
+        // a geom whose bounding sphere the ray misses (or that lies wholly behind the ray's origin) cannot be hit: it
+        // takes no type-specific test, and a type with no candidate left in the wave costs nothing
+        int gt = rg_type;
+        if (gt != GEOM_PLANE) {
+          V3 rel = rg_pos - sp;
+          real t = dot(rel, vec), d2 = dot(rel, rel) - t * t;
+          if (d2 > rg_rb * rg_rb * (1.0 + 1e-9) + 1e-12 || t + rg_rb < -1e-9) gt = -1;
+        }
+        real x = ray_geom(gt, rg_pos, rg_mat, rg_size, sp, vec);
         if (x >= 0) best = x;
       }
       best = wv::min_pos(best);

@@ -110,9 +110,12 @@ __device__ __forceinline__ void set_priority(int p) {
 __device__ __forceinline__ int first_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ double min_pos(double v) {   // minimum over the wave, every lane gets it
-#pragma unroll
-  for (int mask = 1; mask < 64; mask <<= 1) v = fmin(v, shfl_xor(v, mask));
-  return v;
+  // inside the rows of 16 by DPP, across the four rows by v_readlane (the minimum is exact: any order gives the same)
+  v = fmin(v, dpp<0xB1>(v));
+  v = fmin(v, dpp<0x4E>(v));
+  v = fmin(v, dpp<0x141>(v));
+  v = fmin(v, dpp<0x140>(v));
+  return fmin(fmin(lane_value(v, 0), lane_value(v, 16)), fmin(lane_value(v, 32), lane_value(v, 48)));
 }
 
 }  // namespace wv
