@@ -1160,28 +1160,33 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       fi = cold ? 0.0 : fi;
       r = cold ? bi : r;
     }
+    // The sweeps work on the scaled residual s = r / AR_kk and on AR's rows scaled likewise, which takes one multiply
+    // out of every row step's dependent chain (f - r/AR_kk becomes f - s).
+    real sr = r * ainv;
+#pragma unroll
+    for (int k = 0; k < 16; k++) A[k] *= ainv;
     MJ_SUBSTAMP(ST_PGS_SETUP)
     const real haii = 0.5 * aii;
     while (iter < m.iterations) {
-      // The sweep is bound by instruction issue, so a row step carries the minimum: multiply, subtract, max, subtract,
-      // broadcast, and in the row's own lane a capture of the new force and of the residual it was computed from.
-      // What the reference does per step besides -- the cost change 0.5 d^2 A_kk + d r_k, summed into the sweep's
-      // improvement, and the guard that refuses a step which would raise the cost (change > 1e-10) -- is evaluated
-      // once per sweep from the captured values.  Exact arithmetic never raises the cost; a sweep in which rounding
-      // did is redone from its starting point with guarded steps.
-      const real f_start = fi, r_start = r;
-      real rs = r;
-      // (row steps past the last row are no-ops -- their lanes hold f = r = 0 and a zero column of AR -- so the exit
+      // The sweep is bound by instruction issue and by its dependent chain, so a row step carries the minimum:
+      // subtract, max, subtract, broadcast, multiply-add, and in the row's own lane a capture of the new force and of
+      // the residual it was computed from.  What the reference does per step besides -- the cost change
+      // 0.5 d^2 A_kk + d r_k, summed into the sweep's improvement, and the guard that refuses a step which would raise
+      // the cost (change > 1e-10) -- is evaluated once per sweep from the captured values.  Exact arithmetic never
+      // raises the cost; a sweep in which rounding did is redone from its starting point with guarded steps.
+      const real f_start = fi, s_start = sr;
+      real ss = sr;
+      // (row steps past the last row are no-ops -- their lanes hold f = s = 0 and a zero column of AR -- so the exit
       // test, a scalar compare and a branch that costs about a third of a step, is made once per group of steps:
       // groups of two for the first four rows, of four after that; the tests are made on per-sweep copies the
       // optimiser cannot see through, or it would precompute a lane mask per step and spill them)
       const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
 #define MJ_FSTEP(KK)                                                                  \
         {                                                                             \
-          real fn = fmax(fi - r * ainv, 0.0);                                         \
+          real fn = fmax(fi - sr, 0.0);                                               \
           real db = wv::bcast16<KK>(fn - fi);                                         \
-          if (kme_s == KK) { fi = fn; rs = r; }                                       \
-          r += A[KK] * db;                                                            \
+          if (kme_s == KK) { fi = fn; ss = sr; }                                      \
+          sr += A[KK] * db;                                                           \
         }
       do {
         MJ_FSTEP(0) MJ_FSTEP(1)
@@ -1196,24 +1201,24 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       } while (0);
 #undef MJ_FSTEP
       const real dsweep = fi - f_start;
-      const real csweep = dsweep * dsweep * haii + dsweep * rs;
+      const real csweep = dsweep * dsweep * haii + dsweep * (ss * aii);
       real imp = -csweep;
       iter++;
       real improvement = wv::rows_sum(wv::sum16(imp), m.ntree);
       // one branch for the two rare outcomes (a condition computed by the vector unit costs ~80 cycles to branch on)
       if (wv::ballot(csweep > 1e-10 || improvement * scale < m.tolerance)) {
         if (!wv::ballot(csweep > 1e-10)) break;            // converged
-        fi = f_start; r = r_start; imp = 0;                // some step raised the cost: redo the sweep, guarded
+        fi = f_start; sr = s_start; imp = 0;               // some step raised the cost: redo the sweep, guarded
 #define MJ_GSTEP(KK)                                                                  \
         if (KK < tmax) {                                                              \
-          real fn = fmax(fi - r * ainv, 0.0);                                         \
+          real fn = fmax(fi - sr, 0.0);                                               \
           real delta = fn - fi;                                                       \
-          real change = delta * delta * haii + delta * r;                             \
+          real change = delta * delta * haii + delta * (sr * aii);                    \
           bool act = kme == KK && has_row && !(change > 1e-10);                       \
           if (!act) { delta = 0; change = 0; fn = fi; }                               \
           fi = fn;                                                                    \
           imp -= change;                                                              \
-          r += A[KK] * wv::bcast16<KK>(delta);                                        \
+          sr += A[KK] * wv::bcast16<KK>(delta);                                       \
         }
         MJ_GSTEP(0) MJ_GSTEP(1) MJ_GSTEP(2) MJ_GSTEP(3) MJ_GSTEP(4) MJ_GSTEP(5) MJ_GSTEP(6) MJ_GSTEP(7)
         MJ_GSTEP(8) MJ_GSTEP(9) MJ_GSTEP(10) MJ_GSTEP(11) MJ_GSTEP(12) MJ_GSTEP(13) MJ_GSTEP(14) MJ_GSTEP(15)

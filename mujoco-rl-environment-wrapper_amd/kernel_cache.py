@@ -65,6 +65,8 @@ def hipcc() -> str | None:
 def code_object(blob: bytes, build: bool = True) -> str | None:
     """Path of the code object for this blob's shape; built on a cache miss when hipcc is present, else None."""
     sizes = blob_sizes(blob)
+    if os.environ.get("MJRL_SPEC_OBJECT"):       # experiments only: A/B a saved code object of the same model shape
+        return os.environ["MJRL_SPEC_OBJECT"]
     path = object_path(sizes)
     if os.path.exists(path):
         return path
