@@ -1167,20 +1167,28 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     for (int k = 0; k < 16; k++) A[k] *= ainv;
     MJ_SUBSTAMP(ST_PGS_SETUP)
     const real haii = 0.5 * aii;
+    // The sweep is bound by instruction issue and by its dependent chain, so a row step carries the minimum: subtract,
+    // max, subtract, broadcast, multiply-add, and in the row's own lane a capture of the new force and of the residual
+    // it was computed from.  What the reference does per step besides -- the cost change 0.5 d^2 A_kk + d r_k, summed
+    // into the sweep's improvement, and the guard that refuses a step which would raise the cost (change > 1e-10) --
+    // is evaluated once per sweep from the captured values, and ONE SWEEP LATE: the 64-lane sum of sweep n's
+    // improvement and the branch on it run in the shadow of the first two row steps of sweep n+1.  When sweep n turns
+    // out to have converged, the two steps are dropped (the forces go back to the end of sweep n) -- the reference's
+    // result and sweep count exactly.  Exact arithmetic never raises the cost; if rounding did in some step, the
+    // solve resumes from the start of that sweep with guarded sweeps that check at once.
+    real f_start = fi, s_start = sr;           // start of the sweep in progress
+    real f_prev = fi, s_prev = sr;             // start of the sweep before it
+    real c_prev = 0;                           // cost change of the lane's row in the sweep before (pending decision)
+    bool pending = false, guarded = false;
     while (iter < m.iterations) {
-      // The sweep is bound by instruction issue and by its dependent chain, so a row step carries the minimum:
-      // subtract, max, subtract, broadcast, multiply-add, and in the row's own lane a capture of the new force and of
-      // the residual it was computed from.  What the reference does per step besides -- the cost change
-      // 0.5 d^2 A_kk + d r_k, summed into the sweep's improvement, and the guard that refuses a step which would raise
-      // the cost (change > 1e-10) -- is evaluated once per sweep from the captured values.  Exact arithmetic never
-      // raises the cost; a sweep in which rounding did is redone from its starting point with guarded steps.
-      const real f_start = fi, s_start = sr;
-      real ss = sr;
       // (row steps past the last row are no-ops -- their lanes hold f = s = 0 and a zero column of AR -- so the exit
       // test, a scalar compare and a branch that costs about a third of a step, is made once per group of steps:
       // groups of two for the first four rows, of four after that; the tests are made on per-sweep copies the
       // optimiser cannot see through, or it would precompute a lane mask per step and spill them)
       const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
+      f_start = fi; s_start = sr;
+      real ss = sr;
+      const real improvement = wv::rows_sum(wv::sum16(-c_prev), m.ntree);      // of the sweep before
 #define MJ_FSTEP(KK)                                                                  \
         {                                                                             \
           real fn = fmax(fi - sr, 0.0);                                               \
@@ -1188,8 +1196,15 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
           if (kme_s == KK) { fi = fn; ss = sr; }                                      \
           sr += A[KK] * db;                                                           \
         }
+      MJ_FSTEP(0) MJ_FSTEP(1)
+      // one branch for the two rare outcomes (a condition computed by the vector unit costs ~80 cycles to branch on)
+      if (pending && wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
+        if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
+        else { fi = f_start; sr = s_start; }                                                    // it had converged
+        pending = false;
+        break;
+      }
       do {
-        MJ_FSTEP(0) MJ_FSTEP(1)
         if (2 >= tmax_s) break;
         MJ_FSTEP(2) MJ_FSTEP(3)
         if (4 >= tmax_s) break;
@@ -1201,31 +1216,32 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       } while (0);
 #undef MJ_FSTEP
       const real dsweep = fi - f_start;
-      const real csweep = dsweep * dsweep * haii + dsweep * (ss * aii);
-      real imp = -csweep;
+      c_prev = dsweep * dsweep * haii + dsweep * (ss * aii);
+      f_prev = f_start; s_prev = s_start;
+      pending = true;
       iter++;
-      real improvement = wv::rows_sum(wv::sum16(imp), m.ntree);
-      // one branch for the two rare outcomes (a condition computed by the vector unit costs ~80 cycles to branch on)
-      if (wv::ballot(csweep > 1e-10 || improvement * scale < m.tolerance)) {
-        if (!wv::ballot(csweep > 1e-10)) break;            // converged
-        fi = f_start; sr = s_start; imp = 0;               // some step raised the cost: redo the sweep, guarded
+    }
+    if (pending && wv::ballot(c_prev > 1e-10)) {      // the sweep cap was reached and the last sweep has a refused step
+      fi = f_prev; sr = s_prev; iter--; guarded = true;
+    }
+    while (guarded && iter < m.iterations) {
+      real imp = 0;
 #define MJ_GSTEP(KK)                                                                  \
-        if (KK < tmax) {                                                              \
-          real fn = fmax(fi - sr, 0.0);                                               \
-          real delta = fn - fi;                                                       \
-          real change = delta * delta * haii + delta * (sr * aii);                    \
-          bool act = kme == KK && has_row && !(change > 1e-10);                       \
-          if (!act) { delta = 0; change = 0; fn = fi; }                               \
-          fi = fn;                                                                    \
-          imp -= change;                                                              \
-          sr += A[KK] * wv::bcast16<KK>(delta);                                       \
-        }
-        MJ_GSTEP(0) MJ_GSTEP(1) MJ_GSTEP(2) MJ_GSTEP(3) MJ_GSTEP(4) MJ_GSTEP(5) MJ_GSTEP(6) MJ_GSTEP(7)
-        MJ_GSTEP(8) MJ_GSTEP(9) MJ_GSTEP(10) MJ_GSTEP(11) MJ_GSTEP(12) MJ_GSTEP(13) MJ_GSTEP(14) MJ_GSTEP(15)
-#undef MJ_GSTEP
-        improvement = wv::rows_sum(wv::sum16(imp), m.ntree);
-        if (improvement * scale < m.tolerance) break;
+      if (KK < tmax) {                                                                \
+        real fn = fmax(fi - sr, 0.0);                                                 \
+        real delta = fn - fi;                                                         \
+        real change = delta * delta * haii + delta * (sr * aii);                      \
+        bool act = kme == KK && has_row && !(change > 1e-10);                         \
+        if (!act) { delta = 0; change = 0; fn = fi; }                                 \
+        fi = fn;                                                                      \
+        imp -= change;                                                                \
+        sr += A[KK] * wv::bcast16<KK>(delta);                                         \
       }
+      MJ_GSTEP(0) MJ_GSTEP(1) MJ_GSTEP(2) MJ_GSTEP(3) MJ_GSTEP(4) MJ_GSTEP(5) MJ_GSTEP(6) MJ_GSTEP(7)
+      MJ_GSTEP(8) MJ_GSTEP(9) MJ_GSTEP(10) MJ_GSTEP(11) MJ_GSTEP(12) MJ_GSTEP(13) MJ_GSTEP(14) MJ_GSTEP(15)
+#undef MJ_GSTEP
+      iter++;
+      if (wv::rows_sum(wv::sum16(imp), m.ntree) * scale < m.tolerance) break;
     }
     MJ_SUBSTAMP(ST_PGS_SWEEPS)
     if (has_row) Rm[ROW_F] = fi;
