@@ -420,6 +420,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
   if (e->frames && skip_frames > 0) e->frames_valid = true;
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
+  if (const char* pad = getenv("MJRL_LDS_BYTES")) lds_bytes = std::max(lds_bytes, (size_t)atoi(pad));   // experiments: residency
   // The kernel advances one physics frame; a step of skipFrames frames (mujoco_parent.py:333-336) is that many launches
   // on the stream.  The action scatter belongs to the first, everything after the physics (frame cache, debug dump,
   // counters, observations, plugin ops) to the last.
