@@ -122,9 +122,10 @@ int mjrl_step_debug(mjrl_env* env, const double* d_actions, int act_dim, int ski
 int mjrl_lds_offset(const mjrl_env* env, const char* region);
 /* Diagnostic: one step with per-stage wave-clock stamps; h_cycles[n] receives, per stage, the cycles summed over all
  * env copies.  Stage order: load kin com crb factor geom collide vel smooth rows project pgs sensors euler store
- * pgs_warm pgs_lists pgs_sweeps rows_limits rows_addr pgs_setup.  The last six are parts of "rows" and "pgs"
+ * pgs_warm pgs_lists pgs_sweeps rows_limits rows_addr pgs_setup tail.  "tail" is what follows the state store (work-bucket
+ * filing, truncation flags, fused plugin ops); the six before it are parts of "rows" and "pgs"
  * (which then hold the remainder: the row build proper; the solver's return to joint space); for the register solver
- * pgs_setup is the AR build and pgs_sweeps the sweeps alone.  n must be 21. */
+ * pgs_setup is the AR build and pgs_sweeps the sweeps alone.  n must be 22. */
 int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
                       unsigned long long* h_cycles, int n);
 

@@ -218,7 +218,7 @@ class Handle:
         return out
 
     STAGES = ["load", "kin", "com", "crb", "factor", "geom", "collide", "vel", "smooth", "rows", "project", "pgs",
-              "sensors", "euler", "store", "pgs_warm", "pgs_lists", "pgs_sweeps", "rows_limits", "rows_addr", "pgs_setup"]
+              "sensors", "euler", "store", "pgs_warm", "pgs_lists", "pgs_sweeps", "rows_limits", "rows_addr", "pgs_setup", "tail"]
 
     def step_profile(self, skip_frames=1):
         out = np.zeros(len(self.STAGES), np.uint64)

@@ -168,7 +168,7 @@ enum {
 
 enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_VEL, ST_SMOOTH, ST_ROWS, ST_PROJECT, ST_PGS,
        ST_SENSORS, ST_EULER, ST_STORE, ST_PGS_WARM, ST_PGS_LISTS, ST_PGS_SWEEPS, ST_ROWS_LIMITS, ST_ROWS_ADDR, ST_PGS_SETUP,
-       N_STAMPS };
+       ST_TAIL, N_STAMPS };
 
 // The lane's own records of the model, fetched once per launch
 struct LaneK {
@@ -1532,6 +1532,25 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   MJ_FOR(i, m.nq) S[l.qpos + i] = a.qpos[(size_t)env * m.nq + i];
   MJ_FOR(i, m.nv) { S[l.qvel + i] = a.qvel[(size_t)env * m.nv + i]; S[l.warm + i] = a.warm[(size_t)env * m.nv + i]; }
   MJ_FOR(i, m.nu) S[l.ctrl + i] = a.ctrl[(size_t)env * m.nu + i];
+  // what the end of the step reads from HBM is fetched now, one element per lane, so that no load latency is left
+  // exposed after the integrator: the step counter and, for the fused plugin ops, the copy's action row and its
+  // data-store row (staged in the dead bias-force vector once the integrator is done; a program too large for that
+  // reads HBM directly)
+  const int ts = a.forward_only ? 0 : a.timestep[env];
+  // staging area at the end of the step: the five nv-vectors from the bias forces on, all dead after the integrator
+  //   [action row | data-store row | prog_f (4 per op) | prog_i (8 ints per op) | obs_len, agent_body (ints)]
+  const int n_act_row = a.n_agent * a.act_dim, n_store_row = a.n_agent * a.n_slot;
+  const int t_store = n_act_row, t_pf = t_store + n_store_row, t_pi = t_pf + 4 * a.n_op, t_ag = t_pi + 4 * a.n_op;
+  const bool ops_staged = a.n_op > 0 && t_ag + a.n_agent <= 5 * m.nv && n_act_row <= 64 && 8 * a.n_op <= 64;
+  real act_reg = 0, store_reg = 0, pf_reg = 0;
+  int pi_reg = 0, len_reg = 0, body_reg = 0;
+  if (ops_staged) {
+    if (a.actions && L < n_act_row) act_reg = a.actions[(size_t)env * n_act_row + L];
+    if (a.store && L < n_store_row) store_reg = a.store[(size_t)env * n_store_row + L];
+    if (L < 4 * a.n_op) pf_reg = a.prog_f[L];
+    if (L < 8 * a.n_op) pi_reg = a.prog_i[L];
+    if (L < a.n_agent) { len_reg = a.agent_obs_len[L]; body_reg = a.agent_body[L]; }
+  }
   stage_constants(m, l, S, L);
   wv::sync();
   // scatter the physical part of every agent's action (mujoco_parent.py:323-332)
@@ -1593,6 +1612,15 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       }
     }
     if (!a.forward_only) stage_euler(m, l, K, RK, S, L);
+    if (ops_staged) {
+      int* TI = (int*)(S + l.bias);
+      if (L < n_act_row) S[l.bias + L] = act_reg;
+      if (L < n_store_row) S[l.bias + t_store + L] = store_reg;
+      if (L < 4 * a.n_op) S[l.bias + t_pf + L] = pf_reg;
+      if (L < 8 * a.n_op) TI[2 * t_pi + L] = pi_reg;
+      if (L < a.n_agent) { TI[2 * t_ag + L] = len_reg; TI[2 * t_ag + a.n_agent + L] = body_reg; }
+      wv::sync();
+    }
     MJ_STAMP(ST_EULER)
   }
   // state out
@@ -1618,8 +1646,6 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     }
   }
   MJ_STAMP(ST_STORE)
-#undef MJ_STAMP
-  if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
   if (a.lpt_count_out && L == 0) {
     const int* I = (const int*)(S + l.ints);
     unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
@@ -1629,9 +1655,12 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     int pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
     a.lpt_list_out[(size_t)b * a.n_env + pos] = env;
   }
-  if (a.forward_only || a.more_frames) return;
+  if (a.forward_only || a.more_frames) {
+    MJ_STAMP(ST_TAIL)
+    if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+    return;
+  }
   // truncation is evaluated before the counter moves (mujoco_rl.py:279,288)
-  int ts = a.timestep[env];
   MJ_FOR(ag, a.n_agent) {
     if (a.trunc) a.trunc[(size_t)env * a.n_agent + ag] = ts >= a.max_steps;
   }
@@ -1640,11 +1669,18 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     real rew[MAX_AGENT];
     bool term[MAX_AGENT];
     for (int ag = 0; ag < a.n_agent; ag++) { rew[ag] = 0; term[ag] = false; }
-    const real* act = a.actions ? a.actions + (size_t)env * a.n_agent * a.act_dim : nullptr;
-    real* store = a.store ? a.store + (size_t)env * a.n_agent * a.n_slot : nullptr;
+    // the action row and the data-store row of this copy: staged in LDS (see the load stage) or read from HBM
+    const real* act = ops_staged ? (a.actions ? S + l.bias : nullptr)
+                                 : (a.actions ? a.actions + (size_t)env * a.n_agent * a.act_dim : nullptr);
+    real* store = ops_staged ? S + l.bias + t_store : (a.store ? a.store + (size_t)env * a.n_agent * a.n_slot : nullptr);
+    const int* TI = (const int*)(S + l.bias);
+    const real* prog_f = ops_staged ? S + l.bias + t_pf : a.prog_f;
+    const int32_t* prog_i = ops_staged ? (const int32_t*)(TI + 2 * t_pi) : a.prog_i;
+    const int32_t* obs_len = ops_staged ? (const int32_t*)(TI + 2 * t_ag) : a.agent_obs_len;
+    const int32_t* agent_body = ops_staged ? (const int32_t*)(TI + 2 * t_ag + a.n_agent) : a.agent_body;
     for (int op = 0; op < a.n_op; op++) {
-      const int32_t* pi = a.prog_i + 8 * op;
-      const real* pf = a.prog_f + 4 * op;
+      const int32_t* pi = prog_i + 8 * op;
+      const real* pf = prog_f + 4 * op;
       for (int ag = 0; ag < a.n_agent; ag++) {
         if (pi[0] == OP_LANGUAGE) {
           real utter = act ? (real)(long long)act[ag * a.act_dim + pi[1]] : 0.0;
@@ -1652,9 +1688,9 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
           int other = ag == 0 ? 1 : 0;
           real heard = other < a.n_agent ? store[other * a.n_slot + pi[2]] : 0.0;
           if (heard != heard) heard = 0.0;
-          if (a.obs) a.obs[((size_t)env * a.n_agent + ag) * a.obs_dim + a.agent_obs_len[ag] + pi[3]] = heard;
+          if (a.obs) a.obs[((size_t)env * a.n_agent + ag) * a.obs_dim + obs_len[ag] + pi[3]] = heard;
         } else {
-          int body = a.agent_body[ag];
+          int body = agent_body[ag];
           V3 p = ld3(S + l.xpos + 3 * body) + rot(ldq(S + l.xquat + 4 * body), ld3(m.body_ipos + 3 * body));
           V3 t;
           if (pi[1] == 0) t = ld3(S + l.xpos + 3 * pi[2]) + rot(ldq(S + l.xquat + 4 * pi[2]), ld3(m.body_ipos + 3 * pi[2]));
@@ -1681,7 +1717,11 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     }
   }
   wv::sync();
+  if (ops_staged && a.store && L < n_store_row) a.store[(size_t)env * n_store_row + L] = S[l.bias + t_store + L];
   if (L == 0) a.timestep[env] = ts + 1;
+  MJ_STAMP(ST_TAIL)
+  if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+#undef MJ_STAMP
 #undef MJ_FOR
 }
 
