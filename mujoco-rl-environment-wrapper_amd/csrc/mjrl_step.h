@@ -1029,6 +1029,156 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
   wv::sync();
 }
 
+// The register solver for the rare heavy step: at most two kinematic trees and 17..32 rows in one of them (an ant
+// resting on many geoms).  Tree t's row k sits in lane 16 t + (k & 15) + 32 (k >> 4): rows 0..15 in the tree's
+// row of 16 lanes, rows 16..31 in the row of 16 lanes two further up, which a model with two trees leaves idle.  A
+// force change is broadcast inside its row of 16 by DPP and handed to the other half of the wave by one
+// v_permlane32_swap per dword.  Same algorithm, guard and sweep count as the 16-row solver in stage_pgs; without
+// this path such a copy -- the slowest of nearly every launch of 4096 -- ran the LDS-pipelined sweep at three times
+// the cost per row step.  Returns u = B' f for the lane's dof.
+template <int K>
+__device__ __forceinline__ real wide_bcast(real v) {
+  if constexpr (K < 16) return wv::half_to_all<false>(wv::bcast16<K>(v));
+  else return wv::half_to_all<true>(wv::bcast16<K - 16>(v));
+}
+#define MJ_ROWS32(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+                     X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+// (A real function, not inlined: inlined into the step kernel its 32 unrolled row steps drove the kernel's register
+// allocation to 512 VGPRs plus scratch.  It takes plain values only -- a reference to the model or the layout would
+// force those structs into memory.)
+struct WideArgs {
+  int o_rowid, o_row, o_J, o_Dinv;      // LDS offsets (Lay)
+  int iterations, adr0, tn;             // sweep cap; first dof and dof count of the lane's tree
+  real tolerance, scale;
+};
+__device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int* I, int L, int cnt_w, int base_w, int tmax,
+                                                             bool dof, WideArgs w, int* iter_io) {
+  struct { int i_rowid, row, J, Dinv; } l = {w.o_rowid, w.o_row, w.o_J, w.o_Dinv};
+  struct { int iterations; real tolerance; } m = {w.iterations, w.tolerance};
+  const real scale = w.scale;
+  int iter = wv::first_int(*iter_io);
+  tmax = wv::first_int(tmax);              // (arguments arrive in vector registers; these two are wave-uniform)
+  m.iterations = wv::first_int(m.iterations);
+  const int tree = (L >> 4) & 1;
+  (void)tree;
+  const int kme = (L & 15) + 16 * (L >> 5);
+  const bool has_row = kme < cnt_w;
+  const int myrow = has_row ? I[l.i_rowid + base_w + kme] : 0;
+  real* Rm = S + l.row + ROW_STRIDE * myrow;
+  real fi = has_row ? Rm[ROW_F] : 0.0, bi = has_row ? Rm[ROW_B] : 0.0, Ri = has_row ? Rm[ROW_R] : 0.0;
+  const real aii = has_row ? Rm[ROW_ARII] : 1.0;
+  const real ainv = 1.0 / aii;
+  const int adr0 = w.adr0, tn = w.tn;
+  real W[16], A[32];
+#pragma unroll
+  for (int d = 0; d < 16; d++)
+    W[d] = (has_row && d < tn) ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 32; k++) A[k] = 0;
+#define MJ_ASTEP(KK)                                                                  \
+    if (KK >= tmax) break;                                                            \
+    {                                                                                 \
+      const real* Bk = S + l.J + JW * (KK < cnt_w ? I[l.i_rowid + base_w + KK] : 0);  \
+      real p0 = 0, p1 = 0, p2 = 0, p3 = 0;                                            \
+      _Pragma("unroll")                                                               \
+      for (int d = 0; d < 16; d += 4) {                                               \
+        p0 += W[d] * Bk[d]; p1 += W[d + 1] * Bk[d + 1]; p2 += W[d + 2] * Bk[d + 2]; p3 += W[d + 3] * Bk[d + 3]; \
+      }                                                                               \
+      real acc = (p0 + p1) + (p2 + p3);                                               \
+      if (KK >= cnt_w) acc = 0;                                                       \
+      if (KK == kme) acc += Ri;                                                       \
+      A[KK] = acc;                                                                    \
+    }
+  do { MJ_ROWS32(MJ_ASTEP) } while (0);
+#undef MJ_ASTEP
+  real r = bi;
+#define MJ_RINIT(KK) if (KK >= tmax) break; r += A[KK] * wide_bcast<KK>(fi);
+  do { MJ_ROWS32(MJ_RINIT) } while (0);
+#undef MJ_RINIT
+  {
+    real cost = wv::rows4_sum(wv::sum16(0.5 * fi * (r + bi)));
+    const bool cold = cost > 0;
+    fi = cold ? 0.0 : fi;
+    r = cold ? bi : r;
+  }
+  real sr = r * ainv;
+#pragma unroll
+  for (int k = 0; k < 32; k++) A[k] *= ainv;
+  const real haii = 0.5 * aii;
+  real f_start = fi, s_start = sr, f_prev = fi, s_prev = sr, c_prev = 0;
+  bool pending = false, guarded = false;
+  while (iter < m.iterations) {
+    const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
+    f_start = fi; s_start = sr;
+    real ss = sr;
+    const real improvement = wv::rows4_sum(wv::sum16(-c_prev));      // of the sweep before
+#define MJ_FSTEP(KK)                                                                  \
+      {                                                                               \
+        real fn = fmax(fi - sr, 0.0);                                                 \
+        real db = wide_bcast<KK>(fn - fi);                                            \
+        if (kme_s == KK) { fi = fn; ss = sr; }                                        \
+        sr += A[KK] * db;                                                             \
+      }
+    MJ_FSTEP(0) MJ_FSTEP(1)
+    if (pending && wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
+      if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
+      else { fi = f_start; sr = s_start; }
+      pending = false;
+      break;
+    }
+    MJ_FSTEP(2) MJ_FSTEP(3) MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7) MJ_FSTEP(8) MJ_FSTEP(9)
+    MJ_FSTEP(10) MJ_FSTEP(11) MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
+    MJ_FSTEP(16) MJ_FSTEP(17) MJ_FSTEP(18) MJ_FSTEP(19)
+    do {
+      if (20 >= tmax_s) break;
+      MJ_FSTEP(20) MJ_FSTEP(21) MJ_FSTEP(22) MJ_FSTEP(23)
+      if (24 >= tmax_s) break;
+      MJ_FSTEP(24) MJ_FSTEP(25) MJ_FSTEP(26) MJ_FSTEP(27)
+      if (28 >= tmax_s) break;
+      MJ_FSTEP(28) MJ_FSTEP(29) MJ_FSTEP(30) MJ_FSTEP(31)
+    } while (0);
+#undef MJ_FSTEP
+    const real dsweep = fi - f_start;
+    c_prev = dsweep * dsweep * haii + dsweep * (ss * aii);
+    f_prev = f_start; s_prev = s_start;
+    pending = true;
+    iter++;
+  }
+  if (pending && wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
+  while (guarded && iter < m.iterations) {
+    real imp = 0;
+#define MJ_GSTEP(KK)                                                                  \
+    if (KK < tmax) {                                                                  \
+      real fn = fmax(fi - sr, 0.0);                                                   \
+      real delta = fn - fi;                                                           \
+      real change = delta * delta * haii + delta * (sr * aii);                        \
+      bool act = kme == KK && has_row && !(change > 1e-10);                           \
+      if (!act) { delta = 0; change = 0; fn = fi; }                                   \
+      fi = fn;                                                                        \
+      imp -= change;                                                                  \
+      sr += A[KK] * wide_bcast<KK>(delta);                                            \
+    }
+    MJ_ROWS32(MJ_GSTEP)
+#undef MJ_GSTEP
+    iter++;
+    if (wv::rows4_sum(wv::sum16(imp)) * scale < m.tolerance) break;
+  }
+  if (has_row) Rm[ROW_F] = fi;
+  real u = 0;
+#define MJ_USTEP(KK)                                                                  \
+    if (KK >= tmax) break;                                                            \
+    {                                                                                 \
+      real fk = wide_bcast<KK>(fi);                                                   \
+      const int rk = KK < cnt_w ? I[l.i_rowid + base_w + KK] : 0;                     \
+      if (dof && KK < cnt_w) u += S[l.J + JW * rk + (L & 15)] * fk;                   \
+    }
+  do { MJ_ROWS32(MJ_USTEP) } while (0);
+#undef MJ_USTEP
+  *iter_io = iter;
+  return u;
+}
+#undef MJ_ROWS32
+
 // projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed: the lane that
 // owns dof d carries u_d = (B' f)_d, a row's residual is one reduction over its tree's lanes, its update one
 // multiply-add.  In the tree-row lane map a constraint row that touches one kinematic tree only involves that tree's
@@ -1063,6 +1213,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   // per-tree row lists (in the row-id array, which the finished row build no longer needs): list[base_t + rank] = row
   const int mytree = L >> 4;
   int cnt_my = 0, base_my = 0, tmax = 0;
+  int cnt_w = 0, base_w = 0;        // the same for the lane's tree in the wide map of pgs_wide_registers
   bool cross = false;
   if (m.rowmap) {
     int total = 0;
@@ -1078,6 +1229,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
         if (t == 0) cross |= wv::ballot(rt == -2) != 0ull;
       }
       if (t == mytree) { cnt_my = cnt; base_my = total; }
+      if (t == ((L >> 4) & 1)) { cnt_w = cnt; base_w = total; }
       total += cnt;
       tmax = cnt > tmax ? cnt : tmax;
     }
@@ -1085,7 +1237,8 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   tmax = wv::first_int(tmax);       // uniform by construction (ballot counts)
   wv::sync();
   MJ_SUBSTAMP(ST_PGS_LISTS)
-  const bool in_registers = m.rowmap && !cross && tmax <= 16;
+  const bool wide = m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree <= 2;
+  const bool in_registers = (m.rowmap && !cross && tmax <= 16) || wide;
   if (!in_registers) {
     // warm start: keep the forces implied by last step's acceleration only if they beat f = 0
     if (dof)
@@ -1105,7 +1258,16 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   MJ_SUBSTAMP(ST_PGS_WARM)
   real scale = 1.0 / (m.meaninertia * (m.nv > 1 ? m.nv : 1));
   int iter = 0;
-  if (in_registers) {
+  if (wide) {
+    const int wtree = (L >> 4) & 1;
+    WideArgs w;
+    w.o_rowid = l.i_rowid; w.o_row = l.row; w.o_J = l.J; w.o_Dinv = l.Dinv;
+    w.iterations = m.iterations; w.tolerance = m.tolerance; w.scale = scale;
+    w.adr0 = wtree < m.ntree ? m.tree_dofadr[wtree] : 0;
+    w.tn = wtree < m.ntree ? m.tree_dofnum[wtree] : 0;
+    u = pgs_wide_registers(S, I, L, cnt_w, base_w, tmax, dof, w, &iter);
+    wv::sync();
+  } else if (in_registers) {
     // Residual form, all in registers: with at most 16 rows per tree, lane k of a tree's 16 lanes owns the tree's
     // k-th row -- its force f_k, its row of AR = B D^-1 B' + diag(R) and its residual r_k = (AR f)_k + b_k.  A
     // Gauss-Seidel step on row k is a handful of operations in lane k, one DPP broadcast of the force change and one

@@ -65,6 +65,18 @@ __device__ __forceinline__ double bcast16(double v) { return dpp<0x150 + N>(v); 
 template <int N>
 __device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, true); }
 
+// the caller's value from the lower (HIGH = false) or upper half of the wave, in both halves: lane i and lane i + 32
+// both get lane (i + 32 HIGH)'s value.  One v_permlane32_swap per dword (gfx950).
+template <bool HIGH>
+__device__ __forceinline__ int half_to_all_i(int v) {
+  auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return HIGH ? r[1] : r[0];
+}
+template <bool HIGH>
+__device__ __forceinline__ double half_to_all(double v) {
+  return __hiloint2double(half_to_all_i<HIGH>(__double2hiint(v)), half_to_all_i<HIGH>(__double2loint(v)));
+}
+
 // all-reduce (sum) inside each row of 16 lanes only
 __device__ __forceinline__ double sum16(double v) { return sum_n(v, 16); }
 

@@ -292,3 +292,53 @@ def test_general_paths_without_the_lane_map():
     img = emu.step(dbg_stage=1); ora.step()
     n = ora.nefc
     assert n >= 4 and np.allclose(img.J()[:n], ora.efc_J[:n], atol=1e-12)
+
+
+def _pose_with_many_rows_in_one_tree(model, packed):
+    """An agent lowered onto the floor with slightly bent legs: four foot contacts (16 rows) plus its active joint
+    limits put 17..32 rows in its tree.  Found with the oracle alone."""
+    tree, gbody = model.body_treeid, model.geom_bodyid
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == 0]
+    a0 = int(model.jnt_qposadr[free[0]])
+    hinge_q = [int(model.jnt_qposadr[j]) for j in range(model.njnt) if model.jnt_type[j] == 3]
+    rng = np.random.default_rng(1)
+    probe = OracleEnv(packed)
+    for dz in np.linspace(-0.55, -0.95, 9):
+        for trial in range(6):
+            q = model.qpos0.copy()
+            q[a0 + 2] += dz
+            if trial:
+                q[hinge_q] += rng.uniform(-0.3, 0.3, len(hinge_q))
+            probe.qpos[:] = q; probe.qvel[:] = 0
+            probe.forward()
+            rows = [0] * model.ntree
+            for c in probe.contacts():
+                t = max(int(tree[gbody[c["geom1"]]]), int(tree[gbody[c["geom2"]]]))
+                if t >= 0:
+                    rows[t] += 4
+            if rows[0] == 16 and probe.nefc > sum(rows):
+                return q
+    return None
+
+
+def test_wide_register_solver_for_17_to_32_rows_per_tree():
+    """More than 16 constraint rows in a tree (an ant on its four feet with joints at their limits): the solver then
+    keeps 32 rows per tree in registers (pgs_wide_registers).  Sweep counts must still be the oracle's, step for
+    step."""
+    model, ora, emu = pair("two_agent.xml")
+    q = _pose_with_many_rows_in_one_tree(model, blob.pack(model))
+    assert q is not None
+    ora.qpos[:] = q; emu.qpos[:] = q
+    wide_steps = 0
+    rng = np.random.default_rng(4)
+    for k in range(60):
+        ctrl = rng.uniform(-1, 1, model.nu)
+        ora.ctrl[:] = ctrl; emu.ctrl[:] = ctrl
+        img = emu.step(); ora.step()
+        assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter), k
+        info_at = img._off("i_rowinfo")
+        trees = (img.ints[info_at:info_at + img.nefc] >> 19) - 2
+        per_tree = [int((trees == t).sum()) for t in range(model.ntree)]
+        wide_steps += bool((trees >= 0).all() and 16 < max(per_tree) <= 32)
+    assert wide_steps > 0
+    assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
