@@ -431,3 +431,35 @@ def test_general_paths_and_two_chain_rows_on_the_gpu():
     assert seen[0] > 0 and seen[1] > 0
     assert rel(h.get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
     assert rel(h.get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
+
+
+def test_wide_register_solver_on_the_gpu():
+    """17..32 constraint rows in one kinematic tree (an ant on its four feet with joints at their limits) take the
+    32-rows-per-tree register solver (pgs_wide_registers, a real function call inside the kernel)."""
+    from tests.test_emu_parity import _pose_with_many_rows_in_one_tree
+    model, packed, h = make("two_agent.xml", 3)
+    q = _pose_with_many_rows_in_one_tree(model, packed)
+    assert q is not None
+    start = np.tile(q, (3, 1))
+    h.set_field("qpos", start)
+    oras = [OracleEnv(packed) for _ in range(3)]
+    for o in oras:
+        o.qpos[:] = q
+    ioff, info_at = h.lds_offset("ints"), h.lds_offset("i_rowinfo")
+    rng = np.random.default_rng(4)
+    wide_steps = 0
+    for k in range(60):
+        ctrl = rng.uniform(-1, 1, (3, model.nu))
+        h.set_field("ctrl", ctrl)
+        img = h.step_debug(None, 0, 1, 0)
+        ints = img[:, ioff:ioff + (info_at + model.njmax + 1) // 2 + 1].copy().view(np.int32)
+        for e, o in enumerate(oras):
+            o.ctrl[:] = ctrl[e]
+            o.step()
+            assert (ints[e, 1], ints[e, 0], ints[e, 3]) == (o.nefc, o.ncon, o.niter), (k, e)
+        trees = (ints[0, info_at:info_at + ints[0, 1]] >> 19) - 2
+        per_tree = [int((trees == t).sum()) for t in range(model.ntree)]
+        wide_steps += bool((trees >= 0).all() and 16 < max(per_tree) <= 32)
+    assert wide_steps > 0
+    assert rel(h.get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
+    assert rel(h.get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
