@@ -1110,19 +1110,19 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
   while (iter < m.iterations) {
     const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
     f_start = fi; s_start = sr;
-    real ss = sr;
+    real ns = -sr, nss = ns;                 // negated residual: a row step is max, broadcast, multiply-add (see stage_pgs)
+    const real nf = -fi;
     const real improvement = wv::rows4_sum(wv::sum16(-c_prev));      // of the sweep before
 #define MJ_FSTEP(KK)                                                                  \
       {                                                                               \
-        real fn = fmax(fi - sr, 0.0);                                                 \
-        real db = wide_bcast<KK>(fn - fi);                                            \
-        if (kme_s == KK) { fi = fn; ss = sr; }                                        \
-        sr += A[KK] * db;                                                             \
+        real db = wide_bcast<KK>(fmax(ns, nf));                                       \
+        if (kme_s == KK) nss = ns;                                                    \
+        ns -= A[KK] * db;                                                             \
       }
     MJ_FSTEP(0) MJ_FSTEP(1)
     if (pending && wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
       if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
-      else { fi = f_start; sr = s_start; }
+      else { sr = s_start; }
       pending = false;
       break;
     }
@@ -1138,6 +1138,9 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
       MJ_FSTEP(28) MJ_FSTEP(29) MJ_FSTEP(30) MJ_FSTEP(31)
     } while (0);
 #undef MJ_FSTEP
+    sr = -ns;
+    const real ss = -nss;
+    fi = fmax(f_start - ss, 0.0);
     const real dsweep = fi - f_start;
     c_prev = dsweep * dsweep * haii + dsweep * (ss * aii);
     f_prev = f_start; s_prev = s_start;
@@ -1349,20 +1352,25 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       // optimiser cannot see through, or it would precompute a lane mask per step and spill them)
       const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
       f_start = fi; s_start = sr;
-      real ss = sr;
+      // A row step changes its force by d = max(f - s, 0) - f = max(-s, -f): one max on the negated residual, then
+      // the broadcast and the multiply-add -- the whole dependent chain of a step.  (The reference forms d as the
+      // rounded difference of the rounded new force; max(-s, -f) is that quantity without the two roundings.  The new
+      // force itself, max(f - s, 0), is formed after the sweep from the residual captured in the row's step, bit for
+      // bit as the reference forms it, and with it the cost change of the row.)
+      real ns = -sr, nss = ns;
+      const real nf = -fi;
       const real improvement = wv::rows_sum(wv::sum16(-c_prev), m.ntree);      // of the sweep before
 #define MJ_FSTEP(KK)                                                                  \
         {                                                                             \
-          real fn = fmax(fi - sr, 0.0);                                               \
-          real db = wv::bcast16<KK>(fn - fi);                                         \
-          if (kme_s == KK) { fi = fn; ss = sr; }                                      \
-          sr += A[KK] * db;                                                           \
+          real db = wv::bcast16<KK>(fmax(ns, nf));                                    \
+          if (kme_s == KK) nss = ns;                                                  \
+          ns -= A[KK] * db;                                                           \
         }
       MJ_FSTEP(0) MJ_FSTEP(1)
       // one branch for the two rare outcomes (a condition computed by the vector unit costs ~80 cycles to branch on)
       if (pending && wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
         if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
-        else { fi = f_start; sr = s_start; }                                                    // it had converged
+        else { sr = s_start; }                                                                  // it had converged
         pending = false;
         break;
       }
@@ -1377,6 +1385,9 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
         MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
       } while (0);
 #undef MJ_FSTEP
+      sr = -ns;
+      const real ss = -nss;
+      fi = fmax(f_start - ss, 0.0);
       const real dsweep = fi - f_start;
       c_prev = dsweep * dsweep * haii + dsweep * (ss * aii);
       f_prev = f_start; s_prev = s_start;
