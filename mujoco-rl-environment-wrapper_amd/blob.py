@@ -18,19 +18,19 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 11
+VERSION = 12
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
                "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "has_accel", "nitemmax", "rowmap", "nfactor", "npass",
-               "ntab", "reserved0"]
+               "ntab", "maxkdepth"]
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
 # (name, count expression in terms of the size fields)
 F64_FIELDS = [
     ("qpos0", "nq"),
-    ("body_pos", "nbody*3"), ("body_quat", "nbody*4"), ("body_ipos", "nbody*3"), ("body_iquat", "nbody*4"),
+    ("body_pos", "nbody*3"), ("body_quat", "nbody*4"), ("body_kpos", "nbody*3"), ("body_kquat", "nbody*4"), ("body_ipos", "nbody*3"), ("body_iquat", "nbody*4"),
     ("body_mass", "nbody"), ("body_inertia", "nbody*3"), ("body_invweight0", "nbody*2"),
     ("body_subtreemass", "nbody"),
     ("jnt_pos", "njnt*3"), ("jnt_axis", "njnt*3"), ("jnt_range", "njnt*2"), ("jnt_margin", "njnt"),
@@ -64,6 +64,7 @@ I32_FIELDS = [
     ("desc_row", "ndesc"), ("M_coldiag", "nM"), ("dof_actid", "nv"),
     ("factor_sched", "nfactor"), ("row_dof", "64"), ("solve_b", "1024"), ("solve_f", "1024"), ("dof_lane", "nv"),
     ("lds_tab", "ntab"), ("pair_word", "npair"), ("pair_reach", "npair"), ("dof_descmask", "nv*2"),
+    ("body_kparent", "nbody"), ("body_kdepth", "nbody"),
 ]
 
 
@@ -80,7 +81,7 @@ def _sizes(model) -> dict:
     s["has_accel"] = int(any(int(t) == 1 for t in model.sensor_type))     # accelerometers keep cacc/cdof_dot alive
     # narrow-phase work-item list: room for every pair that can plausibly pass the bounding-sphere test at once
     s["nitemmax"] = int(getattr(model, "nitemmax", 0)) or 64 + 160 * max(int(model.ntree), 1)
-    s["reserved0"] = 0
+    s["maxkdepth"] = int(model.body_kdepth.max()) if model.nbody else 0
     return s
 
 

@@ -141,7 +141,7 @@ struct mjrl_env {
 
 extern "C" {
 
-const char* mjrl_version(void) { return "mjrl-hip 0.4 (blob layout 11, gfx950)"; }
+const char* mjrl_version(void) { return "mjrl-hip 0.5 (blob layout 12, gfx950)"; }
 
 const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 

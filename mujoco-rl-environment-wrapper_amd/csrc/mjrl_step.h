@@ -184,7 +184,8 @@ struct LaneK {
 __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
   bool isb = L < m.nbody, isd = L < m.nv;
   int b = isb ? L : 0, d = isd ? L : 0;
-  k.b_parent = m.body_parentid[b]; k.b_depth = isb ? m.body_depth[b] : -1; k.b_tree = m.body_treeid[b];
+  // (kinematic parent and depth: bodies welded to a jointless parent hang off the nearest ancestor that moves, mjcf.py)
+  k.b_parent = m.body_kparent[b]; k.b_depth = isb ? m.body_kdepth[b] : -1; k.b_tree = m.body_treeid[b];
   k.b_dofadr = m.body_dofadr[b]; k.b_dofnum = isb ? m.body_dofnum[b] : 0; k.b_jntadr = m.body_jntadr[b];
   k.b_jntnum = isb ? m.body_jntnum[b] : 0; k.b_subnum = m.body_subtreenum[b]; k.b_mass = m.body_mass[b];
   k.b_jnttype = k.b_jntnum > 0 ? m.jnt_type[k.b_jntadr] : -1;
@@ -270,8 +271,8 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
   // the rotation quaternion of a hinge (one sincos for the whole wave instead of one per tree level), the normalised
   // quaternion of a free joint.
   const bool isb = L < m.nbody;
-  V3 bpos = ld3(m.body_pos + 3 * (isb ? L : 0));
-  Quat bquat = ldq(m.body_quat + 4 * (isb ? L : 0));
+  V3 bpos = ld3(m.body_kpos + 3 * (isb ? L : 0));          // offset from the kinematic parent
+  Quat bquat = ldq(m.body_kquat + 4 * (isb ? L : 0));
   const int j0 = K.b_jntadr;
   const bool hasj = K.b_jntnum > 0;
   const int jt0 = K.b_jnttype, qa0 = hasj ? m.jnt_qposadr[j0] : 0;
@@ -287,7 +288,7 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
     if (jt0 == JNT_HINGE) jq = axis_angle(jaxis0, q0);
   }
   wv::sync();
-  for (int lev = 1; lev <= m.maxdepth; lev++) {
+  for (int lev = 1; lev <= m.maxkdepth; lev++) {
     if (K.b_depth == lev) {
       int b = L, p = K.b_parent;
       Quat pq = ldq(S + l.xquat + 4 * p);
@@ -639,7 +640,7 @@ __device__ inline void stage_velocity(const DevModel& m, const Lay& l, const Lan
   }
   wv::sync();
   real cvel[6] = {0, 0, 0, 0, 0, 0}, cacc[6] = {0, 0, 0, 0, 0, 0};     // the lane's body, kept for the force pass below
-  for (int lev = 1; lev <= m.maxdepth; lev++) {
+  for (int lev = 1; lev <= m.maxkdepth; lev++) {
     if (K.b_depth == lev) {
       int b = L, p = K.b_parent;
       for (int r = 0; r < 6; r++) { cvel[r] = S[l.cvel + 6 * p + r]; cacc[r] = S[l.cacc + 6 * p + r]; }

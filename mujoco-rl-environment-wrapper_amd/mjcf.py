@@ -447,6 +447,20 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
             else:
                 qpos0[jnt_qposadr[j]] = jn["ref"]
         body_lastdof[b] = last
+    # Kinematic parents: a body whose parent carries no joint is welded to it, so its frame (and its spatial velocity)
+    # follows from the nearest ancestor that does move, through a constant offset composed here.  The kernels walk the
+    # tree by these links: fewer levels (the ant: torso - leg - hip - ankle becomes torso - {leg, hip} - ankle).
+    body_kparent, body_kdepth = body_parentid.copy(), np.zeros(nbody, np.int32)
+    body_kpos, body_kquat = body_pos.copy(), body_quat.copy()
+    for b in range(1, nbody):
+        p, pos, quat = int(body_parentid[b]), body_pos[b].copy(), body_quat[b].copy()
+        while p != 0 and body_jntnum[p] == 0:
+            pos = body_pos[p] + quat_to_mat(body_quat[p]) @ pos
+            quat = quat_mul(body_quat[p], quat)
+            p = int(body_parentid[p])
+        body_kparent[b], body_kpos[b], body_kquat[b] = p, pos, quat
+        body_kdepth[b] = body_kdepth[p] + 1
+    A.update(body_kparent=body_kparent, body_kdepth=body_kdepth, body_kpos=body_kpos, body_kquat=body_kquat)
     A.update(body_parentid=body_parentid, body_rootid=body_rootid, body_weldid=body_weldid,
              body_jntnum=body_jntnum, body_jntadr=body_jntadr, body_dofnum=body_dofnum,
              body_dofadr=body_dofadr, body_geomnum=body_geomnum, body_geomadr=body_geomadr,
