@@ -51,7 +51,7 @@ enum { JW = 2 * MAX_DOF_DEPTH, CHAIN_BITS = 19 };
 // accelerometer re-reads the last three after the solve and keeps them outside `u`).
 struct Lay {
   int qpos, qvel, ctrl, warm, xpos, xquat, com, cdof, cdofdot, cvel, cacc, M, LD, Dinv, gpos, gquat, bias, smooth, qaccs,
-      x, qfc, qacc, con, sens, gsize, tab, ints, u, total;
+      x, qfc, qacc, con, sens, zero, gsize, tab, ints, u, total;
   int xanchor, xaxis, cinert, crb;   // inside u, first lifetime
   int J, row;                        // inside u, second lifetime
   int ldj;                           // row stride of J (= JW, the compact row width)
@@ -72,6 +72,7 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(qfc, m.nv) REG(qacc, m.nv)
   l.x = l.bias;      // solver / integrator temporary: the bias forces are dead once qfrc_smooth exists
   REG(con, CON_STRIDE * m.nconmax) REG(sens, m.nsensordata + 1)
+  REG(zero, 1)                   // holds 0.0: where the triangular solves have no factor entry they read this
   REG(tab, (m.ntab + 3) / 4)     // structure tables staged once per launch
   int ni = I_HEAD;
   l.i_cong1 = ni; ni += m.nconmax;
@@ -222,6 +223,7 @@ __device__ inline Tab make_tab(const DevModel& m, const Lay& l, const real* S) {
 __device__ inline void stage_constants(const DevModel& m, const Lay& l, real* S, int L) {
   unsigned short* t = (unsigned short*)(S + l.tab);
   for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned short)m.lds_tab[i];
+  if (L == 0) S[l.zero] = 0.0;
 }
 
 __device__ __forceinline__ float int_as_float(int v) {
@@ -247,15 +249,18 @@ __device__ __forceinline__ int row_slot(int chain, unsigned long long below, int
   return in_p ? dp - depth : (in_q ? MAX_DOF_DEPTH + dq - depth : -1);
 }
 
-__device__ inline void load_row_constants(const DevModel& m, int L, RowK& r) {
+__device__ inline void load_row_constants(const DevModel& m, const Lay& l, int L, RowK& r) {
   r.dof = m.rowmap ? m.row_dof[L] : (L < m.nv ? L : -1);
   int d = r.dof >= 0 ? r.dof : 0;
   r.depth = m.dof_depth[d];
   r.below = r.dof >= 0 ? ((unsigned long long)(unsigned)m.dof_descmask[2 * d + 1] << 32) | (unsigned)m.dof_descmask[2 * d] : 0ull;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    r.eb[k] = m.rowmap ? m.solve_b[k * 64 + L] : -1;
-    r.ef[k] = m.rowmap ? m.solve_f[k * 64 + L] : -1;
+    // absolute LDS offsets of the factor entries (the factor always sits at l.LD); no entry -> the zero slot, so that
+    // the solves need no predication
+    int eb = m.rowmap ? m.solve_b[k * 64 + L] : -1, ef = m.rowmap ? m.solve_f[k * 64 + L] : -1;
+    r.eb[k] = eb >= 0 ? l.LD + eb : l.zero;
+    r.ef[k] = ef >= 0 ? l.LD + ef : l.zero;
   }
 }
 
@@ -476,8 +481,8 @@ __device__ inline real solve_rows(const DevModel& m, const RowK& R, const real* 
   real lb[16], lf[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    lb[k] = (backward && R.eb[k] >= 0) ? S[ld + R.eb[k]] : 0.0;
-    lf[k] = (forward && R.ef[k] >= 0) ? S[ld + R.ef[k]] : 0.0;
+    lb[k] = backward ? S[R.eb[k]] : 0.0;      // (absolute offsets, factor at l.LD == ld; see load_row_constants)
+    lf[k] = forward ? S[R.ef[k]] : 0.0;
   }
   real di = (scale && R.dof >= 0) ? S[dinv + R.dof] : 1.0;
   if (backward) {
@@ -1503,7 +1508,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   if (m.rowmap) {
     // (L' u)_d = u_d + sum over descendants k of L[k][d] u_k: the backward-solve pattern with the ORIGINAL u
     real q = u;
-#define MJ_QSTEP(KK) if (KK < m.maxtreedof) { real uk = wv::bcast16<KK>(u); if (RK.eb[KK] >= 0) q += S[l.LD + RK.eb[KK]] * uk; }
+#define MJ_QSTEP(KK) if (KK < m.maxtreedof) { real uk = wv::bcast16<KK>(u); q += S[RK.eb[KK]] * uk; }
     MJ_QSTEP(1) MJ_QSTEP(2) MJ_QSTEP(3) MJ_QSTEP(4) MJ_QSTEP(5) MJ_QSTEP(6) MJ_QSTEP(7) MJ_QSTEP(8)
     MJ_QSTEP(9) MJ_QSTEP(10) MJ_QSTEP(11) MJ_QSTEP(12) MJ_QSTEP(13) MJ_QSTEP(14) MJ_QSTEP(15)
 #undef MJ_QSTEP
@@ -1688,7 +1693,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   LaneK K;
   load_lane_constants(m, L, K);
   RowK RK;
-  load_row_constants(m, L, RK);
+  load_row_constants(m, l, L, RK);
   // diagnostic stage clock: lane k accumulates the cycles of stage k in a register and adds them to the batch totals
   // when the wave is done -- nothing of the measurement touches memory while a stage is being timed
   Stamps clock_state;
