@@ -112,7 +112,9 @@ struct mjrl_env {
   int32_t *d_prog_i = nullptr, *d_agent_body = nullptr, *d_obs_len = nullptr;
   double *d_prog_f = nullptr, *store = nullptr;
   // longest-first dispatch: two generations of work buckets (read the previous launch's, fill the next one's)
-  int *lpt_count[2] = {nullptr, nullptr}, *lpt_list[2] = {nullptr, nullptr};
+  // three generations of work buckets: a launch reads one, files into the next and clears the third for the launch
+  // after it (a hipMemsetAsync per step was a 5 us kernel of its own, 2 % of the step)
+  int *lpt_count[3] = {nullptr, nullptr, nullptr}, *lpt_list[3] = {nullptr, nullptr, nullptr};
   int lpt_cur = 0;
   bool lpt_valid = false, lpt_enabled = true;
   // forward-pass frames kept for host-side plugin queries
@@ -150,8 +152,8 @@ void mjrl_destroy(mjrl_env* e) {
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
-                  e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_list[0],
-                  e->lpt_list[1]};
+                  e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
+                  e->lpt_list[0], e->lpt_list[1], e->lpt_list[2]};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->spec_module) hipModuleUnload(e->spec_module);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
@@ -203,8 +205,9 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
   CK(hipMalloc(&e->d_mask, n_env));
   e->lpt_enabled = !(flags & 1u);
-  for (int g = 0; g < 2; g++) {
+  for (int g = 0; g < 3; g++) {
     CK(hipMalloc(&e->lpt_count[g], sizeof(int) * mj::LPT_BUCKETS));
+    CK(hipMemset(e->lpt_count[g], 0, sizeof(int) * mj::LPT_BUCKETS));
     CK(hipMalloc(&e->lpt_list[g], sizeof(int) * mj::LPT_BUCKETS * (size_t)n_env));
   }
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -433,9 +436,10 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     a.dbg = last ? d_dbg : nullptr;
     a.frames = last ? e->frames : nullptr;
     a.lpt_count_in = nullptr; a.lpt_list_in = nullptr; a.lpt_count_out = nullptr; a.lpt_list_out = nullptr;
+    a.lpt_count_clear = nullptr;
     if (e->lpt_enabled && !forward_only && !d_dbg) {
-      int in = e->lpt_cur, out = 1 - e->lpt_cur;
-      MJRL_HIP(e, hipMemsetAsync(e->lpt_count[out], 0, sizeof(int) * mj::LPT_BUCKETS, e->stream));
+      int in = e->lpt_cur, out = (e->lpt_cur + 1) % 3;
+      a.lpt_count_clear = e->lpt_count[(e->lpt_cur + 2) % 3];
       if (e->lpt_valid) { a.lpt_count_in = e->lpt_count[in]; a.lpt_list_in = e->lpt_list[in]; }
       a.lpt_count_out = e->lpt_count[out];
       a.lpt_list_out = e->lpt_list[out];

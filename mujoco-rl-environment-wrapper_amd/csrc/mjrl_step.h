@@ -153,6 +153,7 @@ struct StepArgs {
   const int* lpt_list_in;      // [LPT_BUCKETS][n_env]
   int* lpt_count_out;
   int* lpt_list_out;
+  int* lpt_count_clear;        // [LPT_BUCKETS] the counts the NEXT launch files into: zeroed by workgroup 0 of this one
 };
 enum { LPT_BUCKETS = 16 };
 
@@ -1825,6 +1826,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     }
   }
   MJ_STAMP(ST_STORE)
+  if (a.lpt_count_clear && wv::env_index() == 0 && L < LPT_BUCKETS) a.lpt_count_clear[L] = 0;
   if (a.lpt_count_out && L == 0) {
     const int* I = (const int*)(S + l.ints);
     unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
