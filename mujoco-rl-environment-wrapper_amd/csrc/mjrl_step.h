@@ -584,10 +584,11 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
         }
       }
     }
-    // exclusive prefix of the item counts (1, 2, 4 or 8 per lane) from four ballots
+    // exclusive prefix of the item counts (1, 2, 4 or 8 per lane) from four ballots; most chunks have no survivor
+    unsigned long long b1 = wv::ballot(items >= 1);
+    if (b1 == 0ull) continue;
     unsigned long long lower = (1ull << L) - 1ull;
-    unsigned long long b1 = wv::ballot(items >= 1), b2 = wv::ballot(items >= 2), b4 = wv::ballot(items >= 4),
-                       b8 = wv::ballot(items >= 8);
+    unsigned long long b2 = wv::ballot(items >= 2), b4 = wv::ballot(items >= 4), b8 = wv::ballot(items >= 8);
     int off = nitem + wv::popc(b1 & lower) + wv::popc(b2 & lower) + 2 * wv::popc(b4 & lower) + 4 * wv::popc(b8 & lower);
     for (int k = 0; k < items; k++)
       if (off + k < m.nitemmax) I[l.i_item + off + k] = (p << 3) | k;
