@@ -1679,13 +1679,18 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   int env = wv::env_index();
   if (a.lpt_count_in) {
     // workgroup id -> copy: walk the buckets from the heaviest down
-    int rest = env, pick = -1, bucket = 0;
-    for (int b = LPT_BUCKETS - 1; b >= 0 && pick < 0; b--) {
-      int c = a.lpt_count_in[b];
-      if (rest < c) { pick = a.lpt_list_in[(size_t)b * a.n_env + rest]; bucket = b; }
-      rest -= c;
+    // (the bucket counts come in with one load, lane b holding bucket b's; walking them is register work -- a loop of
+    // dependent loads here cost every wave several L2 round trips before it could even fetch its state)
+    const int my_count = L < LPT_BUCKETS ? a.lpt_count_in[L] : 0;
+    int rest = env, bucket = -1;
+    for (int b = LPT_BUCKETS - 1; b >= 0; b--) {
+      int c = wv::lane_int(my_count, b);
+      if (bucket < 0) {
+        if (rest < c) bucket = b; else rest -= c;
+      }
     }
-    env = pick;
+    env = bucket >= 0 ? a.lpt_list_in[(size_t)bucket * a.n_env + rest] : -1;
+    if (bucket < 0) bucket = 0;
     // The launch ends with its slowest copy, and a copy with hundreds of solver row steps is one long dependent
     // chain: its wave gets issue priority over the waves that share its SIMD (they fill the gaps it leaves).
     wv::set_priority(bucket >= 10 ? 3 : (bucket == 9 ? 2 : (bucket == 8 ? 1 : 0)));

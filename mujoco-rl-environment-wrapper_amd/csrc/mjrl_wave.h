@@ -86,6 +86,8 @@ __device__ __forceinline__ double lane_value(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+// lane `src`'s int in every lane; src is wave-uniform (v_readlane)
+__device__ __forceinline__ int lane_int(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ double rows4_sum(double v) {
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
