@@ -1730,8 +1730,15 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   const bool ops_staged = a.n_op > 0 && t_ag + a.n_agent <= 5 * m.nv && n_act_row <= 64 && 8 * a.n_op <= 64;
   real act_reg = 0, store_reg = 0, pf_reg = 0;
   int pi_reg = 0, len_reg = 0, body_reg = 0;
+  // the action row and its scatter indices, one element per lane, issued with the state loads (the scatter below would
+  // otherwise wait for two dependent loads of its own)
+  const bool act_in_lanes = a.actions != nullptr && n_act_row <= 64;
+  int sc_reg = -1;
+  if (act_in_lanes && L < n_act_row) {
+    act_reg = a.actions[(size_t)env * n_act_row + L];
+    if (a.scatter) sc_reg = a.scatter[L];
+  }
   if (ops_staged) {
-    if (a.actions && L < n_act_row) act_reg = a.actions[(size_t)env * n_act_row + L];
     if (a.store && L < n_store_row) store_reg = a.store[(size_t)env * n_store_row + L];
     if (L < 4 * a.n_op) pf_reg = a.prog_f[L];
     if (L < 8 * a.n_op) pi_reg = a.prog_i[L];
@@ -1741,11 +1748,15 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   wv::sync();
   // scatter the physical part of every agent's action (mujoco_parent.py:323-332)
   if (a.actions && a.scatter) {
-    MJ_FOR(it, a.n_agent * a.act_dim) {
-      int idx = a.scatter[it];
-      if (idx >= 0) {
-        real v = a.actions[(size_t)env * a.n_agent * a.act_dim + it];
-        if (a.scatter_mode == 0) S[l.ctrl + idx] = v; else S[l.qvel + idx] = v;
+    if (act_in_lanes) {
+      if (sc_reg >= 0) { if (a.scatter_mode == 0) S[l.ctrl + sc_reg] = act_reg; else S[l.qvel + sc_reg] = act_reg; }
+    } else {
+      MJ_FOR(it, a.n_agent * a.act_dim) {
+        int idx = a.scatter[it];
+        if (idx >= 0) {
+          real v = a.actions[(size_t)env * a.n_agent * a.act_dim + it];
+          if (a.scatter_mode == 0) S[l.ctrl + idx] = v; else S[l.qvel + idx] = v;
+        }
       }
     }
     wv::sync();
