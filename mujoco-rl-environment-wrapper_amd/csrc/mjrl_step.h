@@ -177,6 +177,8 @@ struct LaneK {
   // lane as body
   int b_parent, b_depth, b_tree, b_dofadr, b_dofnum, b_jntadr, b_jntnum, b_subnum;
   int b_jnttype;      // type of the body's first joint (-1: none)
+  int b_qposadr;      // its qpos address
+  real b_q0;          // and its reference position qpos0 (hinge / slide)
   real b_mass;
   // lane as dof
   int d_parent, d_Madr, d_depth, d_body, d_descadr, d_descnum, d_act;
@@ -191,6 +193,8 @@ __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
   k.b_dofadr = m.body_dofadr[b]; k.b_dofnum = isb ? m.body_dofnum[b] : 0; k.b_jntadr = m.body_jntadr[b];
   k.b_jntnum = isb ? m.body_jntnum[b] : 0; k.b_subnum = m.body_subtreenum[b]; k.b_mass = m.body_mass[b];
   k.b_jnttype = k.b_jntnum > 0 ? m.jnt_type[k.b_jntadr] : -1;
+  k.b_qposadr = k.b_jntnum > 0 ? m.jnt_qposadr[k.b_jntadr] : 0;
+  k.b_q0 = k.b_jntnum > 0 ? m.qpos0[k.b_qposadr] : 0.0;
   k.d_parent = m.dof_parentid[d]; k.d_Madr = m.dof_Madr[d]; k.d_depth = isd ? m.dof_depth[d] : -1;
   k.d_body = m.dof_bodyid[d]; k.d_descadr = m.dof_descadr[d]; k.d_descnum = isd ? m.dof_descnum[d] : 0;
   k.d_act = isd ? m.dof_actid[d] : -1; k.d_damping = m.dof_damping[d]; k.d_armature = m.dof_armature[d];
@@ -281,7 +285,7 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
   Quat bquat = ldq(m.body_kquat + 4 * (isb ? L : 0));
   const int j0 = K.b_jntadr;
   const bool hasj = K.b_jntnum > 0;
-  const int jt0 = K.b_jnttype, qa0 = hasj ? m.jnt_qposadr[j0] : 0;
+  const int jt0 = K.b_jnttype, qa0 = K.b_qposadr;
   V3 jaxis0 = hasj ? ld3(m.jnt_axis + 3 * j0) : v3(0, 0, 1), jpos0 = hasj ? ld3(m.jnt_pos + 3 * j0) : v3(0, 0, 0);
   real q0 = 0;
   V3 fpos = v3(0, 0, 0);
@@ -290,7 +294,7 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
     fpos = ld3(S + l.qpos + qa0);
     jq = qnormalized(ldq(S + l.qpos + qa0 + 3));
   } else if (hasj) {
-    q0 = S[l.qpos + qa0] - m.qpos0[qa0];
+    q0 = S[l.qpos + qa0] - K.b_q0;
     if (jt0 == JNT_HINGE) jq = axis_angle(jaxis0, q0);
   }
   wv::sync();
@@ -350,6 +354,7 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
 }
 
 __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+  const Tab T = make_tab(m, l, S);
   // mass-weighted centres of mass; a tree's bodies are the id range of its root (depth-first numbering)
   V3 xi = v3(0, 0, 0);
   Quat q; q.w = 1; q.x = q.y = q.z = 0;
@@ -382,7 +387,7 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const 
   // joint motion axes in the same frame
   if (L < m.njnt) {
     int j = L, b = m.jnt_bodyid[j], da = m.jnt_dofadr[j];
-    V3 off = ld3(S + l.com + 3 * m.body_treeid[b]) - ld3(S + l.xanchor + 3 * j);
+    V3 off = ld3(S + l.com + 3 * T.body_tree(b)) - ld3(S + l.xanchor + 3 * j);     // (tree id from the LDS table)
     if (m.jnt_type[j] == JNT_FREE) {
       M3 xm = qmat(ldq(S + l.xquat + 4 * b));
       for (int k = 0; k < 3; k++) {
@@ -406,6 +411,7 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const 
 }
 
 __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+  const Tab T = make_tab(m, l, S);
   // composite inertia of every body that carries dofs: sum of cinert over its subtree (an id range)
   if (L > 0 && L < m.nbody && K.b_dofnum > 0) {
     real acc[10];
@@ -421,7 +427,7 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
     for (int k = 0; k < 6; k++) c[k] = S[l.cdof + 6 * L + k];
     inert_mul(buf, crb, c);
     for (int t = 0; t <= K.d_depth; t++) {
-      int j = m.M_colid[K.d_Madr + t];
+      int j = T.colid(K.d_Madr + t);          // (LDS structure table: a load from HBM per ancestor would sit on the chain)
       real cj[6];
       for (int k = 0; k < 6; k++) cj[k] = S[l.cdof + 6 * j + k];
       real v = dot6(cj, buf);
