@@ -1010,15 +1010,15 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       // position t has depth nc-1-t; its ancestors are positions t+1 .. nc-1, the factor entries L[k][.] follow
       // the diagonal of row k in the sparse layout
 #pragma unroll
+      // (no predicates inside: positions past the chain's end hold values nobody reads, their updates flow only
+      // further up, and the factor entries read for them are some other dof's, finite; a select per multiply-add cost
+      // more than the arithmetic)
       for (int t = 0; t < MAX_DOF_DEPTH; t++) {
-        if (t < nc) {
-          real v = Bv[t];
-          acc += v * v * S[l.Dinv + cd[t]];
-          int adr = T.madr(cd[t]);
+        real v = Bv[t];
+        if (t < nc) acc += v * v * S[l.Dinv + cd[t]];
+        int adr = T.madr(cd[t]);
 #pragma unroll
-          for (int sft = 1; sft < MAX_DOF_DEPTH; sft++)
-            if (t + sft < nc && v != 0.0) Bv[(t + sft) & (MAX_DOF_DEPTH - 1)] -= v * S[l.LD + adr + sft];
-        }
+        for (int sft = 1; sft < MAX_DOF_DEPTH - t; sft++) Bv[t + sft] -= v * S[l.LD + adr + sft];
       }
 #pragma unroll
       for (int t = 0; t < MAX_DOF_DEPTH; t++) if (t < nc) Jr[local ? cd[t] - adr0 : t] = Bv[t];
