@@ -953,23 +953,22 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
       } else {
         V3 offc = n2 ? c_off2 : c_off1;
 #pragma unroll
+        // (computed for all eight positions and zeroed past the chain's end -- positions there use dof 0 -- so that
+        // neither this loop nor the dot products below run under a per-position lane mask)
         for (int t = 0; t < MAX_DOF_DEPTH; t++) {
-          if (t < nc) {
-            V3 ca = ld3(S + l.cdof + 6 * cd[t]), cl = ld3(S + l.cdof + 6 * cd[t] + 3);
-            V3 colv = cl + cross(ca, offc);
-            if (!n2) colv = v3(0, 0, 0) - colv;
-            real jn = dot(c_n, colv);
-            Bv[t] = c_dim == 1 ? jn : jn + c_sgn * c_mu * dot(c_tk, colv);
-          }
+          V3 ca = ld3(S + l.cdof + 6 * cd[t]), cl = ld3(S + l.cdof + 6 * cd[t] + 3);
+          V3 colv = cl + cross(ca, offc);
+          if (!n2) colv = v3(0, 0, 0) - colv;
+          real jn = dot(c_n, colv);
+          real val = c_dim == 1 ? jn : jn + c_sgn * c_mu * dot(c_tk, colv);
+          Bv[t] = t < nc ? val : 0.0;
         }
       }
 #pragma unroll
       for (int t = MAX_DOF_DEPTH - 1; t >= 0; t--) {      // ascending dof id
-        if (t < nc) {
-          vel += Bv[t] * S[l.qvel + cd[t]];
-          ja += Bv[t] * S[l.qaccs + cd[t]];
-          jw += Bv[t] * S[l.warm + cd[t]];
-        }
+        vel += Bv[t] * S[l.qvel + cd[t]];
+        ja += Bv[t] * S[l.qaccs + cd[t]];
+        jw += Bv[t] * S[l.warm + cd[t]];
       }
     } else {
       int p1 = n1 - 1, p2 = n2 - 1;
