@@ -1081,11 +1081,11 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
   real fi = has_row ? Rm[ROW_F] : 0.0, bi = has_row ? Rm[ROW_B] : 0.0, Ri = has_row ? Rm[ROW_R] : 0.0;
   const real aii = has_row ? Rm[ROW_ARII] : 1.0;
   const real ainv = 1.0 / aii;
-  const int adr0 = w.adr0, tn = w.tn;
+  const int adr0 = w.adr0;
   real W[16], A[32];
 #pragma unroll
   for (int d = 0; d < 16; d++)
-    W[d] = (has_row && d < tn) ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;
+    W[d] = has_row ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;       // (slots past the tree's dofs hold 0)
 #pragma unroll
   for (int k = 0; k < 32; k++) A[k] = 0;
 #define MJ_ASTEP(KK)                                                                  \
@@ -1297,11 +1297,10 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     const real aii = has_row ? Rm[ROW_ARII] : 1.0;
     const real ainv = 1.0 / aii;
     const int adr0 = wv::bcast16i<0>(mydof);            // first dof of the lane's tree
-    const int tn = wv::popc((wv::ballot(dof) >> (L & 48)) & 0xFFFFull);     // dofs in the lane's tree
     real W[16], A[16];
 #pragma unroll
     for (int d = 0; d < 16; d++)
-      W[d] = (has_row && d < tn) ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;
+      W[d] = has_row ? S[l.J + JW * myrow + d] * S[l.Dinv + adr0 + d] : 0.0;     // (slots past the tree's dofs hold 0)
 #pragma unroll
     for (int k = 0; k < 16; k++) A[k] = 0;
     // row k of the tree is owned by lane k of the tree's 16 lanes: its id comes over DPP, not from the list in LDS
