@@ -73,8 +73,12 @@ def code_object(blob: bytes, build: bool = True) -> str | None:
     cc = hipcc()
     if not build or cc is None:
         return None
-    os.makedirs(CACHE, exist_ok=True)
-    with tempfile.TemporaryDirectory(dir=CACHE) as tmp:
+    try:
+        os.makedirs(CACHE, exist_ok=True)
+        probe = tempfile.TemporaryDirectory(dir=CACHE)
+    except OSError:
+        return None                 # read-only install: the generic kernel of libmjrl_hip.so stays in place
+    with probe as tmp:
         hdr = os.path.join(tmp, "spec.h")
         with open(hdr, "w") as f:
             f.write(spec_header(sizes))
