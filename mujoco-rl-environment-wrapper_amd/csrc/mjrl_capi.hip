@@ -98,6 +98,7 @@ struct mjrl_env {
   int n_env = 0, device = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
+  double* inertia = nullptr;       // [n_env][nM] scratch: the sparse inertia matrix between the CRB stage and the integrator
   int* timestep = nullptr;
   unsigned char* d_mask = nullptr;
   // tables
@@ -153,7 +154,7 @@ void mjrl_destroy(mjrl_env* e) {
   void* ptrs[] = {e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
-                  e->lpt_list[0], e->lpt_list[1], e->lpt_list[2]};
+                  e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->spec_module) hipModuleUnload(e->spec_module);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
@@ -201,6 +202,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->qvel, sizeof(double) * n_env * m.nv));
   CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
   CK(hipMalloc(&e->warm, sizeof(double) * n_env * m.nv));
+  CK(hipMalloc(&e->inertia, sizeof(double) * (size_t)n_env * (m.nM > 0 ? m.nM : 1)));
   CK(hipMalloc(&e->sens, sizeof(double) * n_env * (m.nsensordata > 0 ? m.nsensordata : 1)));
   CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
   CK(hipMalloc(&e->d_mask, n_env));
@@ -373,7 +375,7 @@ int mjrl_lds_offset(const mjrl_env* e, const char* region) {
   const mj::Lay& l = e->lay;
 #define R(name) if (!strcmp(region, #name)) return l.name;
   R(qpos) R(qvel) R(ctrl) R(warm) R(xpos) R(xquat) R(xanchor) R(xaxis) R(com) R(cinert) R(crb) R(cdof) R(cdofdot)
-  R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gquat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
+  R(cvel) R(cacc) R(LD) R(Dinv) R(gpos) R(gquat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
   R(sens) R(ints) R(total) R(i_item) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid) R(i_rowinfo)
 #undef R
   return -1;
@@ -404,6 +406,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "step: observations requested but no gather table is set");
   mj::StepArgs a{};
   a.qpos = e->qpos; a.qvel = e->qvel; a.ctrl = e->ctrl; a.warm = e->warm; a.sensordata = e->sens;
+  a.inertia = e->inertia;
   a.timestep = e->timestep;
   a.actions = nullptr; a.scatter = nullptr;
   a.n_agent = e->n_agent; a.act_dim = act_dim; a.scatter_mode = e->scatter_mode;

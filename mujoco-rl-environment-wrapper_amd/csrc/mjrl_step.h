@@ -46,11 +46,11 @@ enum { JW = 2 * MAX_DOF_DEPTH, CHAIN_BITS = 19 };
 // at once (160 KiB / size) and with that how much of the step's latency is hidden, so everything with a short life
 // shares storage.  The block `u` serves two lifetimes: {cinert + a scratch area} from the kinematics to the end of
 // the bias forces, {J, row} from the constraint-row build to the sensors.  The scratch area in turn holds, one after
-// the other: {xanchor, xaxis} (kinematics .. joint axes), {crb} (composite inertias), {gsize, work items} (geoms ..
-// collision) and {body forces in the crb slots, cvel, cdofdot, cacc} (velocity stage .. bias forces; a model with an
+// the other: {xanchor, xaxis} (kinematics .. joint axes), {crb} (composite inertias), {gsize, work items, geom frames}
+// (geoms .. collision; the few later readers of a geom's frame recompute it from its body's, geom_frame()) and {body forces in the crb slots, cvel, cdofdot, cacc} (velocity stage .. bias forces; a model with an
 // accelerometer re-reads the last three after the solve and keeps them outside `u`).
 struct Lay {
-  int qpos, qvel, ctrl, warm, xpos, xquat, com, cdof, cdofdot, cvel, cacc, M, LD, Dinv, gpos, gquat, bias, smooth, qaccs,
+  int qpos, qvel, ctrl, warm, xpos, xquat, com, cdof, cdofdot, cvel, cacc, LD, Dinv, gpos, gquat, bias, smooth, qaccs,
       x, qfc, qacc, con, sens, zero, gsize, tab, ints, u, total;
   int xanchor, xaxis, cinert, crb;   // inside u, first lifetime
   int J, row;                        // inside u, second lifetime
@@ -60,6 +60,8 @@ struct Lay {
   int i_item, i_cong1, i_cong2, i_conadr, i_rowid, i_rowinfo;
 };
 
+// structure tables in LDS: every value is a dof / body / geom id (< 64), a depth, a type, or an address inside the sparse inertia layout
+__host__ __device__ inline bool tab_in_bytes(const DevModel& m) { return m.nM <= 256; }
 __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   int o = 0;
 #define REG(name, n) l.name = o; o += (n);
@@ -67,13 +69,13 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   REG(xpos, 3 * m.nbody) REG(xquat, 4 * m.nbody) REG(com, 3 * (m.ntree + 1))
   REG(cdof, 6 * m.nv)
   if (m.has_accel) { REG(cvel, 6 * m.nbody) REG(cdofdot, 6 * m.nv) REG(cacc, 6 * m.nbody) }
-  REG(M, m.nM) REG(LD, m.nM) REG(Dinv, m.nv)
-  REG(gpos, 3 * m.ngeom) REG(gquat, 4 * m.ngeom)
-  REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(qfc, m.nv) REG(qacc, m.nv)
+  REG(LD, m.nM) REG(Dinv, m.nv)        // (the unfactorised inertia matrix lives in HBM: StepArgs::inertia)
+  REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(qfc, m.nv)
   l.x = l.bias;      // solver / integrator temporary: the bias forces are dead once qfrc_smooth exists
+  l.qacc = l.warm;   // the solver leaves the new acceleration in both; the old warm start is last read by the row build
   REG(con, CON_STRIDE * m.nconmax) REG(sens, m.nsensordata + 1)
   REG(zero, 1)                   // holds 0.0: where the triangular solves have no factor entry they read this
-  REG(tab, (m.ntab + 3) / 4)     // structure tables staged once per launch
+  REG(tab, tab_in_bytes(m) ? (m.ntab + 7) / 8 : (m.ntab + 3) / 4)     // structure tables staged once per launch
   int ni = I_HEAD;
   l.i_cong1 = ni; ni += m.nconmax;
   l.i_cong2 = ni; ni += m.nconmax;
@@ -87,9 +89,10 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   l.xanchor = sb; l.xaxis = sb + 3 * m.njnt;
   l.crb = sb;
   l.gsize = sb; l.i_item = 2 * (sb + 3 * m.ngeom - l.ints);
+  l.gpos = sb + 3 * m.ngeom + (m.nitemmax + 1) / 2; l.gquat = l.gpos + 3 * m.ngeom;
   int scratch = 6 * m.njnt;
   if (10 * m.nbody > scratch) scratch = 10 * m.nbody;
-  if (3 * m.ngeom + (m.nitemmax + 1) / 2 > scratch) scratch = 3 * m.ngeom + (m.nitemmax + 1) / 2;
+  if (10 * m.ngeom + (m.nitemmax + 1) / 2 > scratch) scratch = 10 * m.ngeom + (m.nitemmax + 1) / 2;
   if (!m.has_accel) {
     // (the bias-force recursion keeps its per-body forces in the crb slots, so the velocities start after those)
     l.cvel = sb + 10 * m.nbody; l.cdofdot = l.cvel + 6 * m.nbody; l.cacc = l.cdofdot + 6 * m.nv;
@@ -113,6 +116,11 @@ struct Stamps {
 struct StepArgs {
   // state in HBM, [n_env][n] row-major
   real *qpos, *qvel, *ctrl, *warm, *sensordata;
+  // Per-copy scratch in HBM [n_env][nM]: the sparse inertia matrix M.  The CRB stage writes it (and its copy to be
+  // factorised, in LDS); only the integrator reads it again, a whole step later, for M + h*diag(damping).  Kept out
+  // of LDS it costs 2.6 KB of HBM traffic per copy and step and buys residency (the LDS image decides how many
+  // copies a CU holds, and the step rate follows that number almost linearly).
+  real* inertia;
   int* timestep;
   // action scatter (mujoco_parent.py:323-332): action slot -> ctrl index (mode 0) or qvel index (mode 1)
   const real* actions;       // [n_env][n_agent][act_dim], may be null (no scatter)
@@ -203,22 +211,25 @@ __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
 // Structure tables kept in LDS as 16-bit words (order fixed by mjcf._kernel_schedules): the row build walks them
 // with data-dependent indices, which from HBM would cost one exposed load latency per hop.
 struct Tab {
-  const unsigned short* t;
+  const unsigned char* t8;       // one byte per entry when every value fits (nM <= 256), else 16-bit words
+  bool bytes;
   int Mcol, Madr, depth, dtree, lastdof, btree, gbody, gtype, gcondim;
-  __device__ __forceinline__ int colid(int e) const { return t[Mcol + e]; }
-  __device__ __forceinline__ int madr(int d) const { return t[Madr + d]; }
-  __device__ __forceinline__ int ddepth(int d) const { return t[depth + d]; }
-  __device__ __forceinline__ int dof_tree(int d) const { return t[dtree + d]; }
-  __device__ __forceinline__ int body_lastdof(int b) const { return (int)t[lastdof + b] - 1; }
-  __device__ __forceinline__ int body_tree(int b) const { return (int)t[btree + b] - 1; }
-  __device__ __forceinline__ int geom_body(int g) const { return t[gbody + g]; }
-  __device__ __forceinline__ int geom_type(int g) const { return t[gtype + g]; }
-  __device__ __forceinline__ int geom_condim(int g) const { return t[gcondim + g]; }
+  __device__ __forceinline__ int at(int i) const { return bytes ? (int)t8[i] : (int)((const unsigned short*)t8)[i]; }
+  __device__ __forceinline__ int colid(int e) const { return at(Mcol + e); }
+  __device__ __forceinline__ int madr(int d) const { return at(Madr + d); }
+  __device__ __forceinline__ int ddepth(int d) const { return at(depth + d); }
+  __device__ __forceinline__ int dof_tree(int d) const { return at(dtree + d); }
+  __device__ __forceinline__ int body_lastdof(int b) const { return at(lastdof + b) - 1; }
+  __device__ __forceinline__ int body_tree(int b) const { return at(btree + b) - 1; }
+  __device__ __forceinline__ int geom_body(int g) const { return at(gbody + g); }
+  __device__ __forceinline__ int geom_type(int g) const { return at(gtype + g); }
+  __device__ __forceinline__ int geom_condim(int g) const { return at(gcondim + g); }
 };
 
 __device__ inline Tab make_tab(const DevModel& m, const Lay& l, const real* S) {
   Tab T;
-  T.t = (const unsigned short*)(S + l.tab);
+  T.t8 = (const unsigned char*)(S + l.tab);
+  T.bytes = tab_in_bytes(m);
   T.Mcol = 0; T.Madr = m.nM; T.depth = T.Madr + m.nv; T.dtree = T.depth + m.nv; T.lastdof = T.dtree + m.nv;
   T.btree = T.lastdof + m.nbody; T.gbody = T.btree + m.nbody; T.gtype = T.gbody + m.ngeom; T.gcondim = T.gtype + m.ngeom;
   return T;
@@ -226,8 +237,13 @@ __device__ inline Tab make_tab(const DevModel& m, const Lay& l, const real* S) {
 
 // copy the launch-invariant tables into LDS (one coalesced sweep per launch)
 __device__ inline void stage_constants(const DevModel& m, const Lay& l, real* S, int L) {
-  unsigned short* t = (unsigned short*)(S + l.tab);
-  for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned short)m.lds_tab[i];
+  if (tab_in_bytes(m)) {
+    unsigned char* t = (unsigned char*)(S + l.tab);
+    for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned char)m.lds_tab[i];
+  } else {
+    unsigned short* t = (unsigned short*)(S + l.tab);
+    for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned short)m.lds_tab[i];
+  }
   if (L == 0) S[l.zero] = 0.0;
 }
 
@@ -410,7 +426,7 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const 
   wv::sync();
 }
 
-__device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+__device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L, real* Mg) {
   const Tab T = make_tab(m, l, S);
   // composite inertia of every body that carries dofs: sum of cinert over its subtree (an id range)
   if (L > 0 && L < m.nbody && K.b_dofnum > 0) {
@@ -432,7 +448,7 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
       for (int k = 0; k < 6; k++) cj[k] = S[l.cdof + 6 * j + k];
       real v = dot6(cj, buf);
       if (t == 0) v = K.d_armature + v;
-      S[l.M + K.d_Madr + t] = v;
+      Mg[K.d_Madr + t] = v;
       S[l.LD + K.d_Madr + t] = v;
     }
   }
@@ -540,12 +556,22 @@ __device__ inline void solve_ld(const DevModel& m, const LaneK& K, real* S, int 
   }
 }
 
+// world frame of geom g from its body's frame.  The geom stage stores these for the collision stage only (scratch
+// area of `u`); what needs a geom's frame after that -- rangefinders, the frame cache, a distance op -- calls this
+// again and gets the same bits.
+__device__ __forceinline__ void geom_frame(const DevModel& m, const Lay& l, const real* S, int g, V3& pos, Quat& quat) {
+  int b = m.geom_bodyid[g];
+  Quat bq = ldq(S + l.xquat + 4 * b);
+  pos = ld3(S + l.xpos + 3 * b) + rot(bq, ld3(m.geom_pos + 3 * g));
+  quat = qmul(bq, ldq(m.geom_quat + 4 * g));
+}
+
 __device__ inline void stage_geoms(const DevModel& m, const Lay& l, real* S, int L) {
   if (L < m.ngeom) {
-    int b = m.geom_bodyid[L];
-    Quat bq = ldq(S + l.xquat + 4 * b);
-    st3(S + l.gpos + 3 * L, ld3(S + l.xpos + 3 * b) + rot(bq, ld3(m.geom_pos + 3 * L)));
-    stq(S + l.gquat + 4 * L, qmul(bq, ldq(m.geom_quat + 4 * L)));
+    V3 pos; Quat quat;
+    geom_frame(m, l, S, L, pos, quat);
+    st3(S + l.gpos + 3 * L, pos);
+    stq(S + l.gquat + 4 * L, quat);
   }
   // the geom sizes go next to the work items of the collision stage (scratch area of `u`, free since the composite
   // inertias were consumed); the loads were issued above the frame arithmetic
@@ -1222,7 +1248,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   real u = 0;
   if (nefc == 0) {
     if (L == 0) I[I_NITER] = 0;
-    if (L < m.nv) { S[l.qfc + L] = 0; S[l.qacc + L] = S[l.qaccs + L]; S[l.warm + L] = S[l.qaccs + L]; }
+    if (L < m.nv) { S[l.qfc + L] = 0; S[l.qacc + L] = S[l.qaccs + L]; }
     wv::sync();
     return;
   }
@@ -1532,8 +1558,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     real x = solve_rows(m, RK, S, l.LD, l.Dinv, u, false, true, true);
     if (dof) {
       real a = S[l.qaccs + mydof] + x;
-      S[l.qacc + mydof] = a;
-      S[l.warm + mydof] = a;
+      S[l.qacc + mydof] = a;     // also next step's warm start (same slots)
     }
     wv::sync();
   } else {
@@ -1542,7 +1567,6 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     if (L < m.nv) {
       real a = S[l.qaccs + L] + S[l.x + L];
       S[l.qacc + L] = a;
-      S[l.warm + L] = a;
     }
     wv::sync();
   }
@@ -1560,11 +1584,13 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
   int rg_body = -1, rg_type = -1;
   real rg_rb = 0;
   V3 rg_pos = v3(0, 0, 0), rg_size = v3(0, 0, 0);
-  M3 rg_mat = qmat(ldq(S + l.gquat));
+  M3 rg_mat = qmat(ldq(S + l.xquat));
   if (any_ray && L < m.ngeom && m.geom_rgba[4 * L + 3] != 0) {
     rg_body = m.geom_bodyid[L]; rg_type = m.geom_type[L]; rg_rb = m.geom_rbound[L];
-    rg_pos = ld3(S + l.gpos + 3 * L); rg_size = ld3(m.geom_size + 3 * L);
-    rg_mat = qmat(ldq(S + l.gquat + 4 * L));
+    rg_size = ld3(m.geom_size + 3 * L);
+    Quat gq;
+    geom_frame(m, l, S, L, rg_pos, gq);
+    rg_mat = qmat(gq);
   }
   for (int s = 0; s < m.nsensor; s++) {
     int site = m.sensor_objid[s], adr = m.sensor_adr[s], body = m.site_bodyid[site], type = m.sensor_type[s];
@@ -1637,13 +1663,14 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
 }
 
 // ------------------------------------------------------------------ integrator
-__device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L) {
+__device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L,
+                                   const real* Mg) {
   real h = m.timestep;
   bool damped = wv::ballot(L < m.nv && K.d_damping > 0) != 0ull;
   if (damped) {
     // (M + h*diag(damping)) qacc = qfrc_smooth + qfrc_constraint
     if (L < m.nv) {
-      for (int t = 0; t <= K.d_depth; t++) S[l.LD + K.d_Madr + t] = S[l.M + K.d_Madr + t] + (t == 0 ? h * K.d_damping : 0.0);
+      for (int t = 0; t <= K.d_depth; t++) S[l.LD + K.d_Madr + t] = Mg[K.d_Madr + t] + (t == 0 ? h * K.d_damping : 0.0);
       S[l.x + L] = S[l.smooth + L] + S[l.qfc + L];
     }
     wv::sync();
@@ -1727,11 +1754,11 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // data-store row (staged in the dead bias-force vector once the integrator is done; a program too large for that
   // reads HBM directly)
   const int ts = a.forward_only ? 0 : a.timestep[env];
-  // staging area at the end of the step: the five nv-vectors from the bias forces on, all dead after the integrator
+  // staging area at the end of the step: the four nv-vectors from the bias forces on, all dead after the integrator
   //   [action row | data-store row | prog_f (4 per op) | prog_i (8 ints per op) | obs_len, agent_body (ints)]
   const int n_act_row = a.n_agent * a.act_dim, n_store_row = a.n_agent * a.n_slot;
   const int t_store = n_act_row, t_pf = t_store + n_store_row, t_pi = t_pf + 4 * a.n_op, t_ag = t_pi + 4 * a.n_op;
-  const bool ops_staged = a.n_op > 0 && t_ag + a.n_agent <= 5 * m.nv && n_act_row <= 64 && 8 * a.n_op <= 64;
+  const bool ops_staged = a.n_op > 0 && t_ag + a.n_agent <= 4 * m.nv && n_act_row <= 64 && 8 * a.n_op <= 64;
   real act_reg = 0, store_reg = 0, pf_reg = 0;
   int pi_reg = 0, len_reg = 0, body_reg = 0;
   // the action row and its scatter indices, one element per lane, issued with the state loads (the scatter below would
@@ -1775,7 +1802,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     MJ_STAMP(ST_KIN)
     stage_com_inertia(m, l, K, S, L);
     MJ_STAMP(ST_COM)
-    stage_crb(m, l, K, S, L);
+    stage_crb(m, l, K, S, L, a.inertia + (size_t)env * m.nM);
     MJ_STAMP(ST_CRB)
     factor_ld(m, S, l.LD, l.Dinv, L);
     MJ_STAMP(ST_FACTOR)
@@ -1803,8 +1830,12 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       const int* I = (const int*)(S + l.ints);
       MJ_FOR(i, 3 * m.nbody) F[i] = S[l.xpos + i];
       MJ_FOR(i, 4 * m.nbody) F[3 * m.nbody + i] = S[l.xquat + i];
-      MJ_FOR(i, 3 * m.ngeom) F[7 * m.nbody + i] = S[l.gpos + i];
-      MJ_FOR(i, 4 * m.ngeom) F[7 * m.nbody + 3 * m.ngeom + i] = S[l.gquat + i];
+      MJ_FOR(g, m.ngeom) {
+        V3 gp; Quat gq;
+        geom_frame(m, l, S, g, gp, gq);
+        st3(F + 7 * m.nbody + 3 * g, gp);
+        stq(F + 7 * m.nbody + 3 * m.ngeom + 4 * g, gq);
+      }
       int ncon = I[I_NCON];
       if (L == 0) F[7 * m.nbody + 7 * m.ngeom] = ncon;
       MJ_FOR(c, m.nconmax) {
@@ -1812,7 +1843,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
         F[7 * m.nbody + 7 * m.ngeom + 2 + 2 * c] = c < ncon ? I[l.i_cong2 + c] : -1;
       }
     }
-    if (!a.forward_only) stage_euler(m, l, K, RK, S, L);
+    if (!a.forward_only) stage_euler(m, l, K, RK, S, L, a.inertia + (size_t)env * m.nM);
     if (ops_staged) {
       int* TI = (int*)(S + l.bias);
       if (L < n_act_row) S[l.bias + L] = act_reg;
@@ -1896,7 +1927,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
           V3 p = ld3(S + l.xpos + 3 * body) + rot(ldq(S + l.xquat + 4 * body), ld3(m.body_ipos + 3 * body));
           V3 t;
           if (pi[1] == 0) t = ld3(S + l.xpos + 3 * pi[2]) + rot(ldq(S + l.xquat + 4 * pi[2]), ld3(m.body_ipos + 3 * pi[2]));
-          else t = ld3(S + l.gpos + 3 * pi[2]);
+          else { Quat tq; geom_frame(m, l, S, pi[2], t, tq); }
           V3 d3 = p - t;
           real dist = sqrt(dot(d3, d3));
           if (pi[0] == OP_DIST_REWARD) {

@@ -14,7 +14,7 @@ _lib = None
 REGION_SHAPES = {
     "qpos": ("nq",), "qvel": ("nv",), "ctrl": ("nu",), "warm": ("nv",), "xpos": ("nbody", 3), "xquat": ("nbody", 4),
     "xanchor": ("njnt", 3), "xaxis": ("njnt", 3), "cinert": ("nbody", 10), "crb": ("nbody", 10), "cdof": ("nv", 6),
-    "cdofdot": ("nv", 6), "cvel": ("nbody", 6), "cacc": ("nbody", 6), "M": ("nM",), "LD": ("nM",), "Dinv": ("nv",),
+    "cdofdot": ("nv", 6), "cvel": ("nbody", 6), "cacc": ("nbody", 6), "LD": ("nM",), "Dinv": ("nv",),
     "gpos": ("ngeom", 3), "gquat": ("ngeom", 4), "bias": ("nv",), "smooth": ("nv",), "qaccs": ("nv",), "x": ("nv",),
     "qfc": ("nv",), "qacc": ("nv",), "con": ("nconmax", 15), "row": ("njmax", 4), "sens": ("nsensordata",),
 }
@@ -88,6 +88,23 @@ class LdsImage:
                     dense[r, d] = rows[r, 8 + t]
                 d, t = int(parent[d]), t + 1
         return dense
+
+    def M_from_factor(self):
+        """The sparse inertia matrix (dof_Madr layout) rebuilt from its L'DL factor: M[i][j] = sum over the dofs k at or
+        below i of L[k][i] D[k] L[k][j] (the kernel keeps the unfactorised M in an HBM scratch buffer, not in LDS)."""
+        m = self.model
+        ld, madr, depth, parent = self.region("LD"), m.dof_Madr, m.dof_depth, m.dof_parentid
+        out = np.zeros(m.nM)
+        for k in range(m.nv):
+            chain, d = [], k
+            while d >= 0:
+                chain.append(d); d = int(parent[d])
+            Dk = ld[madr[k]]
+            Lk = [1.0] + [ld[madr[k] + t] for t in range(1, int(depth[k]) + 1)]      # L[k][chain[t]]
+            for ti, i in enumerate(chain):
+                for tj in range(ti, len(chain)):                                    # chain[tj] is an ancestor of i
+                    out[madr[i] + (tj - ti)] += Lk[ti] * Dk * Lk[tj]
+        return out
 
     def contact_geoms(self):
         a, b = self._off("i_cong1"), self._off("i_cong2")

@@ -91,7 +91,7 @@ int emu_lds_offset(const void* blob, size_t nbytes, const char* region) {
   mj::make_layout(m, l);
 #define R(name) if (!strcmp(region, #name)) return l.name;
   R(qpos) R(qvel) R(ctrl) R(warm) R(xpos) R(xquat) R(xanchor) R(xaxis) R(com) R(cinert) R(crb) R(cdof) R(cdofdot)
-  R(cvel) R(cacc) R(M) R(LD) R(Dinv) R(gpos) R(gquat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
+  R(cvel) R(cacc) R(LD) R(Dinv) R(gpos) R(gquat) R(bias) R(smooth) R(qaccs) R(x) R(qfc) R(qacc) R(con) R(J) R(row)
   R(sens) R(ints) R(total) R(ldj) R(i_item) R(i_cong1) R(i_cong2) R(i_conadr) R(i_rowid) R(i_rowinfo)
 #undef R
   return -1;
@@ -109,7 +109,9 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   mj::Lay l;
   mj::make_layout(m, l);
   std::vector<double> lds(l.total, 0.0);
+  std::vector<double> inertia(m.nM > 0 ? m.nM : 1, 0.0);      // the per-copy HBM scratch of the real launch
   mj::StepArgs a{};
+  a.inertia = inertia.data();
   a.qpos = qpos; a.qvel = qvel; a.ctrl = ctrl; a.warm = warm; a.sensordata = sens; a.timestep = timestep;
   a.actions = actions; a.scatter = scatter; a.n_agent = n_agent; a.act_dim = act_dim; a.scatter_mode = scatter_mode;
   a.gather = gather; a.obs_dim = obs_dim; a.obs = obs;

