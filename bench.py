@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)     # one reference episode (maxSteps = 1024)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nconmax", type=int, default=None, help="contact cap per env copy (default: the compiler's)")
+    ap.add_argument("--njmax", type=int, default=None, help="constraint-row cap per env copy (default: the compiler's)")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-language", action="store_true", help="config 2: physics + gather only, no Language channel")
@@ -125,7 +127,8 @@ def main():
     from mjrl_amd.dynamics import Language
     plugins = [] if args.no_language else [Language]
     env = MuJoCoRL({"xmlPath": levels.level_path(LEVEL), "agents": AGENTS, "numEnvs": n_env, "deviceId": local,
-                    "skipFrames": 1, "maxSteps": 1024, "environmentDynamics": plugins})
+                    "skipFrames": 1, "maxSteps": 1024, "environmentDynamics": plugins,
+                    "nconmax": args.nconmax, "njmax": args.njmax})
     env.reset_batched()
     n_agent, obs_dim = len(AGENTS), env._handle.size("obs_dim")
     act_dim = 8 + len(plugins)
@@ -172,6 +175,10 @@ def main():
         wall = float(t.item())
     if not torch.isfinite(obs).all().item():
         raise SystemExit("non-finite observations after the timed region")
+    # frames (warm-up included) in which a copy ran into its contact / row cap, i.e. dropped work: must be zero
+    overflows = env._handle.cap_overflows()
+    if any(overflows):
+        print(f"bench: rank {rank}: {overflows[0]} frames hit nconmax, {overflows[1]} hit njmax -- raise the caps", file=sys.stderr)
 
     if rank == 0:
         m = env._compiled
@@ -190,7 +197,8 @@ def main():
             "config": {"workload": f"2-agent ant arena ({LEVEL} = benchmarking/levels/MultiAgentModel.xml, stand-in for the "
                                    f"unshipped MultiEnvs.xml), {n_env} env copies per GPU, skipFrames=1, PGS solver, "
                                    f"action scatter + physics step + per-agent obs gather fused in one launch",
-                       "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv, "obs_dim": obs_dim},
+                       "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv, "obs_dim": obs_dim,
+                       "nconmax": m.nconmax, "njmax": m.njmax, "cap_overflow_frames": list(overflows)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mjrl_step_kernel_spec" if env._handle.kernel == "specialised" else "mjrl_step_kernel",

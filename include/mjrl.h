@@ -129,6 +129,13 @@ int mjrl_lds_offset(const mjrl_env* env, const char* region);
 int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
                       unsigned long long* h_cycles, int n);
 
+/* Cap overflows since creation (or the last clearing call): h_counts[0] = physics frames, summed over env copies, whose
+ * contact list was cut at nconmax; h_counts[1] = frames whose constraint rows were cut at njmax.  The counterpart of
+ * MuJoCo's mjWARN_CONTACTFULL / mjWARN_CNSTRFULL counters in data.warning (the reference never reads them; mujoco
+ * 2.3.3 prints a warning).  A non-zero count means nconmax / njmax (config keys of the same names) are too small for
+ * the level.  clear != 0 zeroes the counters after reading. */
+int mjrl_cap_overflows(mjrl_env* env, unsigned long long* h_counts, int clear);
+
 /* Attach a model-specialised build of the step kernel: a gfx950 code object made from csrc/mjrl_spec_kernel.hip with
  * the model's sizes as compile-time constants (kernel_cache.py drives hipcc --genco and caches the result next to the
  * library).  The code object carries the sizes it was built for; a mismatch with this batch's model is an error and

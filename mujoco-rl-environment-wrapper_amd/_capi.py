@@ -19,7 +19,7 @@ SYMBOLS = [
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
-    "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel",
+    "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows",
 ]
 
 _lib = None
@@ -64,6 +64,7 @@ def load():
     L.mjrl_render_device.argtypes = [vp, ci, ci, vp]
     L.mjrl_render_host.argtypes = [vp, ci, ci, vp]
     L.mjrl_load_kernel.argtypes = [vp, ctypes.c_char_p]
+    L.mjrl_cap_overflows.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     _lib = L
     return L
 
@@ -102,6 +103,13 @@ class Handle:
         """Attach a model-specialised step kernel (``kernel_cache.code_object``); ``None`` returns to the generic one."""
         self._check(self._lib.mjrl_load_kernel(self._h, path.encode() if path else None))
         self.kernel = "specialised" if path else "generic"
+
+    def cap_overflows(self, clear: bool = False) -> tuple[int, int]:
+        """(frames cut at nconmax, frames cut at njmax), summed over the env copies since creation / the last clear --
+        MuJoCo's mjWARN_CONTACTFULL / mjWARN_CNSTRFULL counts."""
+        out = (ctypes.c_ulonglong * 2)()
+        self._check(self._lib.mjrl_cap_overflows(self._h, out, 1 if clear else 0))
+        return int(out[0]), int(out[1])
 
     def _check(self, rc):
         if rc:

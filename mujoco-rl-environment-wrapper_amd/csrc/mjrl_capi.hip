@@ -99,6 +99,7 @@ struct mjrl_env {
   hipStream_t stream = nullptr, own_stream = nullptr;
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
   double* inertia = nullptr;       // [n_env][nM] scratch: the sparse inertia matrix between the CRB stage and the integrator
+  unsigned long long* overflow = nullptr;   // [2] sticky cap-overflow counters (mjrl_cap_overflows)
   int* timestep = nullptr;
   unsigned char* d_mask = nullptr;
   // tables
@@ -154,7 +155,7 @@ void mjrl_destroy(mjrl_env* e) {
   void* ptrs[] = {e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
-                  e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia};
+                  e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia, e->overflow};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->spec_module) hipModuleUnload(e->spec_module);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
@@ -203,6 +204,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
   CK(hipMalloc(&e->warm, sizeof(double) * n_env * m.nv));
   CK(hipMalloc(&e->inertia, sizeof(double) * (size_t)n_env * (m.nM > 0 ? m.nM : 1)));
+  CK(hipMalloc(&e->overflow, sizeof(unsigned long long) * 2));
+  CK(hipMemset(e->overflow, 0, sizeof(unsigned long long) * 2));
   CK(hipMalloc(&e->sens, sizeof(double) * n_env * (m.nsensordata > 0 ? m.nsensordata : 1)));
   CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
   CK(hipMalloc(&e->d_mask, n_env));
@@ -407,6 +410,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   mj::StepArgs a{};
   a.qpos = e->qpos; a.qvel = e->qvel; a.ctrl = e->ctrl; a.warm = e->warm; a.sensordata = e->sens;
   a.inertia = e->inertia;
+  a.overflow = e->overflow;
   a.timestep = e->timestep;
   a.actions = nullptr; a.scatter = nullptr;
   a.n_agent = e->n_agent; a.act_dim = act_dim; a.scatter_mode = e->scatter_mode;
@@ -458,6 +462,16 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
       MJRL_HIP(e, hipGetLastError());
     }
   }
+  return 0;
+}
+
+int mjrl_cap_overflows(mjrl_env* e, unsigned long long* h_counts, int clear) {
+  if (!e) return 1;
+  if (!h_counts) MJRL_FAIL(e, 4, "cap_overflows: null output");
+  MJRL_HIP(e, hipSetDevice(e->device));
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  MJRL_HIP(e, hipMemcpy(h_counts, e->overflow, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost));
+  if (clear) MJRL_HIP(e, hipMemset(e->overflow, 0, sizeof(unsigned long long) * 2));
   return 0;
 }
 

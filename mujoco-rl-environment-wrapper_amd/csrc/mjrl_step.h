@@ -162,6 +162,10 @@ struct StepArgs {
   int* lpt_count_out;
   int* lpt_list_out;
   int* lpt_count_clear;        // [LPT_BUCKETS] the counts the NEXT launch files into: zeroed by workgroup 0 of this one
+  // Sticky count of physics frames that ran into a cap (what MuJoCo reports as mjWARN_CONTACTFULL / mjWARN_CNSTRFULL):
+  // [0] frames whose contact list was cut at nconmax, [1] frames whose row list was cut at njmax.  Not touched by
+  // forward-only launches.
+  unsigned long long* overflow;
 };
 enum { LPT_BUCKETS = 16 };
 
@@ -1887,6 +1891,11 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
     int pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
     a.lpt_list_out[(size_t)b * a.n_env + pos] = env;
+  }
+  if (a.overflow && !a.forward_only && a.skip_frames && L == 0) {
+    const int warn = ((const int*)(S + l.ints))[I_WARN];
+    if (warn & 1) wv::atomic_add(a.overflow + 0, 1ull);
+    if (warn & 2) wv::atomic_add(a.overflow + 1, 1ull);
   }
   if (a.forward_only || a.more_frames) {
     MJ_STAMP(ST_TAIL)

@@ -695,9 +695,11 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
         return rb[a] + rb[b]
     A["pair_bound"] = np.array([reach(a, b) + max(mg[a], mg[b]) for a, b in pairs], np.float64)
 
-    # caps per env copy (MuJoCo's <size nconmax njmax>): by default room for 8 contacts per kinematic tree and
-    # one limit row per limited joint plus a 4-row pyramid per contact
-    m.nconmax = int(nconmax) if nconmax is not None else min(64, 8 * max(m.ntree, 1))
+    # caps per env copy (MuJoCo's <size nconmax njmax>): by default room for 6 contacts per kinematic tree and
+    # one limit row per limited joint plus a 4-row pyramid per contact.  The caps size the constraint block of the
+    # copy's LDS image (16 doubles of Jacobian per row), i.e. how many copies a CU holds at once; a step that runs
+    # into one is counted (mjrl_cap_overflows) and the config keys ``nconmax`` / ``njmax`` raise them.
+    m.nconmax = int(nconmax) if nconmax is not None else min(64, 6 * max(m.ntree, 1))
     n_limited = int(np.sum(A["jnt_limited"]))
     m.njmax = int(njmax) if njmax is not None else n_limited + 4 * m.nconmax
 

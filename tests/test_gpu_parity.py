@@ -463,3 +463,29 @@ def test_wide_register_solver_on_the_gpu():
     assert wide_steps > 0
     assert rel(h.get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
     assert rel(h.get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
+
+
+def test_cap_overflows_are_counted_and_match_the_oracle():
+    """A copy that runs into nconmax drops the later contacts in detection order, as the oracle does, and every such
+    frame is counted (mjrl_cap_overflows = MuJoCo's mjWARN_CONTACTFULL count); with room for the contacts the count
+    stays zero."""
+    model, packed, h = make("sensor_touch.xml", 5, nconmax=2, njmax=8)
+    assert h.cap_overflows() == (0, 0)
+    ora = OracleEnv(packed)
+    cut = 0
+    for _ in range(40):
+        h.step_device(None, 0, 1)
+        ora.step()
+        cut += ora.warnings & 1
+    assert cut > 0
+    assert h.cap_overflows() == (5 * cut, 0)
+    assert np.allclose(h.get_field("qpos"), np.tile(ora.qpos, (5, 1)), atol=1e-10)
+    h.query("warn")                                      # forward-only launches do not count
+    assert h.cap_overflows(clear=True) == (5 * cut, 0)
+    assert h.cap_overflows() == (0, 0)
+    h.close()
+    model, packed, h = make("sensor_touch.xml", 5)
+    for _ in range(40):
+        h.step_device(None, 0, 1)
+    assert h.cap_overflows() == (0, 0)
+    h.close()
