@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import math
 import random
+import warnings
 
 import numpy as np
 
@@ -308,9 +309,20 @@ class MuJoCoParent:
                 self._init_environment()
                 if getattr(self, "_table_agents", None):
                     self._upload_tables(self._table_agents)
+        self.cap_overflows(report=True)
         self._handle.reset()
         self._obs_cache = None
         return self.get_sensor_data()
+
+    def cap_overflows(self, report: bool = False) -> tuple:
+        """(frames cut at nconmax, frames cut at njmax) over all copies since the last call -- MuJoCo's
+        mjWARN_CONTACTFULL / mjWARN_CNSTRFULL.  ``reset`` calls this once per episode and warns like MuJoCo does."""
+        counts = self._handle.cap_overflows(clear=True)
+        if report and any(counts):
+            warnings.warn(f"{counts[0]} physics frames ran into nconmax={self._compiled.nconmax} and {counts[1]} into "
+                          f"njmax={self._compiled.njmax} during the last episode: contacts were dropped; raise the "
+                          f"'nconmax' / 'njmax' config keys", RuntimeWarning, stacklevel=2)
+        return counts
 
     def mujoco_step(self):
         self._handle.step_host(None, 1)

@@ -489,3 +489,15 @@ def test_cap_overflows_are_counted_and_match_the_oracle():
         h.step_device(None, 0, 1)
     assert h.cap_overflows() == (0, 0)
     h.close()
+
+
+def test_env_class_warns_about_dropped_contacts_at_reset():
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 4, "nconmax": 1, "njmax": 20})
+    env.reset()
+    acts = np.zeros((4, 2, 8))
+    for _ in range(320):                                     # the ants land on four feet each: more than one contact
+        env.step_batched(acts)
+    with pytest.warns(RuntimeWarning, match="nconmax=1"):
+        env.reset()
+    assert env.cap_overflows() == (0, 0)
+    env.close()
