@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--njmax", type=int, default=None, help="constraint-row cap per env copy (default: the compiler's)")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="step the batch as this many independent groups on their own streams (1 = lockstep, the headline)")
+    ap.add_argument("--no-double-buffer", action="store_true", help="skip the secondary two-group measurement")
     ap.add_argument("--no-language", action="store_true", help="config 2: physics + gather only, no Language channel")
     args = ap.parse_args()
 
@@ -126,64 +129,98 @@ def main():
     n_env = args.envs_per_gpu
     from mjrl_amd.dynamics import Language
     plugins = [] if args.no_language else [Language]
-    env = MuJoCoRL({"xmlPath": levels.level_path(LEVEL), "agents": AGENTS, "numEnvs": n_env, "deviceId": local,
-                    "skipFrames": 1, "maxSteps": 1024, "environmentDynamics": plugins,
-                    "nconmax": args.nconmax, "njmax": args.njmax})
-    env.reset_batched()
-    n_agent, obs_dim = len(AGENTS), env._handle.size("obs_dim")
+    n_agent = len(AGENTS)
     act_dim = 8 + len(plugins)
     total_steps = args.warmup + args.steps
     # a cyclic buffer of ACT_RING steps of actions, resident in HBM before the timed region
     acts_host = action_stream(0, rank * n_env, n_env, ACT_RING, n_agent, act_dim)
-    acts = torch.from_numpy(acts_host).to(dev)
-    obs = torch.empty((n_env, n_agent, obs_dim), dtype=torch.float64, device=dev)
-    rew = torch.empty((n_env, n_agent), dtype=torch.float64, device=dev)
-    term = torch.empty((n_env, n_agent), dtype=torch.uint8, device=dev)
-    trunc = torch.empty((n_env, n_agent), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    env._handle.set_stream(stream.cuda_stream)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def one_step(i):
-        # episodes are maxSteps = 1024 steps long, like the reference's benchmark loop (fps_benchmark.py:33-41):
-        # every copy is reset when its episode is over; the reset launch is part of the timed workload
-        if i and i % 1024 == 0:
+    def timed_run(groups):
+        """The batch as `groups` env objects of n_env / groups copies, each on its own HIP stream (1: the whole batch
+        in lockstep on the current stream).  Returns (env objects, wall seconds, ms per step by HIP events, obs)."""
+        per = n_env // groups
+        envs, streams, bufs = [], [], []
+        for g in range(groups):
+            env = MuJoCoRL({"xmlPath": levels.level_path(LEVEL), "agents": AGENTS, "numEnvs": per, "deviceId": local,
+                            "skipFrames": 1, "maxSteps": 1024, "environmentDynamics": plugins,
+                            "nconmax": args.nconmax, "njmax": args.njmax})
+            stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
+            env._handle.set_stream(stream.cuda_stream)
             env.reset_batched()
-        env.step_batched(acts[i % ACT_RING], obs, rew, term, trunc)
+            obs_dim = env._handle.size("obs_dim")
+            acts = torch.from_numpy(np.ascontiguousarray(acts_host[:, g * per:(g + 1) * per])).to(dev)
+            bufs.append((acts,
+                         torch.empty((per, n_agent, obs_dim), dtype=torch.float64, device=dev),
+                         torch.empty((per, n_agent), dtype=torch.float64, device=dev),
+                         torch.empty((per, n_agent), dtype=torch.uint8, device=dev),
+                         torch.empty((per, n_agent), dtype=torch.uint8, device=dev)))
+            envs.append(env)
+            streams.append(stream)
+        torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize(dev)
-    barrier()
-    # HIP events on the stream the step kernel is launched on
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.warmup, total_steps):
-        one_step(i)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    barrier()
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    if not torch.isfinite(obs).all().item():
-        raise SystemExit("non-finite observations after the timed region")
+        def one_step(i):
+            # episodes are maxSteps = 1024 steps long, like the reference's benchmark loop (fps_benchmark.py:33-41):
+            # every copy is reset when its episode is over; the reset launch is part of the timed workload
+            for env, stream, (acts, obs, rew, term, trunc) in zip(envs, streams, bufs):
+                with torch.cuda.stream(stream):
+                    if i and i % 1024 == 0:
+                        env.reset_batched()
+                    env.step_batched(acts[i % ACT_RING], obs, rew, term, trunc)
+
+        for i in range(args.warmup):
+            one_step(i)
+        torch.cuda.synchronize(dev)
+        barrier()
+        # HIP events on the stream the step kernel is launched on
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(streams[0])
+        for i in range(args.warmup, total_steps):
+            one_step(i)
+        ev1.record(streams[0])
+        torch.cuda.synchronize(dev)
+        barrier()
+        wall = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / args.steps if groups == 1 else None
+        if world > 1:
+            t = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        for _, obs, _, _, _ in bufs:
+            if not torch.isfinite(obs).all().item():
+                raise SystemExit("non-finite observations after the timed region")
+        return envs, wall, kernel_ms
+
+    envs, wall, kernel_ms = timed_run(args.groups)
+    env = envs[0]
+    obs_dim = env._handle.size("obs_dim")
     # frames (warm-up included) in which a copy ran into its contact / row cap, i.e. dropped work: must be zero
-    overflows = env._handle.cap_overflows()
+    overflows = [sum(c) for c in zip(*(e._handle.cap_overflows() for e in envs))]
     if any(overflows):
         print(f"bench: rank {rank}: {overflows[0]} frames hit nconmax, {overflows[1]} hit njmax -- raise the caps", file=sys.stderr)
+    for e in envs[1:]:
+        e.close()
+    # Not the headline: the same batch as two half-batches that step independently on two streams (what a
+    # double-buffered sampler does: the policy works on one half while the other half steps).  The tail of one half's
+    # launch -- a few long solves -- then overlaps the body of the other's.
+    double_buffered = None
+    if world == 1 and args.groups == 1 and not args.no_double_buffer:
+        envs2, wall2, _ = timed_run(2)
+        double_buffered = {"groups": 2, "value": n_env * args.steps / wall2, "unit": "env-steps/s",
+                           "ms_per_step": wall2 / args.steps * 1e3}
+        for e in envs2:
+            e.close()
 
     if rank == 0:
         m = env._compiled
         bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * obs_dim, n_agent,
                                                    n_slot=len(plugins))
+        if kernel_ms is None:                 # several groups: launches overlap, the step time is the wall time's
+            kernel_ms = wall / args.steps * 1e3
         achieved = bytes_per * n_env / (kernel_ms * 1e-3) / 1e9
         traffic = None
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
@@ -198,12 +235,15 @@ def main():
                                    f"unshipped MultiEnvs.xml), {n_env} env copies per GPU, skipFrames=1, PGS solver, "
                                    f"action scatter + physics step + per-agent obs gather fused in one launch",
                        "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv, "obs_dim": obs_dim,
-                       "nconmax": m.nconmax, "njmax": m.njmax, "cap_overflow_frames": list(overflows)},
+                       "nconmax": m.nconmax, "njmax": m.njmax, "cap_overflow_frames": list(overflows),
+                       "groups": args.groups},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mjrl_step_kernel_spec" if env._handle.kernel == "specialised" else "mjrl_step_kernel",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
         }
+        if double_buffered:
+            line["double_buffered"] = double_buffered
         if world == 1 and not args.no_cpu_baseline:
             scatter = np.array([env.agents_action_index[a] for a in AGENTS])
             line["cpu_baseline"] = cpu_baseline(env._blob, scatter, language=bool(plugins))

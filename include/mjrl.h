@@ -129,6 +129,12 @@ int mjrl_lds_offset(const mjrl_env* env, const char* region);
 int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
                       unsigned long long* h_cycles, int n);
 
+/* Diagnostic: one step whose waves record when they ran.  h_out[3*w + 0..2] = start and end of workgroup w's wave on
+ * the device's constant 100 MHz clock and the env copy it stepped (w is the dispatch order, which the longest-first
+ * scheduling decouples from the copy index).  n must be 3 * n_env; skip_frames must be 1. */
+int mjrl_step_timeline(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
+                       unsigned long long* h_out, size_t n);
+
 /* Cap overflows since creation (or the last clearing call): h_counts[0] = physics frames, summed over env copies, whose
  * contact list was cut at nconmax; h_counts[1] = frames whose constraint rows were cut at njmax.  The counterpart of
  * MuJoCo's mjWARN_CONTACTFULL / mjWARN_CNSTRFULL counters in data.warning (the reference never reads them; mujoco

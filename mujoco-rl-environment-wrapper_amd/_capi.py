@@ -19,7 +19,7 @@ SYMBOLS = [
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
-    "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows",
+    "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
 ]
 
 _lib = None
@@ -65,6 +65,7 @@ def load():
     L.mjrl_render_host.argtypes = [vp, ci, ci, vp]
     L.mjrl_load_kernel.argtypes = [vp, ctypes.c_char_p]
     L.mjrl_cap_overflows.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    L.mjrl_step_timeline.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t]
     _lib = L
     return L
 
@@ -232,6 +233,13 @@ class Handle:
         out = np.zeros(len(self.STAGES), np.uint64)
         self._check(self._lib.mjrl_step_profile(self._h, None, 0, int(skip_frames), _host_ptr(out), out.size))
         return dict(zip(self.STAGES, out.tolist()))
+
+    def step_timeline(self, d_actions=None, act_dim=0):
+        """One step; ``[n_env, 3]`` uint64 per workgroup in dispatch order: wave start, wave end (100 MHz ticks), copy."""
+        out = np.zeros((self.n_env, 3), np.uint64)
+        self._check(self._lib.mjrl_step_timeline(self._h, ctypes.c_void_p(d_actions or 0), int(act_dim), 1,
+                                                 _host_ptr(out), out.size))
+        return out
 
     def step_debug(self, d_actions, act_dim, skip_frames, stage=0):
         out = np.zeros((self.n_env, self.size("lds_doubles")), np.float64)

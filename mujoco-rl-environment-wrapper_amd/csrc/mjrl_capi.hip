@@ -404,7 +404,7 @@ static int ensure_scatter(mjrl_env* e, int act_dim) {
 // mode: 0 = full step; 1 = forward pass only (no integration, no counters): reset observations and queries
 static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
                        uint8_t* d_term, uint8_t* d_trunc, double* d_dbg, int dbg_stage, int forward_only,
-                       unsigned long long* d_stamps = nullptr) {
+                       unsigned long long* d_stamps = nullptr, unsigned long long* d_timeline = nullptr) {
   if (skip_frames < 0) MJRL_FAIL(e, 3, "step: skip_frames must be >= 0");
   if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "step: observations requested but no gather table is set");
   mj::StepArgs a{};
@@ -425,6 +425,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.dbg_stage = dbg_stage;
   a.forward_only = forward_only;
   a.stamps = d_stamps;
+  a.timeline = d_timeline;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
   a.agent_body = e->d_agent_body; a.agent_obs_len = e->d_obs_len; a.store = e->store;
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
@@ -659,6 +660,22 @@ int mjrl_step_profile(mjrl_env* e, const double* d_actions, int act_dim, int ski
   if (!rc) {
     hipError_t he = hipStreamSynchronize(e->stream);
     if (he == hipSuccess) he = hipMemcpy(h_cycles, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { e->err = hipGetErrorString(he); rc = 100 + (int)he; }
+  }
+  hipFree(d);
+  return rc;
+}
+
+int mjrl_step_timeline(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, unsigned long long* h_out, size_t n) {
+  if (!e) return 1;
+  if (n != 3 * (size_t)e->n_env) MJRL_FAIL(e, 4, "step_timeline: expected room for %zu counters, got %zu", 3 * (size_t)e->n_env, n);
+  if (skip_frames != 1) MJRL_FAIL(e, 4, "step_timeline: one frame per step only");
+  unsigned long long* d = nullptr;
+  MJRL_HIP(e, hipMalloc(&d, sizeof(unsigned long long) * n));
+  int rc = launch_step(e, d_actions, act_dim, skip_frames, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, d);
+  if (!rc) {
+    hipError_t he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = hipMemcpy(h_out, d, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
     if (he != hipSuccess) { e->err = hipGetErrorString(he); rc = 100 + (int)he; }
   }
   hipFree(d);

@@ -166,6 +166,9 @@ struct StepArgs {
   // [0] frames whose contact list was cut at nconmax, [1] frames whose row list was cut at njmax.  Not touched by
   // forward-only launches.
   unsigned long long* overflow;
+  // diagnostic: [n_env][3] per workgroup, in dispatch order: start and end of the wave on the constant 100 MHz clock
+  // and the copy it stepped; null outside tools/timeline_probe.py
+  unsigned long long* timeline;
 };
 enum { LPT_BUCKETS = 16 };
 
@@ -1712,6 +1715,7 @@ __device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK&
 __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   const int L = wv::lane();
   int env = wv::env_index();
+  const unsigned long long t_begin = a.timeline ? wv::realtime() : 0ull;
   if (a.lpt_count_in) {
     // workgroup id -> copy: walk the buckets from the heaviest down
     // (the bucket counts come in with one load, lane b holding bucket b's; walking them is register work -- a loop of
@@ -1897,9 +1901,15 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     if (warn & 1) wv::atomic_add(a.overflow + 0, 1ull);
     if (warn & 2) wv::atomic_add(a.overflow + 1, 1ull);
   }
+#define MJ_TIMELINE                                                                        \
+  if (a.timeline && L == 0) {                                                              \
+    unsigned long long* tl = a.timeline + 3 * (size_t)wv::env_index();                     \
+    tl[0] = t_begin; tl[1] = wv::realtime(); tl[2] = (unsigned long long)env;              \
+  }
   if (a.forward_only || a.more_frames) {
     MJ_STAMP(ST_TAIL)
     if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+    MJ_TIMELINE
     return;
   }
   // truncation is evaluated before the counter moves (mujoco_rl.py:279,288)
@@ -1963,6 +1973,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   if (L == 0) a.timestep[env] = ts + 1;
   MJ_STAMP(ST_TAIL)
   if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+  MJ_TIMELINE
+#undef MJ_TIMELINE
 #undef MJ_STAMP
 #undef MJ_FOR
 }

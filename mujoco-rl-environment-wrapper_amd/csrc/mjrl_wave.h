@@ -28,6 +28,8 @@ __device__ __forceinline__ unsigned long long ballot(bool pred) { return __ballo
 __device__ __forceinline__ int popc(unsigned long long x) { return __popcll(x); }
 // wave clock (s_memtime) and a device-scope counter add, for the diagnostic stage stamps only
 __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)clock64(); }
+// constant-rate counter shared by every CU (100 MHz): comparable between waves, unlike the shader clock
+__device__ __forceinline__ unsigned long long realtime() { return (unsigned long long)wall_clock64(); }
 __device__ __forceinline__ void atomic_add(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 // device-scope counter add returning the old value (work-bucket slots of the longest-first dispatch)
 __device__ __forceinline__ int atomic_add_int(int* p, int v) { return atomicAdd(p, v); }

@@ -47,6 +47,7 @@ inline unsigned long long ballot(bool pred) {
 }
 inline int popc(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long clock() { return 0; }
+inline unsigned long long realtime() { return 0; }
 inline void atomic_add(unsigned long long* p, unsigned long long v) { *p += v; }
 inline int atomic_add_int(int* p, int v) { int old = *p; *p += v; return old; }
 inline double sum_n(double v, int width) {   // all-reduce over aligned groups of `width` lanes (16, 32 or 64)

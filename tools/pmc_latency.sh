@@ -5,7 +5,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 260 > $OUT/$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-double-buffer --steps 40 --warmup 260 > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 run l1 SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES
 run l2 SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS

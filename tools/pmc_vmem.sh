@@ -6,7 +6,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 260 --envs-per-gpu $N > $OUT/$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-double-buffer --steps 40 --warmup 260 --envs-per-gpu $N > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 run v1 TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum
 run v2 TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum

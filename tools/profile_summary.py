@@ -35,7 +35,7 @@ CAL_BYTES = 512 << 20
 fc, wc = CAL_BYTES / (cal_fetch * 1024), CAL_BYTES / (cal_write * 1024)
 hbm = fetch_kb * 1024 * fc + write_kb * 1024 * wc
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --steps 256   [tools/profile_run.sh, tools/profile_summary.py]",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-double-buffer --steps 256   [tools/profile_run.sh, tools/profile_summary.py]",
     "kernel": name, "envs_per_launch": ENVS, "launches_sampled": n,
     "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
     "calibration": {"bytes_read": CAL_BYTES, "bytes_written": CAL_BYTES, "FETCH_SIZE_KB": cal_fetch, "WRITE_SIZE_KB": cal_write,

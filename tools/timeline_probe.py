@@ -1,0 +1,53 @@
+"""When do the waves of one step launch run?  Per-wave start / end times (constant 100 MHz clock) of a launch in the
+contact regime: how full the machine is over the launch, how long a wave takes, what the last waves to finish are."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import __graft_entry__ as entry
+entry.load_package()
+from mjrl_amd import mjcf, levels, blob, _capi
+
+n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+m = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+h = _capi.Handle(blob.pack(m), n_env)
+h.reset()
+h.set_scatter_tables([list(range(m.nu))], 0)
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+ring = torch.from_numpy(rng.uniform(-1, 1, (64, n_env, m.nu))).to(dev)
+ioff = h.lds_offset("ints")
+for t in range(400):
+    h.step_device(ring[t % 64].data_ptr(), m.nu, 1)
+prev = None
+for rep in range(3):
+    tl = h.step_timeline(ring[(400 + rep) % 64].data_ptr(), m.nu).astype(np.int64)
+    start, end, env = tl[:, 0], tl[:, 1], tl[:, 2]
+    t0 = start.min()
+    start, end = (start - t0) / 100.0, (end - t0) / 100.0          # microseconds
+    dur = end - start
+    total = end.max()
+    print(f"launch {rep}: {total:.1f} us from first wave start to last wave end; wave duration mean {dur.mean():.1f} "
+          f"p50 {np.percentile(dur, 50):.1f} p90 {np.percentile(dur, 90):.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f} us; "
+          f"sum of durations / (2048 slots x launch) = {dur.sum() / (2048 * total):.2f}")
+    edges = np.linspace(0, total, 11)
+    occ = [(np.minimum(end, b) - np.maximum(start, a)).clip(0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
+    print("  waves in flight per tenth of the launch: " + " ".join(f"{o:6.0f}" for o in occ))
+    order = np.argsort(start)
+    k = n_env // 8
+    print("  by dispatch order (eighths): start " + " ".join(f"{start[order[i * k:(i + 1) * k]].mean():6.1f}" for i in range(8)))
+    print("                            duration " + " ".join(f"{dur[order[i * k:(i + 1) * k]].mean():6.1f}" for i in range(8)))
+    last = np.argsort(end)[-5:]
+    print("  last five waves: " + "; ".join(f"wg {w} start {start[w]:.1f} dur {dur[w]:.1f}" for w in last))
+    # how well does the previous step predict this one?  (the heaviest 2 % of the waves)
+    d_env = np.zeros(n_env); d_env[env] = dur
+    pos_env = np.zeros(n_env, np.int64); pos_env[env[order]] = np.arange(n_env)
+    if prev is not None:
+        heavy = np.argsort(d_env)[-n_env // 50:]
+        rank_prev = np.argsort(np.argsort(prev))[heavy]
+        print(f"  heaviest 2% now: previous-step duration rank median {np.median(rank_prev):.0f} min {rank_prev.min()} of {n_env}; "
+              f"dispatch position median {np.median(pos_env[heavy]):.0f} max {pos_env[heavy].max()}; "
+              f"in the second round: {(pos_env[heavy] >= 2048).sum()} of {heavy.size}; corr(prev dur, dur) {np.corrcoef(prev, d_env)[0, 1]:.2f}")
+    prev = d_env
+h.close()
