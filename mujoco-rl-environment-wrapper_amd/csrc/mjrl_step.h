@@ -60,8 +60,9 @@ struct Lay {
   int i_item, i_cong1, i_cong2, i_conadr, i_rowid, i_rowinfo;
 };
 
-// structure tables in LDS: every value is a dof / body / geom id (< 64), a depth, a type, or an address inside the sparse inertia layout
-__host__ __device__ inline bool tab_in_bytes(const DevModel& m) { return m.nM <= 256; }
+// structure tables in LDS, one byte per entry when every value fits: dof ids and counts (<= nv), body ids + 1 (<= nbody),
+// depths, geom types, and addresses inside the sparse inertia layout (< nM); 16-bit words otherwise
+__host__ __device__ inline bool tab_in_bytes(const DevModel& m) { return m.nM <= 256 && m.nv < 255 && m.nbody < 255; }
 __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   int o = 0;
 #define REG(name, n) l.name = o; o += (n);
