@@ -21,7 +21,19 @@ ioff = h.lds_offset("ints")
 for t in range(400):
     h.step_device(ring[t % 64].data_ptr(), m.nu, 1)
 prev = None
+h2 = _capi.Handle(blob.pack(m), n_env)          # replays the step with a debug dump: rows and sweeps of every copy
+h2.reset()
+h2.set_scatter_tables([list(range(m.nu))], 0)
+info_at = h.lds_offset("i_rowinfo")
 for rep in range(3):
+    for f in ("qpos", "qvel", "qacc_warmstart", "ctrl"):
+        h2.set_field(f, h.get_field(f))
+    img = h2.step_debug(ring[(400 + rep) % 64].data_ptr(), m.nu, 1, 0)
+    ints = img[:, ioff:ioff + (info_at + m.njmax + 1) // 2 + 1].copy().view(np.int32)
+    nefc, niter = ints[:, 1], ints[:, 3]
+    trees = (ints[:, info_at:info_at + m.njmax] >> 19) - 2
+    valid = np.arange(m.njmax)[None, :] < nefc[:, None]
+    per_tree = np.stack([((trees == k) & valid).sum(1) for k in range(m.ntree)], 1).max(1)
     tl = h.step_timeline(ring[(400 + rep) % 64].data_ptr(), m.nu).astype(np.int64)
     start, end, env = tl[:, 0], tl[:, 1], tl[:, 2]
     t0 = start.min()
@@ -39,7 +51,11 @@ for rep in range(3):
     print("  by dispatch order (eighths): start " + " ".join(f"{start[order[i * k:(i + 1) * k]].mean():6.1f}" for i in range(8)))
     print("                            duration " + " ".join(f"{dur[order[i * k:(i + 1) * k]].mean():6.1f}" for i in range(8)))
     last = np.argsort(end)[-5:]
-    print("  last five waves: " + "; ".join(f"wg {w} start {start[w]:.1f} dur {dur[w]:.1f}" for w in last))
+    print("  last five waves: " + "; ".join(f"wg {w} start {start[w]:.1f} dur {dur[w]:.1f} rows/tree {per_tree[env[w]]} sweeps {niter[env[w]]}" for w in last))
+    wide = per_tree[env] > 16
+    print(f"  waves with 17+ rows in a tree (wide solver): {wide.sum()}, duration mean {dur[wide].mean() if wide.any() else 0:.1f} max {dur[wide].max() if wide.any() else 0:.1f}; "
+          f"of the 20 longest waves {wide[np.argsort(dur)[-20:]].sum()} are wide; 16-row solver waves with 60+ sweeps: {((~wide) & (niter[env] >= 60)).sum()}, "
+          f"duration mean {dur[(~wide) & (niter[env] >= 60)].mean():.1f}")
     # how well does the previous step predict this one?  (the heaviest 2 % of the waves)
     d_env = np.zeros(n_env); d_env[env] = dur
     pos_env = np.zeros(n_env, np.int64); pos_env[env[order]] = np.arange(n_env)
