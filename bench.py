@@ -113,6 +113,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank control flow on a box with one GPU: every rank on device 0, gloo instead of RCCL
+    rehearsal = os.environ.get("MJRL_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
@@ -120,7 +124,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     entry.load_package()
     from mjrl_amd import levels
@@ -187,7 +194,7 @@ def main():
         wall = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / args.steps if groups == 1 else None
         if world > 1:
-            t = torch.tensor([wall], dtype=torch.float64, device=dev)
+            t = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         for _, obs, _, _, _ in bufs:
