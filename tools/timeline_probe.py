@@ -10,7 +10,8 @@ entry.load_package()
 from mjrl_amd import mjcf, levels, blob, _capi
 
 n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-m = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+level = sys.argv[2] if len(sys.argv) > 2 else "two_agent.xml"
+m = mjcf.compile_mjcf(levels.level_path(level))
 h = _capi.Handle(blob.pack(m), n_env)
 h.reset()
 h.set_scatter_tables([list(range(m.nu))], 0)
@@ -18,6 +19,7 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 ring = torch.from_numpy(rng.uniform(-1, 1, (64, n_env, m.nu))).to(dev)
 ioff = h.lds_offset("ints")
+slots = 256 * min(8, int(160 * 1024 // ((h.size("lds_doubles") * 8 + 1279) // 1280 * 1280)))      # wave slots of the chip for this image
 for t in range(400):
     h.step_device(ring[t % 64].data_ptr(), m.nu, 1)
 prev = None
@@ -42,7 +44,7 @@ for rep in range(3):
     total = end.max()
     print(f"launch {rep}: {total:.1f} us from first wave start to last wave end; wave duration mean {dur.mean():.1f} "
           f"p50 {np.percentile(dur, 50):.1f} p90 {np.percentile(dur, 90):.1f} p99 {np.percentile(dur, 99):.1f} max {dur.max():.1f} us; "
-          f"sum of durations / (2048 slots x launch) = {dur.sum() / (2048 * total):.2f}")
+          f"sum of durations / ({slots} slots x launch) = {dur.sum() / (slots * total):.2f}")
     edges = np.linspace(0, total, 11)
     occ = [(np.minimum(end, b) - np.maximum(start, a)).clip(0).sum() / (b - a) for a, b in zip(edges[:-1], edges[1:])]
     print("  waves in flight per tenth of the launch: " + " ".join(f"{o:6.0f}" for o in occ))
@@ -51,6 +53,9 @@ for rep in range(3):
     print("  by dispatch order (eighths): start " + " ".join(f"{start[order[i * k:(i + 1) * k]].mean():6.1f}" for i in range(8)))
     print("                            duration " + " ".join(f"{dur[order[i * k:(i + 1) * k]].mean():6.1f}" for i in range(8)))
     last = np.argsort(end)[-5:]
+    two_tree = ((trees == -2) & valid).sum(1)
+    print(f"  copies with rows that couple two trees (serial sweep): {(two_tree > 0).sum()}, their wave duration mean "
+          f"{dur[np.isin(env, np.nonzero(two_tree > 0)[0])].mean() if (two_tree > 0).any() else 0:.1f} us; copies with 17+ rows in a tree: {(per_tree > 16).sum()}")
     print("  last five waves: " + "; ".join(f"wg {w} start {start[w]:.1f} dur {dur[w]:.1f} rows/tree {per_tree[env[w]]} sweeps {niter[env[w]]}" for w in last))
     wide = per_tree[env] > 16
     print(f"  waves with 17+ rows in a tree (wide solver): {wide.sum()}, duration mean {dur[wide].mean() if wide.any() else 0:.1f} max {dur[wide].max() if wide.any() else 0:.1f}; "
