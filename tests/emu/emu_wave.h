@@ -70,6 +70,7 @@ template <bool HIGH>
 inline double half_to_all(double v) { return shfl(v, (lane() & 31) + (HIGH ? 32 : 0)); }
 inline double sum16(double v) { return sum_n(v, 16); }
 inline int lane_int(int v, int src) { return shfl(v, src); }
+inline double lane_value(double v, int src) { return shfl(v, src); }
 inline double rows4_sum(double v) { return (shfl(v, 0) + shfl(v, 16)) + (shfl(v, 32) + shfl(v, 48)); }
 inline double rows_sum(double v, int rows) {
   if (rows <= 1) return shfl(v, 0);
