@@ -39,10 +39,14 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
 // geom-type switch is wave-uniform.  Camera convention of the reference's renderer: looks along -z, +x right, +y up,
 // vertical field of view fovy, rows stored bottom-up (glReadPixels order), uint8 RGB.
 __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* qpos, int n_env, int width, int height,
-                                                         unsigned char* rgb) {
+                                                         int tiles, unsigned char* rgb) {
+  // grid (n_env, ncam * tiles): a wave renders a group of 8x8 pixel blocks of one camera of one env copy -- with one
+  // wave per copy a batch of 512 copies (BASELINE config 5) left three quarters of the chip's wave slots empty.
+  // Every wave redoes the copy's kinematics.
   extern __shared__ double lds[];
   using namespace mj;
-  const int L = wv::lane(), env = wv::env_index();
+  const int L = wv::lane(), env = blockIdx.x;
+  const int cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
   real* S = lds;
   Lay l;
   make_layout(m, l);
@@ -53,35 +57,84 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   wv::sync();
   stage_kinematics(m, l, K, S, L);
   stage_geoms(m, l, S, L);
-  for (int cam = 0; cam < m.ncam; cam++) {
-    int body = m.cam_bodyid[cam];
-    Quat bq = ldq(S + l.xquat + 4 * body);
-    V3 cp = ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.cam_pos + 3 * cam));
-    M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
-    real t = tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (real)width / (real)height;
-    unsigned char* img = rgb + ((size_t)env * m.ncam + cam) * width * height * 3;
-    for (int pix = L; pix < width * height; pix += 64) {
-      int r = pix / width, c = pix % width;
-      V3 vec = normalized(mul(cm, v3((2.0 * (c + 0.5) / width - 1.0) * t * aspect, (2.0 * (r + 0.5) / height - 1.0) * t, -1.0)), 0);
-      real best = -1;
-      int hit = -1;
-      for (int g = 0; g < m.ngeom; g++) {
-        if (m.geom_rgba[4 * g + 3] == 0) continue;
-        real x = ray_geom(m.geom_type[g], ld3(S + l.gpos + 3 * g), qmat(ldq(S + l.gquat + 4 * g)), ld3(S + l.gsize + 3 * g), cp, vec);
-        if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
-      }
-      unsigned char out[3] = {0, 0, 0};
-      if (hit >= 0) {
-        V3 n = geom_normal(m.geom_type[hit], ld3(S + l.gpos + 3 * hit), qmat(ldq(S + l.gquat + 4 * hit)),
-                           ld3(S + l.gsize + 3 * hit), cp + vec * best);
-        real shade = 0.4 + 0.6 * fmax(-dot(n, vec), 0.0);
-        for (int k = 0; k < 3; k++)
-          out[k] = (unsigned char)(255.0 * fmin(fmax(m.geom_rgba[4 * hit + k], 0.0), 1.0) * shade + 0.5);
-      }
-      img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2];
+  // the geoms' rotation matrices, once per wave (behind the step image): the pixel loop reads them for every ray
+  real* GM = S + l.total;
+  for (int g = L; g < m.ngeom; g += 64) {
+    M3 gm = qmat(ldq(S + l.gquat + 4 * g));
+    for (int k = 0; k < 9; k++) GM[9 * g + k] = gm.m[k];
+  }
+  wv::sync();
+  const int body = m.cam_bodyid[cam];
+  const Quat bq = ldq(S + l.xquat + 4 * body);
+  const V3 cp = ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.cam_pos + 3 * cam));
+  const M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
+  const real t = tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (real)width / (real)height;
+  unsigned char* img = rgb + ((size_t)env * m.ncam + cam) * width * height * 3;
+  // The wave's 64 rays cover an 8x8 block of pixels at a time.  Lane g first tests geom g's bounding sphere against the
+  // block's bounding cone (all geoms at once); the rays then visit only the geoms that passed, each ray with its own
+  // bounding-sphere test (the same conservative one as the rangefinder's, stage_sensors) before the type-specific one.
+  const int bw = (width + 7) / 8, nblock = bw * ((height + 7) / 8);
+  const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
+  auto pixel_ray = [&](real px, real py) {        // px, py in pixel units, pixel centres at +0.5
+    return normalized(mul(cm, v3((2.0 * px / width - 1.0) * t * aspect, (2.0 * py / height - 1.0) * t, -1.0)), 0);
+  };
+  const bool my_geom = L < m.ngeom && m.geom_rgba[4 * (L < m.ngeom ? L : 0) + 3] != 0;
+  const int my_type = my_geom ? m.geom_type[L] : -1;
+  const real my_rb = my_geom ? m.geom_rbound[L] : 0.0;
+  const V3 my_rel = (my_geom ? ld3(S + l.gpos + 3 * L) : cp) - cp;
+  for (int blk = blk0; blk < blk1; blk++) {
+    const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 8;
+    const V3 axis = pixel_ray(c0 + 4.0, r0 + 4.0);
+    real cosmin = 1.0;
+    for (int k = 0; k < 4; k++)
+      cosmin = fmin(cosmin, dot(axis, pixel_ray(c0 + ((k & 1) ? 7.5 : 0.5), r0 + ((k & 2) ? 7.5 : 0.5))));
+    const real cos_t = cosmin * (1.0 - 1e-9) - 1e-12, sin_t = sqrt(fmax(1.0 - cos_t * cos_t, 0.0));
+    bool cand = my_geom;
+    if (my_geom && my_type != GEOM_PLANE) {
+      const real along = dot(my_rel, axis), perp = sqrt(fmax(dot(my_rel, my_rel) - along * along, 0.0));
+      // (perp cos - along sin is a lower bound of the centre's distance to the cone, negative inside it)
+      cand = !(along + my_rb < -1e-9) && perp * cos_t - along * sin_t <= my_rb * (1.0 + 1e-9) + 1e-9;
     }
+    unsigned long long todo = wv::ballot(cand);
+    const int r = r0 + (L >> 3), c = c0 + (L & 7);
+    const bool inside = r < height && c < width;
+    const int pix = r * width + c;
+    const V3 vec = pixel_ray(c + 0.5, r + 0.5);
+    real best = -1;
+    int hit = -1;
+    while (todo) {
+      const int g = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      int gt = m.geom_type[g];
+      const V3 gp = ld3(S + l.gpos + 3 * g);
+      if (!inside) gt = -1;
+      else if (gt != GEOM_PLANE) {
+        const real rb = m.geom_rbound[g];
+        V3 rel = gp - cp;
+        real along = dot(rel, vec), d2 = dot(rel, rel) - along * along;
+        if (d2 > rb * rb * (1.0 + 1e-9) + 1e-12 || along + rb < -1e-9) gt = -1;
+      }
+      if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
+      M3 gm;
+      for (int k = 0; k < 9; k++) gm.m[k] = GM[9 * g + k];
+      real x = ray_geom(gt, gp, gm, ld3(S + l.gsize + 3 * g), cp, vec);
+      if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
+    }
+    unsigned char out[3] = {0, 0, 0};
+    if (hit >= 0) {
+      M3 gm;
+      for (int k = 0; k < 9; k++) gm.m[k] = GM[9 * hit + k];
+      V3 n = geom_normal(m.geom_type[hit], ld3(S + l.gpos + 3 * hit), gm, ld3(S + l.gsize + 3 * hit), cp + vec * best);
+      real shade = 0.4 + 0.6 * fmax(-dot(n, vec), 0.0);
+      for (int k = 0; k < 3; k++)
+        out[k] = (unsigned char)(255.0 * fmin(fmax(m.geom_rgba[4 * hit + k], 0.0), 1.0) * shade + 0.5);
+    }
+    if (inside) { img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2]; }
   }
 }
+
+// the render kernel's LDS: the step image plus one rotation matrix per geom
+inline size_t render_lds_bytes(const mj::Lay& lay, const DevModel& m) { return ((size_t)lay.total + 9 * (size_t)m.ngeom) * sizeof(double); }
 
 std::string g_create_error;
 
@@ -216,7 +269,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     CK(hipMalloc(&e->lpt_list[g], sizeof(int) * mj::LPT_BUCKETS * (size_t)n_env));
   }
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  CK(hipFuncSetAttribute((const void*)mjrl_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CK(hipFuncSetAttribute((const void*)mjrl_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                         (int)render_lds_bytes(e->lay, m)));
 #undef CK
   if (launch_reset(e, nullptr)) return fail(6, e->err);
   he = hipStreamSynchronize(e->stream);
@@ -594,9 +648,14 @@ int mjrl_get_field(mjrl_env* e, const char* name, void* h_out, size_t nbytes) {
 int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
   if (width <= 0 || height <= 0 || !d_rgb) MJRL_FAIL(e, 3, "render: bad arguments");
   if (e->hm.ncam == 0) MJRL_FAIL(e, 3, "render: the level has no cameras");
-  size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
-  hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->dm, e->qpos, e->n_env, width,
-                     height, d_rgb);
+  const size_t lds_bytes = render_lds_bytes(e->lay, e->hm);
+  // groups of 8x8 pixel blocks per camera: enough workgroups to fill the chip's wave slots a few times over, at
+  // least 4 blocks each (every workgroup repeats the copy's kinematics)
+  const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
+  int tiles = (int)((8 * 2048 + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
+  tiles = std::max(1, std::min(tiles, std::max(1, nblock / 4)));
+  hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), lds_bytes, e->stream, e->dm, e->qpos,
+                     e->n_env, width, height, tiles, d_rgb);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }

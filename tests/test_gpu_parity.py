@@ -501,3 +501,28 @@ def test_env_class_warns_about_dropped_contacts_at_reset():
         env.reset()
     assert env.cap_overflows() == (0, 0)
     env.close()
+
+
+def test_render_block_tiling_at_odd_sizes_and_batch_sizes():
+    """The render kernel works in 8x8 pixel blocks, several workgroups per camera, with a block-level cone cull in
+    front of the per-ray tests: image sizes that are no multiple of 8 and batch sizes that change the number of
+    workgroups per camera must give the same pixels as the oracle's plain per-pixel loop."""
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    packed = blob.pack(model)
+    ora = OracleEnv(packed)
+    rng = np.random.default_rng(9)
+    for _ in range(300):
+        ora.ctrl[:] = rng.uniform(-1, 1, model.nu)
+        ora.step()
+    for n_env, (w, h) in ((1, (37, 21)), (5, (64, 64)), (40, (20, 12))):
+        handle = _capi.Handle(packed, n_env)
+        handle.reset()
+        handle.set_field("qpos", np.tile(ora.qpos, (n_env, 1)))
+        got = handle.render(w, h).astype(int)                      # [n_env, ncam, h, w, 3]
+        for cam in range(got.shape[1]):
+            ref = ora.render(cam, w, h).reshape(h, w, 3).astype(int)
+            for e in (0, n_env - 1):
+                differ = np.abs(ref - got[e, cam]).max(axis=-1) > 0
+                assert differ.mean() < 0.004, (n_env, w, h, cam, differ.mean())
+            assert (got[:, cam] == got[0, cam]).all()
+        handle.close()
