@@ -652,7 +652,8 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
   // groups of 8x8 pixel blocks per camera: enough workgroups to fill the chip's wave slots a few times over, at
   // least 4 blocks each (every workgroup repeats the copy's kinematics)
   const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
-  int tiles = (int)((8 * 2048 + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
+  const int target = 8 * 2048;       // (flat between 4 and 32 times the chip's 2048 wave slots, tools/render_rate.py)
+  int tiles = (int)((target + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
   tiles = std::max(1, std::min(tiles, std::max(1, nblock / 4)));
   hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), lds_bytes, e->stream, e->dm, e->qpos,
                      e->n_env, width, height, tiles, d_rgb);
