@@ -105,16 +105,17 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
     while (todo) {
       const int g = __builtin_ctzll(todo);
       todo &= todo - 1;
-      int gt = m.geom_type[g];
-      const V3 gp = ld3(S + l.gpos + 3 * g);
+      // (geom g's type, bounding radius and position come from lane g's registers: no memory latency per candidate)
+      int gt = wv::lane_int(my_type, g);
+      const V3 rel = v3(wv::lane_value(my_rel.x, g), wv::lane_value(my_rel.y, g), wv::lane_value(my_rel.z, g));
       if (!inside) gt = -1;
       else if (gt != GEOM_PLANE) {
-        const real rb = m.geom_rbound[g];
-        V3 rel = gp - cp;
+        const real rb = wv::lane_value(my_rb, g);
         real along = dot(rel, vec), d2 = dot(rel, rel) - along * along;
         if (d2 > rb * rb * (1.0 + 1e-9) + 1e-12 || along + rb < -1e-9) gt = -1;
       }
       if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
+      const V3 gp = ld3(S + l.gpos + 3 * g);
       M3 gm;
       for (int k = 0; k < 9; k++) gm.m[k] = GM[9 * g + k];
       real x = ray_geom(gt, gp, gm, ld3(S + l.gsize + 3 * g), cp, vec);
