@@ -1229,6 +1229,44 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
 }
 #undef MJ_ROWS32
 
+// Row lists for a copy in which some rows couple two kinematic trees (tree-row lane map): list[t * C + p] = the row
+// tree t steps at position p of a sweep, -1 for none, C = njmax / ntree, written over the row-id array.  Rows keep
+// their solver order inside every tree, and a coupling row takes the first position that is free in both its trees.
+// Returns false (lists unusable) when a list would outgrow its C entries; `len` receives the sweep length.
+__device__ inline bool pgs_coupled_schedule(const DevModel& m, const Lay& l, real* S, int L, int nefc, int& len) {
+  int* I = (int*)(S + l.ints);
+  const Tab T = make_tab(m, l, S);
+  len = 0;
+  if (m.ntree > 4 || m.ntree < 1) return false;
+  const int C = m.njmax / m.ntree, n = wv::first_int(nefc);
+  for (int k = L; k < m.ntree * C; k += 64) I[l.i_rowid + k] = -1;
+  wv::sync();
+  int n0 = 0, n1 = 0, n2 = 0, n3 = 0;        // entries used in each tree's list (wave-uniform)
+  bool fits = true;
+  auto used = [&](int t) { return t == 0 ? n0 : (t == 1 ? n1 : (t == 2 ? n2 : n3)); };
+  auto set_used = [&](int t, int v) { if (t == 0) n0 = v; else if (t == 1) n1 = v; else if (t == 2) n2 = v; else n3 = v; };
+  for (int i = 0; i < n; i++) {
+    const int info = wv::first_int(I[l.i_rowinfo + i]);
+    const int rt = (info >> CHAIN_BITS) - 2;
+    if (rt >= 0) {
+      const int p = used(rt);
+      if (p < C) { if (L == 0) I[l.i_rowid + rt * C + p] = i; } else fits = false;
+      set_used(rt, p + 1);
+    } else {
+      const int t1 = wv::first_int(T.dof_tree(info & 63)), t2 = wv::first_int(T.dof_tree(((info >> 9) & 127) - 1));
+      const int p1 = used(t1), p2 = used(t2), p = p1 > p2 ? p1 : p2;
+      if (p < C) { if (L == 0) { I[l.i_rowid + t1 * C + p] = i; I[l.i_rowid + t2 * C + p] = i; } } else fits = false;
+      set_used(t1, p + 1);
+      set_used(t2, p + 1);
+    }
+  }
+  len = n0 > n1 ? n0 : n1;
+  len = n2 > len ? n2 : len;
+  len = n3 > len ? n3 : len;
+  wv::sync();
+  return fits;
+}
+
 // projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed: the lane that
 // owns dof d carries u_d = (B' f)_d, a row's residual is one reduction over its tree's lanes, its update one
 // multiply-add.  In the tree-row lane map a constraint row that touches one kinematic tree only involves that tree's
@@ -1265,6 +1303,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   int cnt_my = 0, base_my = 0, tmax = 0;
   int cnt_w = 0, base_w = 0;        // the same for the lane's tree in the wide map of pgs_wide_registers
   bool cross = false;
+  int sched_len = 0;                // sweep length of the coupled schedule (pgs_coupled_schedule)
   if (m.rowmap) {
     int total = 0;
     for (int t = 0; t < m.ntree; t++) {
@@ -1478,6 +1517,65 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       MJ_USTEP(8) MJ_USTEP(9) MJ_USTEP(10) MJ_USTEP(11) MJ_USTEP(12) MJ_USTEP(13) MJ_USTEP(14) MJ_USTEP(15)
     } while (0);
 #undef MJ_USTEP
+    wv::sync();
+  } else if (m.rowmap && cross && pgs_coupled_schedule(m, l, S, L, nefc, sched_len)) {
+    // Some rows couple two trees (agent against agent).  The trees still sweep side by side: every tree walks its own
+    // list of rows, a coupling row sits in the lists of both its trees AT THE SAME POSITION (the shorter list is padded
+    // with empty entries, pgs_coupled_schedule), and at such a position the two trees add their halves of the row's
+    // residual through the LDS crossbar and then take the same step.  Rows of different trees between two coupling
+    // rows commute, so this is the serial order of the reference as far as any row can tell.  (The serial sweep
+    // below took 10x the wave time of the register solver, and with one such copy the launch took twice as long.)
+    const bool leader = (L & 15) == 0;
+    const int C = m.njmax / m.ntree;
+    const Tab T = make_tab(m, l, S);
+    struct Rec { int i, info; bool has; real bid, fi, Ri, bi, aii, ainv; };
+    auto fetch = [&](int sidx) {
+      Rec r;
+      const int e = mytree < m.ntree ? I[l.i_rowid + mytree * C + sidx] : -1;
+      r.has = e >= 0;
+      r.i = r.has ? e : 0;
+      r.info = I[l.i_rowinfo + r.i];
+      const real* R = S + l.row + ROW_STRIDE * r.i;
+      r.bid = r.has ? coef(r.i, r.info) : 0.0;
+      r.fi = R[ROW_F]; r.Ri = R[ROW_R]; r.bi = R[ROW_B]; r.aii = R[ROW_ARII];
+      r.ainv = 1.0 / r.aii;
+      return r;
+    };
+    Rec nxt = fetch(0);
+    while (iter < m.iterations) {
+      real imp = 0;
+      for (int sidx = 0; sidx < sched_len; sidx++) {
+        Rec c = nxt;
+        nxt = fetch(sidx + 1 < sched_len ? sidx + 1 : 0);
+        real res = wv::sum16(c.bid * dinv * u);
+        const bool coupling = c.has && (c.info >> CHAIN_BITS) == 0;
+        bool counted = true;
+        if (wv::ballot(coupling)) {
+          // the other tree of the row holds the other half of the sum (a + b == b + a: both trees get the same bits)
+          int partner = L;
+          if (coupling) {
+            const int t1 = T.dof_tree(c.info & 63), t2 = T.dof_tree(((c.info >> 9) & 127) - 1);
+            partner = 16 * (t1 == mytree ? t2 : t1) + (L & 15);
+            counted = mytree == (t1 < t2 ? t1 : t2);          // its cost change enters the sweep's improvement once
+          }
+          const real other = wv::shfl(res, partner);
+          if (coupling) res += other;
+        }
+        res += c.Ri * c.fi + c.bi;
+        real fn = c.fi - res * c.ainv;
+        if (fn < 0) fn = 0;
+        real delta = fn - c.fi;
+        real change = 0.5 * delta * delta * c.aii + delta * res;
+        if (change > 1e-10 || !c.has) { fn = c.fi; delta = 0; change = 0; }
+        if (counted) imp -= change;
+        u += delta * c.bid;
+        if (leader && c.has) S[l.row + ROW_STRIDE * c.i + ROW_F] = fn;
+        if (nxt.has && c.has && nxt.i == c.i) nxt.fi = fn;      // the same row comes again (a single-entry list)
+      }
+      iter++;
+      real improvement = wv::rows4_sum(imp);
+      if (improvement * scale < m.tolerance) break;
+    }
     wv::sync();
   } else if (m.rowmap && !cross) {
     const bool leader = (L & 15) == 0;

@@ -347,3 +347,32 @@ def test_wide_register_solver_for_17_to_32_rows_per_tree():
         wide_steps += bool((trees >= 0).all() and 16 < max(per_tree) <= 32)
     assert wide_steps > 0
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
+
+
+def test_coupling_rows_in_several_tree_pairs_at_once():
+    """Four agents, stacked in two pairs and one pair leaning on a third agent: rows that couple trees (0,1), (2,3)
+    and (1,2) in the same step.  The trees sweep side by side with the coupling rows aligned in their lists
+    (pgs_coupled_schedule); sweep counts and trajectories must match the oracle's plain serial sweep."""
+    model, ora, emu = pair("four_agent.xml")
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == 0]
+    assert len(free) == 4
+    adr = [int(model.jnt_qposadr[j]) for j in free]
+    q = model.qpos0.copy()
+    base = q[adr[0]:adr[0] + 3].copy()
+    q[adr[1]:adr[1] + 3] = base + np.array([0.15, 0.10, 0.55])          # agent 1 on agent 0
+    q[adr[2]:adr[2] + 3] = base + np.array([1.05, 0.15, 0.00])          # agent 2 beside them, legs interleaved
+    q[adr[3]:adr[3] + 3] = base + np.array([1.20, 0.25, 0.55])          # agent 3 on agent 2
+    ora.qpos[:] = q; emu.qpos[:] = q
+    pairs_seen = set()
+    rng = np.random.default_rng(3)
+    for k in range(45):
+        ctrl = rng.uniform(-1, 1, model.nu)
+        ora.ctrl[:] = ctrl; emu.ctrl[:] = ctrl
+        img = emu.step(); ora.step()
+        assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter), k
+        for c in ora.contacts():
+            t1, t2 = (int(model.body_treeid[model.geom_bodyid[g]]) for g in (c["geom1"], c["geom2"]))
+            if t1 >= 0 and t2 >= 0 and t1 != t2:
+                pairs_seen.add((min(t1, t2), max(t1, t2)))
+    assert len(pairs_seen) >= 2, pairs_seen
+    assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
