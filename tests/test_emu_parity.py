@@ -376,3 +376,55 @@ def test_coupling_rows_in_several_tree_pairs_at_once():
                 pairs_seen.add((min(t1, t2), max(t1, t2)))
     assert len(pairs_seen) >= 2, pairs_seen
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
+
+
+def test_more_than_sixteen_rows_per_tree_in_a_four_tree_model():
+    """17..32 rows in a tree of the 4-agent level: no idle lanes to spread a tree over, so the copy takes the
+    LDS-resident sweep with all four trees side by side.  One agent is lowered onto the floor with bent legs (four
+    foot contacts plus active joint limits) while the others fall; sweep counts and trajectories must be the
+    oracle's."""
+    model, ora, emu = pair("four_agent.xml")
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == 0]
+    hinge = [j for j in range(model.njnt) if model.jnt_type[j] == 3]
+    rng = np.random.default_rng(2)
+    probe = OracleEnv(blob.pack(model))
+    tree, gbody = model.body_treeid, model.geom_bodyid
+    found = None
+    probe.forward()
+    limits_elsewhere = probe.nefc * (model.ntree - 1) // model.ntree      # the other agents stay as they are
+    for dz in np.linspace(-0.72, -0.94, 12):
+        for trial in range(30):
+            q = model.qpos0.copy()
+            q[int(model.jnt_qposadr[free[0]]) + 2] += dz
+            if trial:
+                hq = [int(model.jnt_qposadr[j]) for j in hinge if model.body_treeid[model.jnt_bodyid[j]] == 0]
+                q[hq] += rng.uniform(-0.3, 0.3, len(hq))
+            probe.qpos[:] = q; probe.qvel[:] = 0
+            probe.forward()
+            rows = [0] * model.ntree
+            coupled = False
+            for c in probe.contacts():
+                t1, t2 = int(tree[gbody[c["geom1"]]]), int(tree[gbody[c["geom2"]]])
+                coupled |= t1 >= 0 and t2 >= 0 and t1 != t2
+                rows[max(t1, t2)] += 4
+            in_tree_0 = rows[0] + probe.nefc - sum(rows) - limits_elsewhere
+            if not coupled and probe.warnings == 0 and sum(rows[1:]) == 0 and 16 < in_tree_0 <= 32:
+                found = q
+                break
+        if found is not None:
+            break
+    assert found is not None
+    ora.qpos[:] = found; emu.qpos[:] = found
+    many_row_steps = 0
+    rng = np.random.default_rng(4)
+    for k in range(50):
+        ctrl = rng.uniform(-1, 1, model.nu)
+        ora.ctrl[:] = ctrl; emu.ctrl[:] = ctrl
+        img = emu.step(); ora.step()
+        assert (img.nefc, img.ncon, img.niter) == (ora.nefc, ora.ncon, ora.niter), k
+        info_at = img._off("i_rowinfo")
+        trees = (img.ints[info_at:info_at + img.nefc] >> 19) - 2
+        per_tree = [int((trees == t).sum()) for t in range(model.ntree)]
+        many_row_steps += bool((trees >= 0).all() and 16 < max(per_tree) <= 32)
+    assert many_row_steps > 0
+    assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
