@@ -1267,6 +1267,114 @@ __device__ inline bool pgs_coupled_schedule(const DevModel& m, const Lay& l, rea
   return fits;
 }
 
+
+// The sweep of a copy on a row schedule (pgs_coupled_schedule: every tree's list of rows, coupling rows at the same
+// position of both their trees' lists) of at most 16 positions, with everything but the arithmetic out of the loop:
+// the lane's coefficient in the row at every position in 16 registers, the rows' records (R, b, AR_ii, its reciprocal,
+// the force) in the lanes -- lane k of a tree's 16 keeps position k -- and broadcast by DPP.  Operation for operation
+// the LDS-resident sweep of stage_pgs (same sums, same order), at a third of its instructions.  (Inlined: as a function
+// of its own its argument list alone cost the kernel 80 B of scratch per lane; 32 positions, two per lane, need more
+// than 256 registers.)
+struct SchedArgs {
+  int o_rowid, o_rowinfo, o_row, o_J, o_tab;   // LDS offsets (Lay)
+  int base, len, iterations;                   // the lane's list, sweep length, sweep cap
+  int tab_dtree, tab_bytes;                    // dof -> tree table (Tab)
+  int depth;                                   // of the lane's dof (RowK)
+  unsigned long long below;
+  real tolerance, scale, dinv, u;
+};
+__device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool dof, SchedArgs w, int* iter_io) {
+  const int k = L & 15, mytree = L >> 4;
+  const int len = wv::first_int(w.len), iterations = wv::first_int(w.iterations);
+  int iter = wv::first_int(*iter_io);
+  const unsigned char* t8 = (const unsigned char*)(S + w.o_tab);
+  auto dof_tree = [&](int d) { return w.tab_bytes ? (int)t8[w.tab_dtree + d] : (int)((const unsigned short*)t8)[w.tab_dtree + d]; };
+  auto entry = [&](int p) { return p < len ? I[w.o_rowid + w.base + p] : -1; };
+  auto coef = [&](int r, int info) -> real {
+    const int rt = (info >> CHAIN_BITS) - 2;
+    const int sl = rt >= 0 ? (rt == mytree ? k : -1) : row_slot(info, w.below, w.depth);
+    return (dof && sl >= 0) ? S[w.o_J + JW * r + sl] : 0.0;
+  };
+  // the lane's coefficient at every position
+  real bid[16];
+#pragma unroll
+  for (int p = 0; p < 16; p++) {
+    const int e = entry(p);
+    bid[p] = e >= 0 ? coef(e, I[w.o_rowinfo + e]) : 0.0;
+  }
+  // the record of position k (an empty position: reciprocal 0, so its step changes nothing)
+  struct Own { int row; bool has; real f, Ri, bi, aii, ainv, cnt; int partner; };
+  auto own = [&](int p) {
+    Own o;
+    const int e = entry(p);
+    o.has = e >= 0;
+    o.row = o.has ? e : 0;
+    const real* R = S + w.o_row + ROW_STRIDE * o.row;
+    const int info = I[w.o_rowinfo + o.row];
+    o.f = o.has ? R[ROW_F] : 0.0; o.Ri = o.has ? R[ROW_R] : 0.0; o.bi = o.has ? R[ROW_B] : 0.0;
+    o.aii = o.has ? R[ROW_ARII] : 1.0;
+    o.ainv = o.has ? 1.0 / o.aii : 0.0;
+    o.cnt = o.has ? 1.0 : 0.0;
+    o.partner = -1;
+    if (o.has && (info >> CHAIN_BITS) == 0) {        // a row that couples two trees
+      const int t1 = dof_tree(info & 63), t2 = dof_tree(((info >> 9) & 127) - 1);
+      o.partner = 16 * (t1 == mytree ? t2 : t1);
+      if (mytree != (t1 < t2 ? t1 : t2)) o.cnt = 0.0;     // its cost change enters the sweep's improvement once
+    }
+    return o;
+  };
+  Own o0 = own(k);
+  // positions at which some tree has a coupling row (bit p)
+  unsigned anyc;
+  {
+    const unsigned long long c0 = wv::ballot(o0.partner >= 0);
+    anyc = (unsigned)((c0 | (c0 >> 16) | (c0 >> 32) | (c0 >> 48)) & 0xFFFFull);
+  }
+  const real dinv = w.dinv, scale = w.scale, tolerance = w.tolerance;
+  real u = w.u;
+  while (iter < iterations) {
+    real imp = 0;
+    const int len_s = wv::opaque_uniform(len);
+#define MJ_PSTEP(P)                                                                   \
+      {                                                                               \
+        const real Ri = wv::bcast16<P>(o0.Ri), bi = wv::bcast16<P>(o0.bi);            \
+        const real aii = wv::bcast16<P>(o0.aii), ainv = wv::bcast16<P>(o0.ainv);      \
+        const real fi = wv::bcast16<P>(o0.f), cnt = wv::bcast16<P>(o0.cnt);           \
+        real res = wv::sum16(bid[P] * dinv * u);                                      \
+        if ((anyc >> P) & 1u) {                                                       \
+          const int pl = wv::bcast16i<P>(o0.partner);                                 \
+          const real other = wv::shfl(res, pl >= 0 ? pl + k : L);                     \
+          if (pl >= 0) res += other;                                                  \
+        }                                                                             \
+        res = res + Ri * fi + bi;                                                     \
+        real fn = fi - res * ainv;                                                    \
+        if (fn < 0) fn = 0;                                                           \
+        real delta = fn - fi;                                                         \
+        real change = 0.5 * delta * delta * aii + delta * res;                        \
+        if (change > 1e-10) { fn = fi; delta = 0; change = 0; }                       \
+        imp -= change * cnt;                                                          \
+        u += delta * bid[P];                                                          \
+        if (k == P) o0.f = fn;                                                        \
+      }
+    do {
+      MJ_PSTEP(0) MJ_PSTEP(1) MJ_PSTEP(2) MJ_PSTEP(3)
+      if (4 >= len_s) break;
+      MJ_PSTEP(4) MJ_PSTEP(5) MJ_PSTEP(6) MJ_PSTEP(7)
+      if (8 >= len_s) break;
+      MJ_PSTEP(8) MJ_PSTEP(9) MJ_PSTEP(10) MJ_PSTEP(11)
+      if (12 >= len_s) break;
+      MJ_PSTEP(12) MJ_PSTEP(13) MJ_PSTEP(14) MJ_PSTEP(15)
+    } while (0);
+#undef MJ_PSTEP
+    iter++;
+    const real improvement = wv::rows4_sum(imp);
+    if (improvement * scale < tolerance) break;
+  }
+  if (o0.has) S[w.o_row + ROW_STRIDE * o0.row + ROW_F] = o0.f;
+  *iter_io = iter;
+  return u;
+}
+
 // projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed: the lane that
 // owns dof d carries u_d = (B' f)_d, a row's residual is one reduction over its tree's lanes, its update one
 // multiply-add.  In the tree-row lane map a constraint row that touches one kinematic tree only involves that tree's
@@ -1528,6 +1636,16 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     const bool leader = (L & 15) == 0;
     const int C = m.njmax / m.ntree;
     const Tab T = make_tab(m, l, S);
+    if (sched_len <= 16) {
+      SchedArgs w;
+      w.o_rowid = l.i_rowid; w.o_rowinfo = l.i_rowinfo; w.o_row = l.row; w.o_J = l.J; w.o_tab = l.tab;
+      w.base = mytree < m.ntree ? mytree * C : 0; w.len = mytree < m.ntree ? sched_len : 0; w.iterations = m.iterations;
+      w.tab_dtree = T.dtree; w.tab_bytes = T.bytes ? 1 : 0;
+      w.depth = RK.depth; w.below = RK.below;
+      w.tolerance = m.tolerance; w.scale = scale; w.dinv = dinv; w.u = u;
+      u = pgs_schedule_registers(S, I, L, dof, w, &iter);
+      wv::sync();
+    } else {
     struct Rec { int i, info; bool has; real bid, fi, Ri, bi, aii, ainv; };
     auto fetch = [&](int sidx) {
       Rec r;
@@ -1561,7 +1679,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
           const real other = wv::shfl(res, partner);
           if (coupling) res += other;
         }
-        res += c.Ri * c.fi + c.bi;
+        res = res + c.Ri * c.fi + c.bi;
         real fn = c.fi - res * c.ainv;
         if (fn < 0) fn = 0;
         real delta = fn - c.fi;
@@ -1577,6 +1695,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       if (improvement * scale < m.tolerance) break;
     }
     wv::sync();
+    }
   } else if (m.rowmap && !cross) {
     const bool leader = (L & 15) == 0;
     // software pipeline: the record of the tree's next row is fetched while the current row is processed
