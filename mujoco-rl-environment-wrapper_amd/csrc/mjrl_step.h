@@ -1268,6 +1268,13 @@ __device__ inline bool pgs_coupled_schedule(const DevModel& m, const Lay& l, rea
 }
 
 
+// lane K & 15 of the caller's row of 16 lanes: of `lo` for K < 16, of `hi` for K >= 16 (two values per lane)
+template <int K>
+__device__ __forceinline__ real tall_bcast(real lo, real hi) {
+  if constexpr (K < 16) return wv::bcast16<K>(lo);
+  else return wv::bcast16<K - 16>(hi);
+}
+
 // The sweep of a copy on a row schedule (pgs_coupled_schedule: every tree's list of rows, coupling rows at the same
 // position of both their trees' lists) of at most 16 positions, with everything but the arithmetic out of the loop:
 // the lane's coefficient in the row at every position in 16 registers, the rows' records (R, b, AR_ii, its reciprocal,
@@ -1283,6 +1290,7 @@ struct SchedArgs {
   unsigned long long below;
   real tolerance, scale, dinv, u;
 };
+template <int NP>       // 16: one position per lane; 32: two (more than 256 registers: for images that hold a CU to 4 copies anyway)
 __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool dof, SchedArgs w, int* iter_io) {
   const int k = L & 15, mytree = L >> 4;
   const int len = wv::first_int(w.len), iterations = wv::first_int(w.iterations);
@@ -1296,9 +1304,9 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
     return (dof && sl >= 0) ? S[w.o_J + JW * r + sl] : 0.0;
   };
   // the lane's coefficient at every position
-  real bid[16];
+  real bid[NP];
 #pragma unroll
-  for (int p = 0; p < 16; p++) {
+  for (int p = 0; p < NP; p++) {
     const int e = entry(p);
     bid[p] = e >= 0 ? coef(e, I[w.o_rowinfo + e]) : 0.0;
   }
@@ -1323,12 +1331,13 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
     }
     return o;
   };
-  Own o0 = own(k);
+  Own o0 = own(k), o1 = own(NP > 16 ? k + 16 : (1 << 20));
   // positions at which some tree has a coupling row (bit p)
   unsigned anyc;
   {
-    const unsigned long long c0 = wv::ballot(o0.partner >= 0);
-    anyc = (unsigned)((c0 | (c0 >> 16) | (c0 >> 32) | (c0 >> 48)) & 0xFFFFull);
+    const unsigned long long c0 = wv::ballot(o0.partner >= 0), c1 = wv::ballot(o1.partner >= 0);
+    anyc = (unsigned)((c0 | (c0 >> 16) | (c0 >> 32) | (c0 >> 48)) & 0xFFFFull)
+         | ((unsigned)((c1 | (c1 >> 16) | (c1 >> 32) | (c1 >> 48)) & 0xFFFFull) << 16);
   }
   const real dinv = w.dinv, scale = w.scale, tolerance = w.tolerance;
   real u = w.u;
@@ -1337,12 +1346,12 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
     const int len_s = wv::opaque_uniform(len);
 #define MJ_PSTEP(P)                                                                   \
       {                                                                               \
-        const real Ri = wv::bcast16<P>(o0.Ri), bi = wv::bcast16<P>(o0.bi);            \
-        const real aii = wv::bcast16<P>(o0.aii), ainv = wv::bcast16<P>(o0.ainv);      \
-        const real fi = wv::bcast16<P>(o0.f), cnt = wv::bcast16<P>(o0.cnt);           \
-        real res = wv::sum16(bid[P] * dinv * u);                                      \
+        const real Ri = tall_bcast<P>(o0.Ri, o1.Ri), bi = tall_bcast<P>(o0.bi, o1.bi);  \
+        const real aii = tall_bcast<P>(o0.aii, o1.aii), ainv = tall_bcast<P>(o0.ainv, o1.ainv); \
+        const real fi = tall_bcast<P>(o0.f, o1.f), cnt = tall_bcast<P>(o0.cnt, o1.cnt); \
+        real res = wv::sum16(bid[P < NP ? P : 0] * dinv * u);                         \
         if ((anyc >> P) & 1u) {                                                       \
-          const int pl = wv::bcast16i<P>(o0.partner);                                 \
+          const int pl = wv::bcast16i<(P & 15)>(P < 16 ? o0.partner : o1.partner);    \
           const real other = wv::shfl(res, pl >= 0 ? pl + k : L);                     \
           if (pl >= 0) res += other;                                                  \
         }                                                                             \
@@ -1353,8 +1362,8 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
         real change = 0.5 * delta * delta * aii + delta * res;                        \
         if (change > 1e-10) { fn = fi; delta = 0; change = 0; }                       \
         imp -= change * cnt;                                                          \
-        u += delta * bid[P];                                                          \
-        if (k == P) o0.f = fn;                                                        \
+        u += delta * bid[P < NP ? P : 0];                                             \
+        if (k == (P & 15)) { if (P < 16) o0.f = fn; else o1.f = fn; }                 \
       }
     do {
       MJ_PSTEP(0) MJ_PSTEP(1) MJ_PSTEP(2) MJ_PSTEP(3)
@@ -1364,6 +1373,14 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
       MJ_PSTEP(8) MJ_PSTEP(9) MJ_PSTEP(10) MJ_PSTEP(11)
       if (12 >= len_s) break;
       MJ_PSTEP(12) MJ_PSTEP(13) MJ_PSTEP(14) MJ_PSTEP(15)
+      if (NP <= 16 || 16 >= len_s) break;
+      MJ_PSTEP(16) MJ_PSTEP(17) MJ_PSTEP(18) MJ_PSTEP(19)
+      if (20 >= len_s) break;
+      MJ_PSTEP(20) MJ_PSTEP(21) MJ_PSTEP(22) MJ_PSTEP(23)
+      if (24 >= len_s) break;
+      MJ_PSTEP(24) MJ_PSTEP(25) MJ_PSTEP(26) MJ_PSTEP(27)
+      if (28 >= len_s) break;
+      MJ_PSTEP(28) MJ_PSTEP(29) MJ_PSTEP(30) MJ_PSTEP(31)
     } while (0);
 #undef MJ_PSTEP
     iter++;
@@ -1371,8 +1388,17 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
     if (improvement * scale < tolerance) break;
   }
   if (o0.has) S[w.o_row + ROW_STRIDE * o0.row + ROW_F] = o0.f;
+  if (o1.has) S[w.o_row + ROW_STRIDE * o1.row + ROW_F] = o1.f;
   *iter_io = iter;
   return u;
+}
+
+__device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
+#if defined(MJRL_SPEC) || !defined(__HIPCC__)
+  return m.ntree > 2 && (size_t)l.total * sizeof(real) > 32 * 1024;
+#else
+  return false;
+#endif
 }
 
 // projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed: the lane that
@@ -1626,7 +1652,10 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     } while (0);
 #undef MJ_USTEP
     wv::sync();
-  } else if (m.rowmap && cross && pgs_coupled_schedule(m, l, S, L, nefc, sched_len)) {
+  } else if (m.rowmap && (cross || (pgs_roomy(m, l) && tmax > 16 && tmax <= 32)) &&
+             pgs_coupled_schedule(m, l, S, L, nefc, sched_len)) {
+    // (also a copy without coupling rows but with 17..32 rows in a tree of a model with more than two trees, where the
+    // two-positions-per-lane form below is available: its plain per-tree lists are a schedule too)
     // Some rows couple two trees (agent against agent).  The trees still sweep side by side: every tree walks its own
     // list of rows, a coupling row sits in the lists of both its trees AT THE SAME POSITION (the shorter list is padded
     // with empty entries, pgs_coupled_schedule), and at such a position the two trees add their halves of the row's
@@ -1636,14 +1665,18 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     const bool leader = (L & 15) == 0;
     const int C = m.njmax / m.ntree;
     const Tab T = make_tab(m, l, S);
-    if (sched_len <= 16) {
+    // two positions per lane only where the LDS image already holds the CU to four copies (one wave per SIMD): the
+    // form needs more than 256 registers.  (Specialised builds and the CPU emulation; the generic GPU kernel keeps the
+    // LDS-resident sweep there -- the same arithmetic, so the two builds still agree to the bit.)
+    const bool roomy = pgs_roomy(m, l);
+    if (sched_len <= 16 || (roomy && sched_len <= 32)) {
       SchedArgs w;
       w.o_rowid = l.i_rowid; w.o_rowinfo = l.i_rowinfo; w.o_row = l.row; w.o_J = l.J; w.o_tab = l.tab;
       w.base = mytree < m.ntree ? mytree * C : 0; w.len = mytree < m.ntree ? sched_len : 0; w.iterations = m.iterations;
       w.tab_dtree = T.dtree; w.tab_bytes = T.bytes ? 1 : 0;
       w.depth = RK.depth; w.below = RK.below;
       w.tolerance = m.tolerance; w.scale = scale; w.dinv = dinv; w.u = u;
-      u = pgs_schedule_registers(S, I, L, dof, w, &iter);
+      u = sched_len <= 16 ? pgs_schedule_registers<16>(S, I, L, dof, w, &iter) : pgs_schedule_registers<32>(S, I, L, dof, w, &iter);
       wv::sync();
     } else {
     struct Rec { int i, info; bool has; real bid, fi, Ri, bi, aii, ainv; };
