@@ -526,3 +526,57 @@ def test_render_block_tiling_at_odd_sizes_and_batch_sizes():
                 assert differ.mean() < 0.004, (n_env, w, h, cam, differ.mean())
             assert (got[:, cam] == got[0, cam]).all()
         handle.close()
+
+
+def test_four_agent_schedule_solver_on_the_gpu_and_in_both_builds():
+    """Four agents stacked in pairs (rows that couple trees (0,1), (2,3), (1,2) in one step: the aligned schedule with
+    two positions per lane in the specialised build, the LDS-resident loop in the generic one) and, in another copy,
+    one agent pressed onto the floor (17+ rows in a tree).  Both builds must give the oracle's sweep counts and each
+    other's bits."""
+    model = mjcf.compile_mjcf(levels.level_path("four_agent.xml"))
+    packed = blob.pack(model)
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == 0]
+    adr = [int(model.jnt_qposadr[j]) for j in free]
+    stacked = model.qpos0.copy()
+    base = stacked[adr[0]:adr[0] + 3].copy()
+    stacked[adr[1]:adr[1] + 3] = base + np.array([0.15, 0.10, 0.55])
+    stacked[adr[2]:adr[2] + 3] = base + np.array([1.05, 0.15, 0.00])
+    stacked[adr[3]:adr[3] + 3] = base + np.array([1.20, 0.25, 0.55])
+    pressed = model.qpos0.copy()
+    pressed[adr[0] + 2] -= 0.80
+    hinge0 = [int(model.jnt_qposadr[j]) for j in range(model.njnt)
+              if model.jnt_type[j] == 3 and model.body_treeid[model.jnt_bodyid[j]] == 0]
+    pressed[hinge0] += np.random.default_rng(6).uniform(-0.3, 0.3, len(hinge0))
+    start = np.stack([stacked, pressed, model.qpos0])
+    handles = [_capi.Handle(packed, 3, specialize=True), _capi.Handle(packed, 3, specialize=False)]
+    assert handles[0].kernel == "specialised" and handles[1].kernel == "generic"
+    oras = [OracleEnv(packed) for _ in range(3)]
+    for h in handles:
+        h.reset()
+        h.set_field("qpos", start)
+    for e, o in enumerate(oras):
+        o.qpos[:] = start[e]
+    ioff, info_at = handles[0].lds_offset("ints"), handles[0].lds_offset("i_rowinfo")
+    rng = np.random.default_rng(7)
+    coupled_steps = many_row_steps = 0
+    for k in range(45):
+        ctrl = rng.uniform(-1, 1, (3, model.nu))
+        imgs = []
+        for h in handles:
+            h.set_field("ctrl", ctrl)
+            imgs.append(h.step_debug(None, 0, 1, 0))
+        ints = imgs[0][:, ioff:ioff + (info_at + model.njmax + 1) // 2 + 1].copy().view(np.int32)
+        for e, o in enumerate(oras):
+            o.ctrl[:] = ctrl[e]
+            o.step()
+            assert (ints[e, 1], ints[e, 0], ints[e, 3]) == (o.nefc, o.ncon, o.niter), (k, e)
+            trees = (ints[e, info_at:info_at + ints[e, 1]] >> 19) - 2
+            coupled_steps += bool((trees == -2).any())
+            many_row_steps += bool((trees >= 0).all() and max((trees == t).sum() for t in range(model.ntree)) > 16)
+    assert coupled_steps > 0 and many_row_steps > 0
+    for name in ("qpos", "qvel", "qacc_warmstart"):
+        assert np.array_equal(handles[0].get_field(name), handles[1].get_field(name)), name
+    assert rel(handles[0].get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
+    assert rel(handles[0].get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
+    for h in handles:
+        h.close()
