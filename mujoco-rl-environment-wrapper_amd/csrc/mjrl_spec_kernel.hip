@@ -14,7 +14,14 @@ extern "C" __device__ const int mjrl_spec_sizes[MJRL_NSIZES] = {
 #undef X
 };
 
-extern "C" __global__ __launch_bounds__(64) void mjrl_step_kernel_spec(const char* __restrict__ image, mj::StepArgs a) {
+// experiments (tools/build_variant.py -- -DMJRL_SPEC_WAVES_PER_EU=3): cap the registers for that many waves per SIMD
+#ifdef MJRL_SPEC_WAVES_PER_EU
+#define MJRL_SPEC_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MJRL_SPEC_WAVES_PER_EU, MJRL_SPEC_WAVES_PER_EU)))
+#else
+#define MJRL_SPEC_OCCUPANCY
+#endif
+
+extern "C" __global__ __launch_bounds__(64) MJRL_SPEC_OCCUPANCY void mjrl_step_kernel_spec(const char* __restrict__ image, mj::StepArgs a) {
   extern __shared__ double lds[];
   DevModel m;
   mjrl_model_from_base(&m, (const char MJRL_GLOBAL*)image);
