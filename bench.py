@@ -1,17 +1,27 @@
-"""Headline benchmark: env-steps/sec of the batched 2-agent env step on N MI355X of one node.
+"""Headline benchmark: env-steps/sec of the batched multi-agent env step on N MI355X of one node.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched under
-``python -m torch.distributed.run`` with one rank per GPU.  A "step" is one step() of every env copy:
-action scatter -> skip_frames=1 physics step -> per-agent observation gather, one kernel launch per rank.
-The env batch shards across ranks (weak scaling: 4096 copies per GPU) with no collective on the step path;
-torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the timed region.
-Rank 0 prints ONE JSON line.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  Typed plainly with N > 1 it starts the N rank
+processes itself (fresh children under ``python -m torch.distributed.run``, before this process touches a GPU); the
+driver's own ``torch.distributed.run`` launch (WORLD_SIZE set) is used as it comes.  A "step" is one step() of every env
+copy: action scatter -> skip_frames=1 physics step -> per-agent observation gather (+ the fused plugin ops), one kernel
+launch per rank.  The env batch shards across ranks (weak scaling: 4096 copies per GPU) with no collective on the step
+path; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the timed region.
+
+Workload: episodes of maxSteps = 1024 steps with every copy at its own point of its episode (copy e is ``phase(e)``
+steps ahead of copy 0, phases uniform over 0..1023), so every launch sees the stationary mix of airborne, landed and
+resetting copies that an autoreset sampler sees -- and a window of K steps measures the same thing whatever K is.  The
+mix is set up by an untimed pre-roll of one episode length; a copy whose episode is over is reset inside the step
+launch (mjrl_set_step_reset_mask), as in the reference's loop (benchmarking/different_env_configs/fps_benchmark.py:
+33-38: ``env.reset()`` then 1024 x ``env.step``).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,104 +33,269 @@ import __graft_entry__ as entry  # noqa: E402
 
 ENVS_PER_GPU = 4096
 ACT_RING = 64
-AGENTS = ["sender", "receiver"]
-LEVEL = "two_agent.xml"          # stand-in for the unshipped MultiEnvs.xml
+EPISODE = 1024                   # maxSteps of the reference's benchmark configs (fps_benchmark.py:21)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, MI355X_MICROARCH.md chip-level table
+WORKLOADS = {
+    # stand-in for the unshipped MultiEnvs.xml = benchmarking/levels/MultiAgentModel.xml
+    "two_agent": dict(level="two_agent.xml", agents=["sender", "receiver"],
+                      what="2-agent ant arena (two_agent.xml = benchmarking/levels/MultiAgentModel.xml, stand-in for the "
+                           "unshipped MultiEnvs.xml)"),
+    # BASELINE config 4: no such level ships; the 2-agent arena with four ants
+    "four_agent": dict(level="four_agent.xml", agents=["sender", "receiver", "agent_3", "agent_4"],
+                       what="4-agent contact-heavy arena (four_agent.xml: the 2-agent arena with the ant instantiated four "
+                            "times, SURVEY 8d config 4; no such level ships with the reference)"),
+}
 
 
 def algorithmic_bytes_per_env_step(nq, nv, n_act_total, obs_total, n_agent, n_slot=0, s=8):
     """state in/out + warm start in/out + actions + observations + data-store read/write +
     per-agent reward/term/trunc.  fp64 (s = 8): 2-agent level without plugins 2460 B, with the Language channel
-    (one action, one observation and one data-store slot more per agent) 2524 B."""
+    (one action, one observation and one data-store slot more per agent) 2524 B; 4-agent arena 6800 B + 24."""
     return s * (2 * nq + 2 * nv + 2 * nv + n_act_total + obs_total) + n_agent * n_slot * 2 * s + n_agent * (4 + 1 + 1)
 
 
-def action_stream(seed, first_env, n_env, n_steps, n_agent, act_dim):
-    """uniform(-1, 1) keyed on the GLOBAL env id, so a copy's trajectory does not depend on the GPU count.  Slots past
-    the eight motors are utterances of the Language channel: uniform(0, 3)."""
+def action_stream(seed, first_env, n_env, n_steps, n_agent, act_dim, n_phys):
+    """uniform(-1, 1) keyed on the GLOBAL env id (Philox counter), so a copy's trajectory does not depend on the GPU
+    count -- and the CPU baseline steps env id w on exactly the stream the GPU feeds that copy.  Slots past the motors
+    are utterances of the Language channel: uniform(0, 3)."""
     out = np.empty((n_steps, n_env, n_agent, act_dim), np.float64)
     for e in range(n_env):
         rng = np.random.Generator(np.random.Philox(key=seed, counter=[0, 0, 0, first_env + e]))
         out[:, e] = rng.uniform(-1.0, 1.0, (n_steps, n_agent, act_dim))
-    if act_dim > 8:
-        out[..., 8:] = 1.5 * (out[..., 8:] + 1.0)
+    if act_dim > n_phys:
+        out[..., n_phys:] = 1.5 * (out[..., n_phys:] + 1.0)
     return out
 
 
-def cpu_baseline(blob_bytes, scatter, seconds=8.0, language=False):
-    """The CPU oracle (kind "port": the repo's own fp64 restatement of the step; mujoco is not installed on the
-    box) timed on the host cores on a bounded sample of the same workload: one env copy per worker, the same
-    action distribution, for `seconds` of wall time; once single-threaded, once with one process per core."""
-    import multiprocessing as mp
-    from oracle.oracle import OracleEnv
+def phase_of(global_env, envs_per_gpu):
+    """Episode phase of a copy: uniform over 0..EPISODE-1 inside every rank's shard, a function of the global id."""
+    return (np.asarray(global_env, dtype=np.int64) * EPISODE // max(envs_per_gpu, 1)) % EPISODE
 
-    def run_one(q, seed, duration):
-        env = OracleEnv(blob_bytes)
-        rng = np.random.default_rng(seed)
+
+def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seconds=8.0, language=False):
+    """The step on the host cores, on a bounded sample of the same workload: worker w steps GLOBAL env id w with the
+    action stream the GPU feeds that copy (same Philox key and counter), episodes of 1024 steps from reset, for
+    `seconds` of wall time; once on one core, once with one process per core.  kind "reference": the box has the
+    reference's own physics library (`mujoco`), run as the reference runs it (mj_step + numpy gather, solver set to PGS
+    like the kernel).  kind "port": it has not (the case in this image) and the repo's fp64 restatement
+    (oracle/ora_step.c) stands in."""
+    import multiprocessing as mp
+    have_mujoco = importlib.util.find_spec("mujoco") is not None
+    flat = scatter.reshape(-1)
+    routed = flat >= 0
+
+    def make_env():
+        if have_mujoco:
+            import mujoco
+            model = mujoco.MjModel.from_xml_path(level_file)
+            model.opt.solver = mujoco.mjtSolver.mjSOL_PGS
+            data = mujoco.MjData(model)
+
+            class Ref:
+                qpos, qvel, ctrl, sensordata = data.qpos, data.qvel, data.ctrl, data.sensordata
+                def step(self): mujoco.mj_step(model, data)
+                def reset(self):
+                    mujoco.mj_resetData(model, data)
+                    mujoco.mj_forward(model, data)
+            return Ref()
+        from oracle.oracle import OracleEnv
+        return OracleEnv(blob_bytes)
+
+    def run_one(q, worker, duration):
+        env = make_env()
+        ring = action_stream(0, worker, 1, ACT_RING, n_agent, act_dim, n_phys)[:, 0]
         n = 0
-        store = [{} for _ in range(scatter.shape[0])]
+        store = [{} for _ in range(n_agent)]
+        env.reset()
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < duration:
             for _ in range(64):
-                act = rng.uniform(-1, 1, scatter.shape)
-                env.ctrl[scatter.reshape(-1)] = act.reshape(-1)
+                act = ring[n % ACT_RING]
+                env.ctrl[flat[routed]] = act.reshape(-1)[routed]
                 env.step()
                 # the reference's observation gather: sensordata | qpos | qvel per agent (+ the language channel)
-                for a in range(scatter.shape[0]):
+                for a in range(n_agent):
                     obs = np.concatenate([env.sensordata[[a]], env.qpos, env.qvel])
                     if language:
-                        store[a]["utterance"] = int(rng.uniform(0, 3))
-                        obs = np.concatenate((obs, np.array([store[1 - a].get("utterance", 0)])))
-            n += 64
-            if env.time > 2.0:          # episode of 1024 steps ~ 2 s of sim time
-                env.reset()
+                        store[a]["utterance"] = int(act[a, n_phys])
+                        obs = np.concatenate((obs, np.array([store[(a + 1) % n_agent].get("utterance", 0)])))
+                n += 1
+                if n % EPISODE == 0:
+                    env.reset()
+                    store = [{} for _ in range(n_agent)]
         q.put((n, time.perf_counter() - t0))
 
     ctx = mp.get_context("fork")
     q = ctx.Queue()
-    run_one(q, 0, seconds)
+    error = None
+    try:
+        run_one(q, 0, seconds)
+    except Exception as exc:            # a broken mujoco install must not cost the bench line
+        if not have_mujoco:
+            raise
+        error, have_mujoco = repr(exc), False
+        run_one(q, 0, seconds)
     n1, t1 = q.get()
     cores = os.cpu_count() or 1
-    procs = [ctx.Process(target=run_one, args=(q, 100 + i, seconds)) for i in range(cores)]
+    procs = [ctx.Process(target=run_one, args=(q, i, seconds)) for i in range(cores)]
     for p in procs:
         p.start()
     results = [q.get() for _ in procs]
     for p in procs:
         p.join()
     total = sum(n / t for n, t in results)
-    return {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (oracle/ora_step.c), {cores} processes x 1 env copy x {seconds:.0f} s of "
-                      f"{LEVEL} with uniform(-1,1) actions, step + numpy obs gather",
-            "single_thread": n1 / t1}
+    found = importlib.util.find_spec("mujoco") is not None
+    engine = "mujoco (the reference's physics, solver PGS)" if have_mujoco else "CPU oracle (oracle/ora_step.c)"
+    out = {"value": total, "unit": "env-steps/s", "cores": cores, "kind": "reference" if have_mujoco else "port",
+           "sample": f"{engine}; importlib.util.find_spec('mujoco') -> {'found' if found else 'None'}; {cores} processes x "
+                     f"1 env copy x {seconds:.0f} s of {os.path.basename(level_file)}, worker w = global env id w on the GPU "
+                     f"run's Philox action stream, episodes of {EPISODE} steps from reset, step + numpy obs gather",
+           "mujoco_found": found, "single_thread": n1 / t1}
+    if error:
+        out["mujoco_error"] = error
+    return out
 
 
-def main():
+class DeviceBatch:
+    """The product path: ``MuJoCoRL`` over libmjrl_hip.so, tensors resident in HBM."""
+
+    def __init__(self, torch, dev, level_file, agents, n_env, plugins, args, stream):
+        from mjrl_amd.mujoco_rl import MuJoCoRL
+        self.torch, self.dev = torch, dev
+        self.env = MuJoCoRL({"xmlPath": level_file, "agents": agents, "numEnvs": n_env, "deviceId": dev.index,
+                             "skipFrames": 1, "maxSteps": EPISODE, "environmentDynamics": plugins,
+                             "nconmax": args.nconmax, "njmax": args.njmax})
+        self.stream = stream
+        self.env._handle.set_stream(stream.cuda_stream)
+        self.env.reset_batched()
+        self.obs_dim = self.env._handle.size("obs_dim")
+        self.model = self.env._compiled
+        self.kernel = "mjrl_step_kernel_spec" if self.env._handle.kernel == "specialised" else "mjrl_step_kernel"
+        self.agents_action_index = self.env.agents_action_index
+        self.blob = self.env._blob
+
+    def buffers(self, n_env, n_agent):
+        t, dev = self.torch, self.dev
+        return (t.empty((n_env, n_agent, self.obs_dim), dtype=t.float64, device=dev),
+                t.empty((n_env, n_agent), dtype=t.float64, device=dev),
+                t.empty((n_env, n_agent), dtype=t.uint8, device=dev),
+                t.empty((n_env, n_agent), dtype=t.uint8, device=dev))
+
+    def to_device(self, array):
+        return self.torch.from_numpy(np.ascontiguousarray(array)).to(self.dev)
+
+    def set_step_reset_mask(self, row):
+        self.env._handle.set_step_reset_mask(None if row is None else row.data_ptr())
+
+    def step_batched(self, actions, obs, reward, term, trunc):
+        with self.torch.cuda.stream(self.stream):
+            self.env.step_batched(actions, obs, reward, term, trunc)
+
+    def solver_stats(self):
+        return self.env._handle.get_field("solver_stats")
+
+    def cap_overflows(self):
+        return self.env._handle.cap_overflows()
+
+    def finite(self, obs):
+        return bool(self.torch.isfinite(obs).all().item())
+
+    def close(self):
+        self.env.close()
+
+
+class RehearsalBatch:
+    """MJRL_BENCH_REHEARSAL=cpu: the same control flow without a GPU -- the env copies are stepped by the CPU
+    lane-emulation of the device source (tests/emu, test infrastructure).  Its line is marked as a rehearsal and is not
+    a measurement."""
+
+    def __init__(self, level_file, agents, n_env, language):
+        from tests.emu.batch import EmuBatch
+        self.b = EmuBatch(level_file, agents, n_env, language=language, max_steps=EPISODE)
+        self.obs_dim, self.model, self.kernel = self.b.obs_dim, self.b.model, self.b.kernel
+        self.agents_action_index, self.blob = self.b.agents_action_index, self.b.blob
+
+    def buffers(self, n_env, n_agent):
+        return (np.zeros((n_env, n_agent, self.obs_dim)), np.zeros((n_env, n_agent)),
+                np.zeros((n_env, n_agent), np.uint8), np.zeros((n_env, n_agent), np.uint8))
+
+    def to_device(self, array):
+        return np.ascontiguousarray(array)
+
+    def set_step_reset_mask(self, row):
+        self.b.set_step_reset_mask(row)
+
+    def step_batched(self, actions, obs, reward, term, trunc):
+        self.b.step_batched(actions, obs, reward, term, trunc)
+
+    def solver_stats(self):
+        return self.b.solver_stats()
+
+    def cap_overflows(self):
+        return self.b.cap_overflows()
+
+    def finite(self, obs):
+        return bool(np.isfinite(obs).all())
+
+    def close(self):
+        self.b.close()
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)     # one reference episode (maxSteps = 1024)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preroll", type=int, default=EPISODE,
+                    help="untimed steps before the warm-up that spread the copies over their episodes (default: one episode)")
+    ap.add_argument("--level", choices=sorted(WORKLOADS), default="two_agent")
     ap.add_argument("--nconmax", type=int, default=None, help="contact cap per env copy (default: the compiler's)")
     ap.add_argument("--njmax", type=int, default=None, help="constraint-row cap per env copy (default: the compiler's)")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--groups", type=int, default=1,
                     help="step the batch as this many independent groups on their own streams (1 = lockstep, the headline)")
-    ap.add_argument("--no-double-buffer", action="store_true", help="skip the secondary two-group measurement")
+    ap.add_argument("--double-buffer", action="store_true",
+                    help="also measure the batch as two independent half-batches on two streams (reported beside the value)")
     ap.add_argument("--no-language", action="store_true", help="config 2: physics + gather only, no Language channel")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` typed plainly: start the N ranks as fresh children BEFORE this process imports torch
+    or touches a GPU (a process that has initialised the GPU must never be replaced or forked into ranks), pass their
+    output through and exit with their status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal of the multi-rank control flow on a box with one GPU: every rank on device 0, gloo instead of RCCL
-    rehearsal = os.environ.get("MJRL_BENCH_REHEARSAL") == "1"
+    # rehearsals of the multi-rank control flow: "1" = every rank on device 0 of a one-GPU box, gloo instead of RCCL;
+    # "cpu" = no GPU at all, the copies stepped by the CPU emulation of the device source (tests/emu)
+    rehearsal = os.environ.get("MJRL_BENCH_REHEARSAL", "")
+    on_cpu = rehearsal == "cpu"
     if rehearsal:
         local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    import torch
+    dev = None
+    if not on_cpu:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -131,16 +306,13 @@ def main():
 
     entry.load_package()
     from mjrl_amd import levels
-    from mjrl_amd.mujoco_rl import MuJoCoRL
-
-    n_env = args.envs_per_gpu
     from mjrl_amd.dynamics import Language
-    plugins = [] if args.no_language else [Language]
-    n_agent = len(AGENTS)
-    act_dim = 8 + len(plugins)
-    total_steps = args.warmup + args.steps
-    # a cyclic buffer of ACT_RING steps of actions, resident in HBM before the timed region
-    acts_host = action_stream(0, rank * n_env, n_env, ACT_RING, n_agent, act_dim)
+
+    work = WORKLOADS[args.level]
+    agents, level_file = work["agents"], levels.level_path(work["level"])
+    n_env, n_agent = args.envs_per_gpu, len(agents)
+    # the Language channel is a 2-agent dynamic (README.md:109-136)
+    plugins = [Language] if (n_agent == 2 and not args.no_language) else []
 
     def barrier():
         if world > 1:
@@ -148,114 +320,132 @@ def main():
 
     def timed_run(groups):
         """The batch as `groups` env objects of n_env / groups copies, each on its own HIP stream (1: the whole batch
-        in lockstep on the current stream).  Returns (env objects, wall seconds, ms per step by HIP events, obs)."""
+        in lockstep on the current stream).  Returns (batches, wall seconds, ms per step by HIP events, stats)."""
         per = n_env // groups
-        envs, streams, bufs = [], [], []
+        batches, bufs, acts, masks = [], [], [], []
         for g in range(groups):
-            env = MuJoCoRL({"xmlPath": levels.level_path(LEVEL), "agents": AGENTS, "numEnvs": per, "deviceId": local,
-                            "skipFrames": 1, "maxSteps": 1024, "environmentDynamics": plugins,
-                            "nconmax": args.nconmax, "njmax": args.njmax})
-            stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
-            env._handle.set_stream(stream.cuda_stream)
-            env.reset_batched()
-            obs_dim = env._handle.size("obs_dim")
-            acts = torch.from_numpy(np.ascontiguousarray(acts_host[:, g * per:(g + 1) * per])).to(dev)
-            bufs.append((acts,
-                         torch.empty((per, n_agent, obs_dim), dtype=torch.float64, device=dev),
-                         torch.empty((per, n_agent), dtype=torch.float64, device=dev),
-                         torch.empty((per, n_agent), dtype=torch.uint8, device=dev),
-                         torch.empty((per, n_agent), dtype=torch.uint8, device=dev)))
-            envs.append(env)
-            streams.append(stream)
-        torch.cuda.synchronize(dev)
+            if on_cpu:
+                batch = RehearsalBatch(level_file, agents, per, bool(plugins))
+            else:
+                stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
+                batch = DeviceBatch(torch, dev, level_file, agents, per, plugins, args, stream)
+            n_phys = max(len(batch.agents_action_index[a]) for a in agents)
+            act_dim = n_phys + len(plugins)
+            first = rank * n_env + g * per
+            # a cyclic buffer of ACT_RING steps of actions and the reset masks of every episode phase, resident in HBM
+            # before the timed region
+            acts.append(batch.to_device(action_stream(0, first, per, ACT_RING, n_agent, act_dim, n_phys)))
+            phase = phase_of(first + np.arange(per), n_env)
+            masks.append(batch.to_device((phase[None, :] == np.arange(EPISODE)[:, None]).astype(np.uint8)))
+            bufs.append(batch.buffers(per, n_agent))
+            batches.append(batch)
+        if not on_cpu:
+            torch.cuda.synchronize(dev)
 
         def one_step(i):
-            # episodes are maxSteps = 1024 steps long, like the reference's benchmark loop (fps_benchmark.py:33-41):
-            # every copy is reset when its episode is over; the reset launch is part of the timed workload
-            for env, stream, (acts, obs, rew, term, trunc) in zip(envs, streams, bufs):
-                with torch.cuda.stream(stream):
-                    if i and i % 1024 == 0:
-                        env.reset_batched()
-                    env.step_batched(acts[i % ACT_RING], obs, rew, term, trunc)
+            # copy e starts a new episode at the steps i with (i - phase(e)) % 1024 == 0: it is reset inside the launch
+            for batch, a, m, (obs, rew, term, trunc) in zip(batches, acts, masks, bufs):
+                batch.set_step_reset_mask(m[i % EPISODE] if i else None)
+                batch.step_batched(a[i % ACT_RING], obs, rew, term, trunc)
 
-        for i in range(args.warmup):
+        lead = args.preroll + args.warmup
+        for i in range(lead):
             one_step(i)
-        torch.cuda.synchronize(dev)
+        if not on_cpu:
+            torch.cuda.synchronize(dev)
         barrier()
-        # HIP events on the stream the step kernel is launched on
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kernel_ms = None
+        if not on_cpu:
+            # HIP events on the stream the step kernel is launched on
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(streams[0])
-        for i in range(args.warmup, total_steps):
+        if not on_cpu:
+            ev0.record(batches[0].stream)
+        for i in range(lead, lead + args.steps):
             one_step(i)
-        ev1.record(streams[0])
-        torch.cuda.synchronize(dev)
+        if not on_cpu:
+            ev1.record(batches[0].stream)
+            torch.cuda.synchronize(dev)
         barrier()
         wall = time.perf_counter() - t0
-        kernel_ms = ev0.elapsed_time(ev1) / args.steps if groups == 1 else None
+        if not on_cpu and groups == 1:
+            kernel_ms = ev0.elapsed_time(ev1) / args.steps
         if world > 1:
             t = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
-        for _, obs, _, _, _ in bufs:
-            if not torch.isfinite(obs).all().item():
+        for batch, (obs, _, _, _) in zip(batches, bufs):
+            if not batch.finite(obs):
                 raise SystemExit("non-finite observations after the timed region")
-        return envs, wall, kernel_ms
+        # what the copies did in the last timed step: with staggered episodes one step is a sample of the stationary mix
+        stats = np.concatenate([np.asarray(b.solver_stats()) for b in batches]).astype(np.float64)
+        n_phys = max(len(batches[0].agents_action_index[a]) for a in agents)
+        return batches, wall, kernel_ms, stats, n_phys
 
-    envs, wall, kernel_ms = timed_run(args.groups)
-    env = envs[0]
-    obs_dim = env._handle.size("obs_dim")
-    # frames (warm-up included) in which a copy ran into its contact / row cap, i.e. dropped work: must be zero
-    overflows = [sum(c) for c in zip(*(e._handle.cap_overflows() for e in envs))]
+    batches, wall, kernel_ms, stats, n_phys = timed_run(args.groups)
+    batch = batches[0]
+    obs_dim = batch.obs_dim
+    act_dim = n_phys + len(plugins)
+    # frames (pre-roll and warm-up included) in which a copy ran into its contact / row cap, i.e. dropped work: must be zero
+    overflows = [sum(c) for c in zip(*(b.cap_overflows() for b in batches))]
     if any(overflows):
         print(f"bench: rank {rank}: {overflows[0]} frames hit nconmax, {overflows[1]} hit njmax -- raise the caps", file=sys.stderr)
-    for e in envs[1:]:
-        e.close()
+    for b in batches[1:]:
+        b.close()
     # Not the headline: the same batch as two half-batches that step independently on two streams (what a
-    # double-buffered sampler does: the policy works on one half while the other half steps).  The tail of one half's
-    # launch -- a few long solves -- then overlaps the body of the other's.
+    # double-buffered sampler does: the policy works on one half while the other half steps).
     double_buffered = None
-    if world == 1 and args.groups == 1 and not args.no_double_buffer:
-        envs2, wall2, _ = timed_run(2)
+    if world == 1 and args.groups == 1 and args.double_buffer and not on_cpu:
+        b2, wall2, _, _, _ = timed_run(2)
         double_buffered = {"groups": 2, "value": n_env * args.steps / wall2, "unit": "env-steps/s",
                            "ms_per_step": wall2 / args.steps * 1e3}
-        for e in envs2:
-            e.close()
+        for b in b2:
+            b.close()
 
     if rank == 0:
-        m = env._compiled
+        m = batch.model
         bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * obs_dim, n_agent,
                                                    n_slot=len(plugins))
-        if kernel_ms is None:                 # several groups: launches overlap, the step time is the wall time's
+        if kernel_ms is None:                 # several groups / no GPU: the step time is the wall time's
             kernel_ms = wall / args.steps * 1e3
         achieved = bytes_per * n_env / (kernel_ms * 1e-3) / 1e9
         traffic = None
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
-        pmc = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(pmc) and n_env == ENVS_PER_GPU:
+        pmc = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{args.level}.json")
+        if os.path.exists(pmc) and n_env == ENVS_PER_GPU and not on_cpu:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
             "metric": "env-steps/sec", "value": n_env * world * args.steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"2-agent ant arena ({LEVEL} = benchmarking/levels/MultiAgentModel.xml, stand-in for the "
-                                   f"unshipped MultiEnvs.xml), {n_env} env copies per GPU, skipFrames=1, PGS solver, "
-                                   f"action scatter + physics step + per-agent obs gather fused in one launch",
-                       "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv, "obs_dim": obs_dim,
-                       "nconmax": m.nconmax, "njmax": m.njmax, "cap_overflow_frames": list(overflows),
-                       "groups": args.groups},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not on_cpu else "REHEARSAL on the CPU emulation of the device source -- not a measurement",
+            "config": {"workload": f"{work['what']}, {n_env} env copies per GPU, skipFrames=1, PGS solver, episodes of "
+                                   f"{EPISODE} steps with the copies' episode phases uniform over 0..{EPISODE - 1} (in-launch "
+                                   f"reset of the copies whose episode is over); action scatter + physics step + per-agent "
+                                   f"obs gather{' + Language channel' if plugins else ''} fused in one launch",
+                       "level": args.level, "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv,
+                       "obs_dim": obs_dim, "act_dim": act_dim, "nconmax": m.nconmax, "njmax": m.njmax,
+                       "preroll_steps": args.preroll, "episode_steps": EPISODE,
+                       "mean_ncon": float(stats[:, 0].mean()), "mean_nefc": float(stats[:, 1].mean()),
+                       "mean_solver_sweeps": float(stats[:, 2].mean()),
+                       "max_ncon": int(stats[:, 0].max()), "max_nefc": int(stats[:, 1].max()),
+                       "max_solver_sweeps": int(stats[:, 2].max()),
+                       "cap_overflow_frames": list(overflows), "groups": args.groups},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mjrl_step_kernel_spec" if env._handle.kernel == "specialised" else "mjrl_step_kernel",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
+                         "kernel": batch.kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
         }
         if double_buffered:
             line["double_buffered"] = double_buffered
-        if world == 1 and not args.no_cpu_baseline:
-            scatter = np.array([env.agents_action_index[a] for a in AGENTS])
-            line["cpu_baseline"] = cpu_baseline(env._blob, scatter, language=bool(plugins))
+        if world == 1 and not args.no_cpu_baseline and not on_cpu:
+            scatter = np.full((n_agent, act_dim), -1, np.int64)
+            for k, a in enumerate(agents):
+                idx = batch.agents_action_index[a]
+                scatter[k, :len(idx)] = idx
+            line["cpu_baseline"] = cpu_baseline(level_file, batch.blob, scatter, n_agent, act_dim, n_phys,
+                                                language=bool(plugins))
         print(json.dumps(line), flush=True)
-    env.close()
+    batch.close()
     if world > 1:
         dist.destroy_process_group()
 

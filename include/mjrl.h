@@ -71,11 +71,21 @@ int mjrl_set_program(mjrl_env* env, int n_op, const int32_t* prog_i, const doubl
  * "n_agent","n_env","lds_doubles","ncon_stride", ...; -1 for an unknown name. */
 int mjrl_size(const mjrl_env* env, const char* name);
 
-/* Reset copies to qpos0 / zero velocity / zero ctrl / zero warm start / timestep 0.
- * Replaces mj_resetData (mujoco_parent.py:349); mask is a host array [n_env] of 0/1, NULL = all.
- * If d_obs is non-NULL the post-reset observations (mj_forward sensordata | qpos | qvel,
- * mujoco_parent.py:350 + mujoco_rl.py:314) are written there. */
+/* Reset copies: qpos0 / zero velocity / zero ctrl / timestep 0 / empty data store, followed by mj_forward.
+ * Replaces mj_resetData + mj_forward (mujoco_parent.py:349-350); mask is a host array [n_env] of 0/1, NULL = all.
+ * Every copy resets to the same state, so what mj_forward leaves there (sensordata, qacc_warmstart) is computed once
+ * per model at mjrl_create and copied; copies outside the mask are not touched.
+ * If d_obs is non-NULL the post-reset observations of the selected copies (sensordata | qpos | qvel,
+ * mujoco_rl.py:314; slots owned by fused dynamics: 0) are written to their rows of d_obs [n_env][n_agent][obs_dim]. */
 int mjrl_reset(mjrl_env* env, const uint8_t* h_mask, double* d_obs);
+/* The same with the mask in device memory (e.g. the term | trunc bytes a step wrote): asynchronous, no host copy. */
+int mjrl_reset_device(mjrl_env* env, const uint8_t* d_mask, double* d_obs);
+/* In-launch reset for sampling loops (`if done: env.reset()` then `env.step(a)`, fps_benchmark.py:33-38): while a mask
+ * is set, every step launch first resets the copies whose byte is non-zero at that moment -- exactly as mjrl_reset would
+ * -- and then steps them, in the same launch.  The mask [n_env] is caller-owned device memory, read by each launch
+ * (typically the done flags of the previous step); NULL turns it off.  The reset observation is not produced: the
+ * step returns the observation after the first step of the new episode. */
+int mjrl_set_step_reset_mask(mjrl_env* env, const uint8_t* d_mask);
 
 /* One step() of every copy: scatter actions, skip_frames physics steps, gather observations.
  * Replaces apply_action + mj_step loop (mujoco_parent.py:316-336) and get_observations (:380-392),
@@ -91,7 +101,9 @@ int mjrl_step_host(mjrl_env* env, const double* h_actions, int act_dim, int skip
                    double* h_reward, uint8_t* h_term, uint8_t* h_trunc);
 
 /* State access for parity tests and host-side plugins (synchronous, host buffers [n_env][n]).
- * Fields: "qpos","qvel","ctrl","qacc_warmstart","sensordata","timestep"(int32),"store" [n_env][n_agent][n_slot]. */
+ * Fields: "qpos","qvel","ctrl","qacc_warmstart","sensordata","timestep"(int32),"store" [n_env][n_agent][n_slot],
+ * "solver_stats"(int32, read-only) [n_env][4] = data.ncon, data.nefc, solver sweeps, cap-warning bits (1 nconmax,
+ * 2 njmax) of each copy's last physics frame. */
 int mjrl_get_field(mjrl_env* env, const char* name, void* h_out, size_t nbytes);
 int mjrl_set_field(mjrl_env* env, const char* name, const void* h_in, size_t nbytes);
 

@@ -20,6 +20,7 @@ SYMBOLS = [
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
+    "mjrl_reset_device", "mjrl_set_step_reset_mask",
 ]
 
 _lib = None
@@ -51,6 +52,8 @@ def load():
     L.mjrl_set_max_steps.argtypes = [vp, ci]
     L.mjrl_size.argtypes = [vp, ctypes.c_char_p]
     L.mjrl_reset.argtypes = [vp, vp, vp]
+    L.mjrl_reset_device.argtypes = [vp, vp, vp]
+    L.mjrl_set_step_reset_mask.argtypes = [vp, vp]
     L.mjrl_step_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.mjrl_step_host.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.mjrl_get_field.argtypes = [vp, ctypes.c_char_p, vp, sz]
@@ -191,6 +194,14 @@ class Handle:
                 raise Exception(f"reset mask has {m.size} entries for {self.n_env} env copies")
         self._check(self._lib.mjrl_reset(self._h, _host_ptr(m), ctypes.c_void_p(d_obs or 0)))
 
+    def reset_device(self, d_mask: int | None, d_obs: int | None = None):
+        """Reset the copies flagged in the device byte mask at address ``d_mask`` (None: all); asynchronous."""
+        self._check(self._lib.mjrl_reset_device(self._h, ctypes.c_void_p(d_mask or 0), ctypes.c_void_p(d_obs or 0)))
+
+    def set_step_reset_mask(self, d_mask: int | None):
+        """Every later step launch first resets the copies flagged in the device byte mask (None: off)."""
+        self._check(self._lib.mjrl_set_step_reset_mask(self._h, ctypes.c_void_p(d_mask or 0)))
+
     def step_device(self, d_actions, act_dim, skip_frames, d_obs=None, d_reward=None, d_term=None, d_trunc=None):
         """All pointers are integer device addresses (e.g. ``tensor.data_ptr()``) or None."""
         c = lambda p: ctypes.c_void_p(p or 0)
@@ -206,6 +217,8 @@ class Handle:
         per = {"qpos": "nq", "qvel": "nv", "ctrl": "nu", "qacc_warmstart": "nv", "sensordata": "nsensordata"}
         if name == "timestep":
             out = np.zeros(self.n_env, np.int32)
+        elif name == "solver_stats":
+            out = np.zeros((self.n_env, 4), np.int32)
         elif name == "store":
             out = np.zeros((self.n_env, max(self.size("n_agent"), 1), max(self.size("n_slot"), 0)), np.float64)
         else:

@@ -20,17 +20,35 @@ __global__ __launch_bounds__(64) void mjrl_step_kernel(const DevModel* __restric
   mj::env_step(*mp, a, lds);
 }
 
-// masked reset of the HBM state (mj_resetData for the selected copies)
-__global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double* ctrl, double* warm, int* timestep,
-                                  const unsigned char* mask, int n_env, double* store, int store_per_env) {
+// Masked reset of the HBM state: mj_resetData + mj_forward (mujoco_parent.py:349-350) for the selected copies.  Every
+// copy resets to the same state, so what mj_forward leaves there -- the warm start and the sensor readings -- is computed
+// once per model (reset image, mjrl_create) and copied; copies that are not selected are not touched at all.  With
+// `obs` the reset observations (mujoco_rl.py:314: sensordata | qpos | qvel per agent; slots owned by fused dynamics: 0)
+// of the selected copies are gathered from the image.
+__global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
+                                  int* timestep, const unsigned char* mask, int n_env, double* store, int store_per_env,
+                                  const double* warm0, const double* sens0, const int32_t* gather, int n_agent, int obs_dim,
+                                  double* obs) {
   int env = blockIdx.x;
   if (env >= n_env || (mask && !mask[env])) return;
   // an empty data store (mujoco_rl.py:312): every slot "absent"
   for (int i = threadIdx.x; i < store_per_env; i += blockDim.x) store[(size_t)env * store_per_env + i] = __longlong_as_double(0x7FF8000000000000ll);
   for (int i = threadIdx.x; i < m.nq; i += blockDim.x) qpos[(size_t)env * m.nq + i] = m.qpos0[i];
-  for (int i = threadIdx.x; i < m.nv; i += blockDim.x) { qvel[(size_t)env * m.nv + i] = 0; warm[(size_t)env * m.nv + i] = 0; }
+  for (int i = threadIdx.x; i < m.nv; i += blockDim.x) { qvel[(size_t)env * m.nv + i] = 0; warm[(size_t)env * m.nv + i] = warm0 ? warm0[i] : 0.0; }
   for (int i = threadIdx.x; i < m.nu; i += blockDim.x) ctrl[(size_t)env * m.nu + i] = 0;
+  if (sens0) for (int i = threadIdx.x; i < m.nsensordata; i += blockDim.x) sens[(size_t)env * m.nsensordata + i] = sens0[i];
   if (threadIdx.x == 0) timestep[env] = 0;
+  if (obs && gather) {
+    for (int it = threadIdx.x; it < n_agent * obs_dim; it += blockDim.x) {
+      int code = gather[it];
+      double v = 0;
+      if (code >= 0) {
+        int kind = code >> 24, idx = code & 0xFFFFFF;
+        v = kind == 0 ? (sens0 ? sens0[idx] : 0.0) : (kind == 1 ? m.qpos0[idx] : 0.0);
+      }
+      obs[(size_t)env * n_agent * obs_dim + it] = v;
+    }
+  }
 }
 
 // Fixed body-mounted cameras as a ray caster (replaces mjv_updateScene + mjr_render + mjr_readPixels of
@@ -154,8 +172,12 @@ struct mjrl_env {
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
   double* inertia = nullptr;       // [n_env][nM] scratch: the sparse inertia matrix between the CRB stage and the integrator
   unsigned long long* overflow = nullptr;   // [2] sticky cap-overflow counters (mjrl_cap_overflows)
+  int* stats = nullptr;            // [n_env][4] ncon, nefc, solver sweeps, warning bits of each copy's last physics frame
   int* timestep = nullptr;
   unsigned char* d_mask = nullptr;
+  // reset image: what mj_forward leaves at the reset state (the same for every copy), computed once at create
+  double *reset_warm = nullptr, *reset_sens = nullptr;
+  const unsigned char* step_reset_mask = nullptr;   // caller-owned device mask of the in-launch reset (mjrl_set_step_reset_mask)
   // tables
   int n_agent = 0, obs_dim = 0, scatter_mode = 0, max_steps = 1024;
   std::vector<int32_t> h_gather;                 // [n_agent][obs_dim]
@@ -197,6 +219,20 @@ struct mjrl_env {
     if (e_ != hipSuccess) MJRL_FAIL(env, 100 + (int)e_, "%s failed: %s", #call, hipGetErrorString(e_)); \
   } while (0)
 
+// Every entry point works on the handle's device whatever the calling thread's current device is, and leaves the
+// caller's current device as it found it.
+struct DeviceGuard {
+  int prev = -1, want;
+  explicit DeviceGuard(int device) : want(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) hipSetDevice(want);
+  }
+  ~DeviceGuard() { if (prev >= 0 && prev != want) hipSetDevice(prev); }
+};
+#define MJRL_ENTER(env)                  \
+  if (!(env)) return 1;                  \
+  DeviceGuard device_guard_((env)->device)
+
 extern "C" {
 
 const char* mjrl_version(void) { return "mjrl-hip 0.5 (blob layout 12, gfx950)"; }
@@ -205,8 +241,8 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
-  hipSetDevice(e->device);
-  void* ptrs[] = {e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  DeviceGuard guard(e->device);
+  void* ptrs[] = {e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia, e->overflow};
@@ -216,12 +252,18 @@ void mjrl_destroy(mjrl_env* e) {
   delete e;
 }
 
-static int launch_reset(mjrl_env* e, const unsigned char* d_mask) {
+static int launch_reset(mjrl_env* e, const unsigned char* d_mask, double* d_obs = nullptr) {
+  if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "reset: observations requested but no gather table is set");
   hipLaunchKernelGGL(mjrl_reset_kernel, dim3(e->n_env), dim3(64), 0, e->stream, e->dm, e->qpos, e->qvel, e->ctrl, e->warm,
-                     e->timestep, d_mask, e->n_env, e->store, e->n_agent * e->n_slot);
+                     e->sens, e->timestep, d_mask, e->n_env, e->store, e->n_agent * e->n_slot, e->reset_warm, e->reset_sens,
+                     e->d_gather, e->n_agent, e->obs_dim, d_obs);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }
+
+static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
+                       uint8_t* d_term, uint8_t* d_trunc, double* d_dbg, int dbg_stage, int forward_only,
+                       unsigned long long* d_stamps = nullptr, unsigned long long* d_timeline = nullptr);
 
 int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out) {
   if (!blob || !out || n_env <= 0) { g_create_error = "mjrl_create: bad arguments"; return 1; }
@@ -243,6 +285,9 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   if (lds_bytes > 160 * 1024) return fail(3, "mjrl_create: env working set exceeds the 160 KiB LDS of a CU");
   e->n_env = n_env;
   e->device = device_id;
+  int caller_device = -1;
+  hipGetDevice(&caller_device);
+  struct Restore { int d; ~Restore() { if (d >= 0) hipSetDevice(d); } } restore{caller_device};
   hipError_t he = hipSetDevice(device_id);
   if (he != hipSuccess) return fail(4, std::string("hipSetDevice: ") + hipGetErrorString(he));
 #define CK(call) do { he = (call); if (he != hipSuccess) return fail(5, std::string(#call ": ") + hipGetErrorString(he)); } while (0)
@@ -258,6 +303,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
   CK(hipMalloc(&e->warm, sizeof(double) * n_env * m.nv));
   CK(hipMalloc(&e->inertia, sizeof(double) * (size_t)n_env * (m.nM > 0 ? m.nM : 1)));
+  CK(hipMalloc(&e->stats, sizeof(int) * 4 * (size_t)n_env));
+  CK(hipMemset(e->stats, 0, sizeof(int) * 4 * (size_t)n_env));
   CK(hipMalloc(&e->overflow, sizeof(unsigned long long) * 2));
   CK(hipMemset(e->overflow, 0, sizeof(unsigned long long) * 2));
   CK(hipMalloc(&e->sens, sizeof(double) * n_env * (m.nsensordata > 0 ? m.nsensordata : 1)));
@@ -273,14 +320,25 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipFuncSetAttribute((const void*)mjrl_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                          (int)render_lds_bytes(e->lay, m)));
 #undef CK
+  // the reset image: reset every copy (zero warm start, as mj_resetData leaves it), run mj_forward once, keep copy 0's
+  // warm start and sensor readings
   if (launch_reset(e, nullptr)) return fail(6, e->err);
-  he = hipStreamSynchronize(e->stream);
-  if (he != hipSuccess) return fail(6, std::string("reset: ") + hipGetErrorString(he));
+  if (launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1)) return fail(6, e->err);
+  double *w0 = nullptr, *s0 = nullptr;
+  he = hipMalloc(&w0, sizeof(double) * m.nv);
+  if (he == hipSuccess) he = hipMalloc(&s0, sizeof(double) * (m.nsensordata > 0 ? m.nsensordata : 1));
+  if (he == hipSuccess) he = hipMemcpyAsync(w0, e->warm, sizeof(double) * m.nv, hipMemcpyDeviceToDevice, e->stream);
+  if (he == hipSuccess && m.nsensordata > 0)
+    he = hipMemcpyAsync(s0, e->sens, sizeof(double) * m.nsensordata, hipMemcpyDeviceToDevice, e->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+  e->reset_warm = w0; e->reset_sens = s0;
+  if (he != hipSuccess) return fail(6, std::string("reset image: ") + hipGetErrorString(he));
   *out = e;
   return 0;
 }
 
 int mjrl_set_stream(mjrl_env* e, void* hip_stream) {
+  MJRL_ENTER(e);
   hipStream_t next = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
   if (next == e->stream) return 0;
   MJRL_HIP(e, hipStreamSynchronize(e->stream));   // work queued on the old stream finishes before the switch
@@ -289,11 +347,14 @@ int mjrl_set_stream(mjrl_env* e, void* hip_stream) {
 }
 
 int mjrl_sync(mjrl_env* e) {
+  MJRL_ENTER(e);
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   return 0;
 }
 
-int mjrl_set_max_steps(mjrl_env* e, int max_steps) { e->max_steps = max_steps; return 0; }
+int mjrl_set_max_steps(mjrl_env* e, int max_steps) {
+  MJRL_ENTER(e);
+  e->max_steps = max_steps; return 0; }
 
 // device gather table = physical part [base_obs_dim] + n_extra slots per agent owned by the fused program (-2)
 static int upload_gather(mjrl_env* e) {
@@ -318,6 +379,7 @@ static int upload_gather(mjrl_env* e) {
 
 int mjrl_set_program(mjrl_env* e, int n_op, const int32_t* prog_i, const double* prog_f, int n_slot, int n_extra_obs,
                      const int32_t* agent_body) {
+  MJRL_ENTER(e);
   if (!e->n_agent || e->h_obs_len.empty()) MJRL_FAIL(e, 1, "set_program: set the gather tables first");
   if (e->n_agent > mj::MAX_AGENT) MJRL_FAIL(e, 1, "set_program: at most %d agents", (int)mj::MAX_AGENT);
   if (n_op < 0 || n_slot < 0 || n_extra_obs < 0) MJRL_FAIL(e, 1, "set_program: negative size");
@@ -354,6 +416,7 @@ int mjrl_set_program(mjrl_env* e, int n_op, const int32_t* prog_i, const double*
 int mjrl_set_gather_tables(mjrl_env* e, int n_agent, const int32_t* n_sensor, const int32_t* sensor_idx,
                            const int32_t* n_qpos, const int32_t* qpos_idx, const int32_t* n_qvel,
                            const int32_t* qvel_idx) {
+  MJRL_ENTER(e);
   if (n_agent <= 0) MJRL_FAIL(e, 1, "set_gather_tables: n_agent must be positive");
   if (e->n_agent && e->n_agent != n_agent) MJRL_FAIL(e, 1, "set_gather_tables: agent count differs from the scatter table's");
   const DevModel& m = e->hm;
@@ -388,6 +451,7 @@ int mjrl_set_gather_tables(mjrl_env* e, int n_agent, const int32_t* n_sensor, co
 }
 
 int mjrl_set_scatter_tables(mjrl_env* e, int n_agent, int mode, const int32_t* n_idx, const int32_t* idx) {
+  MJRL_ENTER(e);
   if (n_agent <= 0) MJRL_FAIL(e, 1, "set_scatter_tables: n_agent must be positive");
   if (e->n_agent && e->n_agent != n_agent) MJRL_FAIL(e, 1, "set_scatter_tables: agent count differs from the gather table's");
   const DevModel& m = e->hm;
@@ -459,13 +523,14 @@ static int ensure_scatter(mjrl_env* e, int act_dim) {
 // mode: 0 = full step; 1 = forward pass only (no integration, no counters): reset observations and queries
 static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
                        uint8_t* d_term, uint8_t* d_trunc, double* d_dbg, int dbg_stage, int forward_only,
-                       unsigned long long* d_stamps = nullptr, unsigned long long* d_timeline = nullptr) {
+                       unsigned long long* d_stamps, unsigned long long* d_timeline) {
   if (skip_frames < 0) MJRL_FAIL(e, 3, "step: skip_frames must be >= 0");
   if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "step: observations requested but no gather table is set");
   mj::StepArgs a{};
   a.qpos = e->qpos; a.qvel = e->qvel; a.ctrl = e->ctrl; a.warm = e->warm; a.sensordata = e->sens;
   a.inertia = e->inertia;
   a.overflow = e->overflow;
+  a.stats = e->stats;
   a.timestep = e->timestep;
   a.actions = nullptr; a.scatter = nullptr;
   a.n_agent = e->n_agent; a.act_dim = act_dim; a.scatter_mode = e->scatter_mode;
@@ -481,6 +546,8 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.forward_only = forward_only;
   a.stamps = d_stamps;
   a.timeline = d_timeline;
+  a.reset_mask = forward_only ? nullptr : e->step_reset_mask;
+  a.reset_warm = e->reset_warm;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
   a.agent_body = e->d_agent_body; a.agent_obs_len = e->d_obs_len; a.store = e->store;
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
@@ -495,7 +562,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     const bool last = f == launches - 1;
     a.skip_frames = skip_frames > 0 ? 1 : 0;
     a.more_frames = last ? 0 : 1;
-    if (f > 0) a.scatter = nullptr;
+    if (f > 0) { a.scatter = nullptr; a.reset_mask = nullptr; }
     a.dbg = last ? d_dbg : nullptr;
     a.frames = last ? e->frames : nullptr;
     a.lpt_count_in = nullptr; a.lpt_list_in = nullptr; a.lpt_count_out = nullptr; a.lpt_list_out = nullptr;
@@ -522,9 +589,8 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
 }
 
 int mjrl_cap_overflows(mjrl_env* e, unsigned long long* h_counts, int clear) {
-  if (!e) return 1;
+  MJRL_ENTER(e);
   if (!h_counts) MJRL_FAIL(e, 4, "cap_overflows: null output");
-  MJRL_HIP(e, hipSetDevice(e->device));
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   MJRL_HIP(e, hipMemcpy(h_counts, e->overflow, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost));
   if (clear) MJRL_HIP(e, hipMemset(e->overflow, 0, sizeof(unsigned long long) * 2));
@@ -532,8 +598,7 @@ int mjrl_cap_overflows(mjrl_env* e, unsigned long long* h_counts, int clear) {
 }
 
 int mjrl_load_kernel(mjrl_env* e, const char* path) {
-  if (!e) return 1;
-  MJRL_HIP(e, hipSetDevice(e->device));
+  MJRL_ENTER(e);
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   if (e->spec_module) { hipModuleUnload(e->spec_module); e->spec_module = nullptr; e->spec_fn = nullptr; }
   if (!path) return 0;                      // back to the generic kernel
@@ -566,6 +631,7 @@ int mjrl_load_kernel(mjrl_env* e, const char* path) {
 
 int mjrl_step_device(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
                      uint8_t* d_term, uint8_t* d_trunc) {
+  MJRL_ENTER(e);
   return launch_step(e, d_actions, act_dim, skip_frames, d_obs, d_reward, d_term, d_trunc, nullptr, 0, 0);
 }
 
@@ -593,6 +659,7 @@ static int ensure_staging(mjrl_env* e, int act_dim) {
 
 int mjrl_step_host(mjrl_env* e, const double* h_actions, int act_dim, int skip_frames, double* h_obs, double* h_reward,
                    uint8_t* h_term, uint8_t* h_trunc) {
+  MJRL_ENTER(e);
   if (int rc = ensure_staging(e, act_dim)) return rc;
   size_t na = (size_t)e->n_env * std::max(e->n_agent, 1);
   if (h_actions)
@@ -610,16 +677,27 @@ int mjrl_step_host(mjrl_env* e, const double* h_actions, int act_dim, int skip_f
 }
 
 int mjrl_reset(mjrl_env* e, const uint8_t* h_mask, double* d_obs) {
+  MJRL_ENTER(e);
   const unsigned char* d_mask = nullptr;
   if (h_mask) {
     MJRL_HIP(e, hipMemcpyAsync(e->d_mask, h_mask, e->n_env, hipMemcpyHostToDevice, e->stream));
     d_mask = e->d_mask;
   }
-  if (int rc = launch_reset(e, d_mask)) return rc;
   e->frames_valid = false;
-  // mj_forward after the reset (mujoco_parent.py:350): refreshes sensordata and the warm start of every copy
-  // (a forward pass on an un-reset copy recomputes the same values it already holds)
-  return launch_step(e, nullptr, 0, 1, d_obs, nullptr, nullptr, nullptr, nullptr, 0, 1);
+  // mj_resetData + mj_forward (mujoco_parent.py:349-350) from the reset image; unselected copies are not touched
+  return launch_reset(e, d_mask, d_obs);
+}
+
+int mjrl_reset_device(mjrl_env* e, const uint8_t* d_mask, double* d_obs) {
+  MJRL_ENTER(e);
+  e->frames_valid = false;
+  return launch_reset(e, d_mask, d_obs);
+}
+
+int mjrl_set_step_reset_mask(mjrl_env* e, const uint8_t* d_mask) {
+  MJRL_ENTER(e);
+  e->step_reset_mask = d_mask;
+  return 0;
 }
 
 struct field_ref { void* ptr; size_t bytes; };
@@ -632,12 +710,14 @@ static int find_field(mjrl_env* e, const char* name, field_ref* f) {
   else if (!strcmp(name, "qacc_warmstart")) *f = {e->warm, sizeof(double) * n * m.nv};
   else if (!strcmp(name, "sensordata")) *f = {e->sens, sizeof(double) * n * m.nsensordata};
   else if (!strcmp(name, "timestep")) *f = {e->timestep, sizeof(int) * n};
+  else if (!strcmp(name, "solver_stats")) *f = {e->stats, sizeof(int) * 4 * n};
   else if (!strcmp(name, "store")) *f = {e->store, sizeof(double) * n * e->n_agent * e->n_slot};
   else MJRL_FAIL(e, 4, "unknown field '%s'", name);
   return 0;
 }
 
 int mjrl_get_field(mjrl_env* e, const char* name, void* h_out, size_t nbytes) {
+  MJRL_ENTER(e);
   field_ref f;
   if (int rc = find_field(e, name, &f)) return rc;
   if (nbytes != f.bytes) MJRL_FAIL(e, 4, "get_field(%s): buffer holds %zu bytes, field has %zu", name, nbytes, f.bytes);
@@ -647,6 +727,7 @@ int mjrl_get_field(mjrl_env* e, const char* name, void* h_out, size_t nbytes) {
 }
 
 int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
+  MJRL_ENTER(e);
   if (width <= 0 || height <= 0 || !d_rgb) MJRL_FAIL(e, 3, "render: bad arguments");
   if (e->hm.ncam == 0) MJRL_FAIL(e, 3, "render: the level has no cameras");
   const size_t lds_bytes = render_lds_bytes(e->lay, e->hm);
@@ -663,6 +744,7 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
 }
 
 int mjrl_render_host(mjrl_env* e, int width, int height, uint8_t* h_rgb) {
+  MJRL_ENTER(e);
   size_t n = (size_t)e->n_env * e->hm.ncam * width * height * 3;
   uint8_t* d = nullptr;
   MJRL_HIP(e, hipMalloc(&d, n ? n : 1));
@@ -677,6 +759,7 @@ int mjrl_render_host(mjrl_env* e, int width, int height, uint8_t* h_rgb) {
 }
 
 int mjrl_set_query_cache(mjrl_env* e, int enabled) {
+  MJRL_ENTER(e);
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   if (enabled && !e->frames)
     MJRL_HIP(e, hipMalloc(&e->frames, sizeof(double) * (size_t)e->n_env * mj::frame_doubles(e->hm)));
@@ -686,6 +769,7 @@ int mjrl_set_query_cache(mjrl_env* e, int enabled) {
 }
 
 int mjrl_set_field(mjrl_env* e, const char* name, const void* h_in, size_t nbytes) {
+  MJRL_ENTER(e);
   field_ref f;
   if (int rc = find_field(e, name, &f)) return rc;
   e->frames_valid = false;      // the state the cached frames belong to is being replaced
@@ -702,6 +786,7 @@ static int ensure_dbg(mjrl_env* e) {
 
 int mjrl_step_debug(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, int stage, double* h_dump,
                     size_t nbytes) {
+  MJRL_ENTER(e);
   size_t need = sizeof(double) * (size_t)e->n_env * e->lay.total;
   if (nbytes != need) MJRL_FAIL(e, 4, "step_debug: dump buffer holds %zu bytes, need %zu", nbytes, need);
   if (int rc = ensure_dbg(e)) return rc;
@@ -713,6 +798,7 @@ int mjrl_step_debug(mjrl_env* e, const double* d_actions, int act_dim, int skip_
 
 int mjrl_step_profile(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, unsigned long long* h_cycles,
                       int n) {
+  MJRL_ENTER(e);
   if (n != mj::N_STAMPS) MJRL_FAIL(e, 4, "step_profile: expected room for %d stage counters, got %d", (int)mj::N_STAMPS, n);
   unsigned long long* d = nullptr;
   MJRL_HIP(e, hipMalloc(&d, sizeof(unsigned long long) * n));
@@ -728,7 +814,7 @@ int mjrl_step_profile(mjrl_env* e, const double* d_actions, int act_dim, int ski
 }
 
 int mjrl_step_timeline(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, unsigned long long* h_out, size_t n) {
-  if (!e) return 1;
+  MJRL_ENTER(e);
   if (n != 3 * (size_t)e->n_env) MJRL_FAIL(e, 4, "step_timeline: expected room for %zu counters, got %zu", 3 * (size_t)e->n_env, n);
   if (skip_frames != 1) MJRL_FAIL(e, 4, "step_timeline: one frame per step only");
   unsigned long long* d = nullptr;
@@ -744,12 +830,14 @@ int mjrl_step_timeline(mjrl_env* e, const double* d_actions, int act_dim, int sk
 }
 
 int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
+  MJRL_ENTER(e);
   const DevModel& m = e->hm;
   // The frames of the last forward pass: kept by the step kernel when the query cache is on (what the reference's
   // data.xipos / data.contact hold after mj_step); otherwise, or after a state write, one forward-only launch.
   if (!e->frames) if (int rc = mjrl_set_query_cache(e, 1)) return rc;
   if (!e->frames_valid) {
-    if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1)) return rc;
+    // (a pure query: the forward pass fills the frame cache and refreshes sensordata, the warm start stays)
+    if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 2, nullptr, nullptr)) return rc;
   }
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   const int fd = mj::frame_doubles(m);
@@ -774,7 +862,7 @@ int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
     // cap-overflow flags live in the LDS image only: one debug forward pass
     if (int rc = ensure_dbg(e)) return rc;
     bool keep = e->frames_valid;
-    if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, e->dbg, 0, 1)) return rc;
+    if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, e->dbg, 0, 2, nullptr, nullptr)) return rc;
     e->frames_valid = keep;
     MJRL_HIP(e, hipStreamSynchronize(e->stream));
     std::vector<double> lds((size_t)e->n_env * e->lay.total);

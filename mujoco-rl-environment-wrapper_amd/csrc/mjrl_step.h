@@ -139,7 +139,17 @@ struct StepArgs {
   // debug dump of the env's whole LDS image after the forward pass of the last substep
   real* dbg;                 // [n_env][lay.total], may be null
   int dbg_stage;             // 0: end of forward pass; 1: right after the constraint rows are built
-  int forward_only;          // 1: mj_forward semantics -- no integration, no counters (reset observations, queries)
+  int forward_only;          // 1: mj_forward semantics -- no integration, no counters; writes sensordata and the warm
+                             // start like mj_forward.  2: the same as a pure query (mjrl_query): the warm start stays
+  // In-launch reset (mjrl_set_step_reset_mask): a copy whose byte is set starts this step from the reset image instead of
+  // its state rows -- qpos0, zero velocity and controls, the warm start mj_forward leaves at the reset state (reset_warm,
+  // computed once per model at create), step counter 0, an empty data store -- i.e. `env.reset(); env.step(a)` of the
+  // reference's sampling loops (fps_benchmark.py:33-38, mujoco_rl.py:291-331) in one launch.
+  const unsigned char* reset_mask;   // [n_env] device bytes, may be null
+  // what the copy's last physics frame did: [n_env][4] = contacts, constraint rows, solver sweeps, cap-warning bits
+  // (data.ncon, data.nefc, data.solver_iter, data.warning of MjData); may be null
+  int* stats;
+  const real* reset_warm;            // [nv]
   unsigned long long* stamps;   // diagnostic: per-stage wave-clock sums over all env copies [N_STAMPS], may be null
   // Fused plugin vocabulary, run after the gather in list order, agent-minor, strictly sequentially -- the order of the
   // reference's plugin loop (mujoco_rl.py:215-241 dynamics, :276-277 rewards, :281-286 dones).  Op word layout: OP_*.
@@ -1979,8 +1989,9 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
         if (rest < c) bucket = b; else rest -= c;
       }
     }
-    env = bucket >= 0 ? a.lpt_list_in[(size_t)bucket * a.n_env + rest] : -1;
-    if (bucket < 0) bucket = 0;
+    // (the bucket counts sum to n_env by construction; a workgroup past them has no copy to step)
+    if (bucket < 0) return;
+    env = a.lpt_list_in[(size_t)bucket * a.n_env + rest];
     // The launch ends with its slowest copy, and a copy with hundreds of solver row steps is one long dependent
     // chain: its wave gets issue priority over the waves that share its SIMD (they fill the gaps it leaves).
     wv::set_priority(bucket >= 10 ? 3 : (bucket == 9 ? 2 : (bucket == 8 ? 1 : 0)));
@@ -2004,15 +2015,22 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     stamps->prev = t_now;                                                  \
   }
 #define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
-  // state in
-  MJ_FOR(i, m.nq) S[l.qpos + i] = a.qpos[(size_t)env * m.nq + i];
-  MJ_FOR(i, m.nv) { S[l.qvel + i] = a.qvel[(size_t)env * m.nv + i]; S[l.warm + i] = a.warm[(size_t)env * m.nv + i]; }
-  MJ_FOR(i, m.nu) S[l.ctrl + i] = a.ctrl[(size_t)env * m.nu + i];
+  // state in: the copy's rows, or the reset image when the copy is flagged for an in-launch reset
+  const bool resetting = a.reset_mask != nullptr && !a.forward_only && wv::first_int((int)a.reset_mask[env]) != 0;
+  if (resetting) {
+    MJ_FOR(i, m.nq) S[l.qpos + i] = m.qpos0[i];
+    MJ_FOR(i, m.nv) { S[l.qvel + i] = 0; S[l.warm + i] = a.reset_warm[i]; }
+    MJ_FOR(i, m.nu) S[l.ctrl + i] = 0;
+  } else {
+    MJ_FOR(i, m.nq) S[l.qpos + i] = a.qpos[(size_t)env * m.nq + i];
+    MJ_FOR(i, m.nv) { S[l.qvel + i] = a.qvel[(size_t)env * m.nv + i]; S[l.warm + i] = a.warm[(size_t)env * m.nv + i]; }
+    MJ_FOR(i, m.nu) S[l.ctrl + i] = a.ctrl[(size_t)env * m.nu + i];
+  }
   // what the end of the step reads from HBM is fetched now, one element per lane, so that no load latency is left
   // exposed after the integrator: the step counter and, for the fused plugin ops, the copy's action row and its
   // data-store row (staged in the dead bias-force vector once the integrator is done; a program too large for that
   // reads HBM directly)
-  const int ts = a.forward_only ? 0 : a.timestep[env];
+  const int ts = (a.forward_only || resetting) ? 0 : a.timestep[env];
   // staging area at the end of the step: the four nv-vectors from the bias forces on, all dead after the integrator
   //   [action row | data-store row | prog_f (4 per op) | prog_i (8 ints per op) | obs_len, agent_body (ints)]
   const int n_act_row = a.n_agent * a.act_dim, n_store_row = a.n_agent * a.n_slot;
@@ -2029,7 +2047,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     if (a.scatter) sc_reg = a.scatter[L];
   }
   if (ops_staged) {
-    if (a.store && L < n_store_row) store_reg = a.store[(size_t)env * n_store_row + L];
+    if (a.store && L < n_store_row)
+      store_reg = resetting ? __builtin_nan("") : a.store[(size_t)env * n_store_row + L];     // (reset: an empty store)
     if (L < 4 * a.n_op) pf_reg = a.prog_f[L];
     if (L < 8 * a.n_op) pi_reg = a.prog_i[L];
     if (L < a.n_agent) { len_reg = a.agent_obs_len[L]; body_reg = a.agent_body[L]; }
@@ -2120,7 +2139,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     MJ_FOR(i, m.nv) a.qvel[(size_t)env * m.nv + i] = S[l.qvel + i];
     MJ_FOR(i, m.nu) a.ctrl[(size_t)env * m.nu + i] = S[l.ctrl + i];
   }
-  MJ_FOR(i, m.nv) a.warm[(size_t)env * m.nv + i] = S[l.warm + i];
+  if (a.forward_only != 2) MJ_FOR(i, m.nv) a.warm[(size_t)env * m.nv + i] = S[l.warm + i];
   MJ_FOR(i, m.nsensordata) a.sensordata[(size_t)env * m.nsensordata + i] = S[l.sens + i];
   // per-agent observation gather: sensordata | qpos | qvel (sensordata is the pre-integration forward pass,
   // qpos/qvel are post-integration, exactly as the reference reads them after mj_step)
@@ -2146,6 +2165,10 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
     int pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
     a.lpt_list_out[(size_t)b * a.n_env + pos] = env;
+  }
+  if (a.stats && a.skip_frames && L < 4) {
+    const int* I = (const int*)(S + l.ints);
+    a.stats[4 * (size_t)env + L] = I[L == 0 ? I_NCON : (L == 1 ? I_NEFC : (L == 2 ? I_NITER : I_WARN))];
   }
   if (a.overflow && !a.forward_only && a.skip_frames && L == 0) {
     const int warn = ((const int*)(S + l.ints))[I_WARN];
@@ -2181,6 +2204,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     const int32_t* prog_i = ops_staged ? (const int32_t*)(TI + 2 * t_pi) : a.prog_i;
     const int32_t* obs_len = ops_staged ? (const int32_t*)(TI + 2 * t_ag) : a.agent_obs_len;
     const int32_t* agent_body = ops_staged ? (const int32_t*)(TI + 2 * t_ag + a.n_agent) : a.agent_body;
+    if (resetting && !ops_staged && store)      // (the staged copy of the row was cleared when it was fetched)
+      for (int k = 0; k < a.n_agent * a.n_slot; k++) store[k] = __builtin_nan("");
     for (int op = 0; op < a.n_op; op++) {
       const int32_t* pi = prog_i + 8 * op;
       const real* pf = prog_f + 4 * op;

@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE: a batch of env copies stepped by the CPU lane-emulation build of the DEVICE step source
+(csrc/mjrl_step.h through tests/emu), behind the handful of calls ``bench.py`` and the sharding test make on the
+product's device batch.  It lets the multi-rank control flow of ``bench.py`` (rank children, rendezvous, barrier,
+max over ranks, rank-0 line) and the sharding property (a copy's trajectory depends on its global env id only) be
+exercised in a container without a GPU, on the product's own arithmetic.  Never imported by the package."""
+from __future__ import annotations
+
+import numpy as np
+
+from mjrl_amd import blob, mjcf
+from mjrl_amd.mujoco_parent import MuJoCoParent
+from tests.emu.emu import EmuEnv
+
+
+class EmuBatch:
+    kernel = "cpu-emulation of the device source"
+
+    def __init__(self, xml_path: str, agents, n_env: int, language: bool = False, free_joint: bool = False,
+                 max_steps: int = 1024):
+        self.model = mjcf.compile_mjcf(xml_path)
+        self.blob = blob.pack(self.model)
+        self.agents, self.n_env, self.max_steps = list(agents), int(n_env), int(max_steps)
+        host = MuJoCoParent.tables_only(xml_path, free_joint=free_joint)
+        n_agent = len(self.agents)
+        for agent in self.agents:
+            host.get_observation_space_mujoco(agent)
+            host.get_action_space_mujoco(agent)
+        self.agents_action_index = host.agents_action_index
+        phys = max(len(host.agents_action_index[a]) for a in self.agents)
+        self.act_dim = phys + (1 if language else 0)
+        self.scatter = np.full((n_agent, self.act_dim), -1, np.int32)
+        self.scatter_mode = 1 if free_joint else 0
+        lens = []
+        rows = []
+        for k, agent in enumerate(self.agents):
+            idx = host.agents_observation_index[agent]
+            self.scatter[k, :len(host.agents_action_index[agent])] = host.agents_action_index[agent]
+            row = [(0 << 24) | i for i in idx["sensors"]] + [(1 << 24) | i for i in idx["qpos"]] + [(2 << 24) | i for i in idx["qvel"]]
+            rows.append(row)
+            lens.append(len(row))
+        self.obs_dim = max(lens) + (1 if language else 0)
+        self.gather = np.full((n_agent, self.obs_dim), -1, np.int32)
+        for k, row in enumerate(rows):
+            self.gather[k, :len(row)] = row
+            if language:
+                self.gather[k, lens[k]] = -2
+        self.program = None
+        if language:
+            names = self.model.names["body"]
+            self.program = dict(prog_i=np.array([[1, phys, 0, 0, 0, 0, 0, 0]], np.int32), prog_f=np.zeros((1, 4)), n_slot=1,
+                                agent_body=np.array([names.index(a) for a in self.agents], np.int32),
+                                agent_obs_len=np.array(lens, np.int32))
+        self.envs = [EmuEnv(self.model, self.blob) for _ in range(self.n_env)]
+        self.stores = [np.full((n_agent, 1), np.nan) for _ in range(self.n_env)]
+        self.envs[0].step(forward_only=True)
+        self.reset_warm = self.envs[0].warm.copy()          # the reset image (mjrl_create)
+        self.reset_sens = self.envs[0].sens.copy()
+        self._reset_mask = None
+        self.reset_batched()
+
+    def reset_batched(self, mask=None):
+        for e, env in enumerate(self.envs):
+            if mask is not None and not mask[e]:
+                continue
+            env.qpos[:] = self.model.qpos0
+            env.qvel[:] = 0
+            env.ctrl[:] = 0
+            env.warm[:] = self.reset_warm
+            env.sens[:] = self.reset_sens
+            env.timestep[:] = 0
+            self.stores[e][:] = np.nan
+
+    def set_step_reset_mask(self, mask):
+        self._reset_mask = None if mask is None else np.asarray(mask)
+
+    def step_batched(self, actions, obs, reward, term, trunc):
+        n_agent = len(self.agents)
+        self.last_stats = np.zeros((self.n_env, 4), np.int32)
+        for e, env in enumerate(self.envs):
+            program = None
+            if self.program is not None:
+                program = dict(self.program, store=self.stores[e], reward=reward[e], term=term[e], trunc=trunc[e])
+            resetting = self._reset_mask is not None and self._reset_mask[e]
+            if resetting:
+                self.stores[e][:] = np.nan
+            act = np.ascontiguousarray(actions[e], dtype=np.float64)
+            row = np.zeros((n_agent, self.obs_dim))
+            img = env.step(actions=act, scatter=self.scatter, n_agent=n_agent, scatter_mode=self.scatter_mode,
+                           gather=self.gather, obs=row, program=program, max_steps=self.max_steps,
+                           reset_warm=self.reset_warm if resetting else None)
+            obs[e] = row
+            if program is None:
+                reward[e] = 0
+                term[e] = 0
+                trunc[e] = env.timestep[0] - 1 >= self.max_steps
+            self.last_stats[e] = (img.ncon, img.nefc, img.niter, img.warn)
+        return obs, reward, term, trunc
+
+    def solver_stats(self):
+        return self.last_stats
+
+    def cap_overflows(self):
+        return (0, 0)
+
+    def close(self):
+        self.envs = []

@@ -31,6 +31,8 @@ def lib():
         L.emu_step.argtypes = [ctypes.c_char_p, ctypes.c_size_t, P, P, P, P, P, P, P, P, ctypes.c_int, ctypes.c_int,
                                ctypes.c_int, P, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P,
                                ctypes.c_int, ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int, P, P, P, P, P, P]
+        L.emu_set_step_reset.argtypes = [ctypes.c_int, P]
+        L.emu_set_step_reset.restype = None
         _lib = L
     return _lib
 
@@ -138,9 +140,13 @@ class EmuEnv:
         return lib().emu_lds_offset(self.blob, len(self.blob), name.encode())
 
     def step(self, nsteps=1, skip_frames=1, dbg_stage=0, forward_only=False, actions=None, scatter=None, n_agent=0,
-             scatter_mode=0, gather=None, obs=None, program=None, max_steps=1 << 30):
+             scatter_mode=0, gather=None, obs=None, program=None, max_steps=1 << 30, reset_warm=None):
         """``program``: dict(prog_i, prog_f, n_slot, agent_body, agent_obs_len, store, reward, term, trunc) for the
-        fused plugin ops."""
+        fused plugin ops.  ``reset_warm``: the first frame starts from the reset image (in-launch reset) with this warm
+        start."""
+        if reset_warm is not None:
+            self._reset_warm = np.ascontiguousarray(reset_warm, dtype=np.float64)
+            lib().emu_set_step_reset(1, _p(self._reset_warm))
         act_dim = 0 if actions is None else actions.shape[-1]
         obs_dim = 0 if gather is None else gather.shape[-1]
         rc = lib().emu_step(self.blob, len(self.blob), _p(self.qpos), _p(self.qvel), _p(self.ctrl), _p(self.warm),

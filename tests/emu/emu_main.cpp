@@ -97,6 +97,12 @@ int emu_lds_offset(const void* blob, size_t nbytes, const char* region) {
   return -1;
 }
 
+// in-launch reset of the next emu_step call's first frame (mjrl_set_step_reset_mask): flag != 0 and the reset image's
+// warm start; cleared by the call
+static unsigned char g_reset_flag = 0;
+static const double* g_reset_warm = nullptr;
+void emu_set_step_reset(int flag, const double* reset_warm) { g_reset_flag = flag ? 1 : 0; g_reset_warm = reset_warm; }
+
 // one env copy, `nsteps` step() calls with the same actions; state arrays are updated in place
 int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
              int* timestep, const double* actions, const int32_t* scatter, int n_agent, int act_dim, int scatter_mode,
@@ -130,9 +136,11 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
       b.more_frames = f < launches - 1;
       if (f > 0) b.scatter = nullptr;
       if (b.more_frames) { b.dbg = nullptr; b.frames = nullptr; }
+      if (s == 0 && f == 0 && g_reset_flag) { b.reset_mask = &g_reset_flag; b.reset_warm = g_reset_warm; }
       if (emu::run_wave(m, b, lds.data())) return 2;
     }
   }
+  g_reset_flag = 0;
   return 0;
 }
 }

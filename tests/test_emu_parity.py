@@ -428,3 +428,25 @@ def test_more_than_sixteen_rows_per_tree_in_a_four_tree_model():
         many_row_steps += bool((trees >= 0).all() and 16 < max(per_tree) <= 32)
     assert many_row_steps > 0
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
+
+
+def test_in_launch_reset_equals_reset_then_step():
+    """A copy flagged in the step's reset mask (mjrl_set_step_reset_mask) starts the launch from the reset image: the
+    result is bit for bit that of reset (+ mj_forward) followed by the same step, whatever state the copy was in."""
+    model, ora, emu = pair("two_agent.xml")
+    reset_warm = emu.warm.copy()                     # what mj_forward leaves at the reset state
+    rng = np.random.default_rng(3)
+    scatter = np.array([[2, 3, 4, 5, 6, 7, 0, 1], [10, 11, 12, 13, 14, 15, 8, 9]], np.int32)
+    for _ in range(40):                              # somewhere into an episode
+        emu.step(actions=rng.uniform(-1, 1, (2, 8)), scatter=scatter, n_agent=2)
+    assert emu.timestep[0] == 40
+    actions = rng.uniform(-1, 1, (2, 8))
+    emu.step(actions=actions, scatter=scatter, n_agent=2, reset_warm=reset_warm)
+    _, _, fresh = pair("two_agent.xml")
+    fresh.step(actions=actions, scatter=scatter, n_agent=2)
+    assert emu.timestep[0] == 1
+    for name in ("qpos", "qvel", "ctrl", "warm", "sens"):
+        assert np.array_equal(getattr(emu, name), getattr(fresh, name)), name
+    ora.ctrl[scatter.reshape(-1)] = actions.reshape(-1)
+    ora.step()
+    assert np.allclose(emu.qpos, ora.qpos, atol=1e-12)

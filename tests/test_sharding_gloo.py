@@ -1,8 +1,13 @@
 """The N>1 path of bench.py on CPU: world_size-2 gloo ranks shard the env batch with no data-path collective; the
 only collectives are the barrier and the max-reduce of the timed region.  The check that matters for the physics:
 a copy's trajectory is a function of its GLOBAL env id only, so the union of the two shards equals the
-single-process batch bit for bit (here the oracle steps the copies; on the GPU box the same property is tested
-through the C-ABI in test_gpu_parity.py::test_full_batch_properties)."""
+single-process batch bit for bit.  The copies are stepped by the product's own arithmetic: the DEVICE step source
+(csrc/mjrl_step.h) in its CPU lane-emulation build (tests/emu/batch.py), with the episode-phase reset masks of bench.py;
+on the GPU box the same property is tested through the C-ABI in test_gpu_parity.py::test_full_batch_properties.
+test_bench_py_typed_plainly_starts_its_own_ranks runs bench.py's own control flow (rank children, rendezvous, barrier,
+max over ranks, rank-0 line) from the bare command."""
+import json
+import subprocess
 import os
 import socket
 import sys
@@ -13,7 +18,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_ENV, STEPS = 6, 40
+N_ENV, STEPS = 4, 12
 
 
 def free_port():
@@ -27,20 +32,18 @@ def shard_run(first_env, n_env):
     import __graft_entry__ as entry
     entry.load_package()
     import bench
-    from mjrl_amd import blob, levels, mjcf
-    from oracle.oracle import OracleEnv
-    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
-    packed = blob.pack(model)
-    acts = bench.action_stream(0, first_env, n_env, STEPS, 2, 8)
-    scatter = np.array([[2, 3, 4, 5, 6, 7, 0, 1], [10, 11, 12, 13, 14, 15, 8, 9]])
-    out = []
-    for e in range(n_env):
-        env = OracleEnv(packed)
-        for t in range(STEPS):
-            env.ctrl[scatter.reshape(-1)] = acts[t, e].reshape(-1)
-            env.step()
-        out.append(env.qpos.copy())
-    return np.stack(out)
+    from mjrl_amd import levels
+    from tests.emu.batch import EmuBatch
+    batch = EmuBatch(levels.level_path("two_agent.xml"), ["sender", "receiver"], n_env, language=True)
+    acts = bench.action_stream(0, first_env, n_env, STEPS, 2, 9, 8)
+    # episodes shortened to 8 steps so that the in-launch resets of bench.py's phase schedule are part of the run
+    phase = (first_env + np.arange(n_env)) % 8
+    obs, rew = np.zeros((n_env, 2, batch.obs_dim)), np.zeros((n_env, 2))
+    term, trunc = np.zeros((n_env, 2), np.uint8), np.zeros((n_env, 2), np.uint8)
+    for t in range(STEPS):
+        batch.set_step_reset_mask((phase == t % 8).astype(np.uint8) if t else None)
+        batch.step_batched(acts[t], obs, rew, term, trunc)
+    return np.concatenate([np.stack([e.qpos for e in batch.envs]), obs.reshape(n_env, -1)], axis=1)
 
 
 def worker(rank, world, port, result):
@@ -72,6 +75,33 @@ def test_two_rank_shards_reproduce_the_single_process_batch():
 def test_action_stream_is_keyed_on_global_env_id():
     sys.path.insert(0, ROOT)
     import bench
-    whole = bench.action_stream(3, 0, 8, 5, 2, 8)
-    assert np.array_equal(bench.action_stream(3, 4, 4, 5, 2, 8), whole[:, 4:])
+    whole = bench.action_stream(3, 0, 8, 5, 2, 8, 8)
+    assert np.array_equal(bench.action_stream(3, 4, 4, 5, 2, 8, 8), whole[:, 4:])
     assert whole.min() >= -1 and whole.max() <= 1 and not np.array_equal(whole[:, 0], whole[:, 1])
+    # the CPU baseline's worker w steps global env id w on the same stream
+    assert np.array_equal(bench.action_stream(3, 5, 1, 5, 2, 8, 8)[:, 0], whole[:, 5])
+    # episode phases: a function of the global id, uniform inside every rank's shard
+    phase = bench.phase_of(np.arange(8192), 4096)
+    assert np.array_equal(phase[:4096], phase[4096:]) and np.array_equal(np.bincount(phase[:4096]), np.full(1024, 4))
+
+
+def test_bench_py_typed_plainly_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself, as fresh children, before
+    it touches a GPU, and relays rank 0's line (here the ranks step the CPU emulation of the device source)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MJRL_BENCH_REHEARSAL"] = "cpu"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--preroll", "3",
+           "--envs-per-gpu", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert "REHEARSAL" in line["data"] and line["config"]["preroll_steps"] == 3
+    # whole-job rate: all ranks' copies over the slowest rank's time
+    assert abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    # a mismatch between --gpus and an inherited WORLD_SIZE is refused loudly
+    env["WORLD_SIZE"] = "3"
+    bad = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
