@@ -166,7 +166,7 @@ class DeviceBatch:
                              "skipFrames": 1, "maxSteps": EPISODE, "environmentDynamics": plugins,
                              "nconmax": args.nconmax, "njmax": args.njmax})
         self.stream = stream
-        self.env._handle.set_stream(stream.cuda_stream)
+        self.env.set_stream(stream.cuda_stream)
         self.env.reset_batched()
         self.obs_dim = self.env._handle.size("obs_dim")
         self.model = self.env._compiled

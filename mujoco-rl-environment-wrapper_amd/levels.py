@@ -3,7 +3,7 @@
 ``/root/reference`` does not travel to the GPU box, so the levels are produced here from their
 parameters.  The arena and ant parameters are those of the reference's shipped data files
 (benchmarking/levels/MultiAgentModel{,2Sensors,3Sensors}.xml, SingleAgentModel.xml,
-Testing/sensor_levels/Model1-4.xml); tests/test_levels.py checks, whenever the reference tree is
+Testing/sensor_levels/Model1-4.xml); tests/test_index_tables.py checks, whenever the reference tree is
 present, that every generated level compiles to exactly the same tables as the file it stands for.
 BASELINE.json names a ``MultiEnvs.xml`` that the reference does not ship (SURVEY.md F3);
 ``two_agent`` is the stand-in.  ``four_agent`` is the synthetic config-4 arena of SURVEY.md 8(d).
@@ -178,7 +178,7 @@ LEVELS = {
     "sensor_framexaxis.xml": lambda: sensor_level("framexaxis"),
 }
 
-# which reference file each generated level stands for (checked by tests/test_levels.py when present)
+# which reference file each generated level stands for (checked by tests/test_index_tables.py::test_generated_level_compiles_like_the_reference_file when the reference tree is present)
 REFERENCE_FILES = {
     "two_agent.xml": "benchmarking/levels/MultiAgentModel.xml",
     "two_agent_2sensors.xml": "benchmarking/levels/MultiAgentModel2Sensors.xml",

@@ -141,6 +141,7 @@ class MuJoCoParent:
         with open(self.xml_path, "r") as fh:
             self.xml_dict = xmldict.parse(fh.read())
         self._handle = None
+        self._stream = None
         self._init_environment()
         self.agents_action_index = {}
         self.agents_observation_index = {}
@@ -155,8 +156,22 @@ class MuJoCoParent:
         if self._handle is not None:
             self._handle.close()
         self._handle = _capi.Handle(self._blob, self.n_env, self.device_id)
+        if self._stream is not None:
+            self._handle.set_stream(self._stream)
         self.model = ModelView(self._compiled)
         self.data = DataView(self)
+
+    def set_stream(self, hip_stream):
+        """Launch on a caller-provided HIP stream (integer handle; None = the library's own).  Kept across the handle
+        re-creations of a multi-level ``reset()``."""
+        self._stream = hip_stream
+        self._handle.set_stream(hip_stream)
+
+    def _after_init_environment(self):
+        """Hook: called when ``reset()`` has switched to another level of an ``xmlPath`` list and re-created the device
+        state (mujoco_parent.py:351-356).  Whatever was configured on the old handle has to be configured again."""
+        if getattr(self, "_table_agents", None):
+            self._upload_tables(self._table_agents)
 
     @classmethod
     def tables_only(cls, xml_path: str, free_joint: bool = False, agent_cameras: bool = False):
@@ -307,8 +322,7 @@ class MuJoCoParent:
             if chosen != self.xml_path:
                 self.xml_path = chosen
                 self._init_environment()
-                if getattr(self, "_table_agents", None):
-                    self._upload_tables(self._table_agents)
+                self._after_init_environment()
         self.cap_overflows(report=True)
         self._handle.reset()
         self._obs_cache = None

@@ -68,7 +68,18 @@ class MuJoCoRL(MuJoCoParent):
         self._action_space = self._create_action_space()
         self._first_action_space = self._action_space[list(self._action_space.keys())[0]]
         self._upload_tables(self.agents)
-        self._setup_fused_program(config_dict.get("fusedPlugins", True))
+        self._fused_allowed = config_dict.get("fusedPlugins", True)
+        self._setup_fused_program(self._fused_allowed)
+
+    def _after_init_environment(self):
+        """A multi-level ``reset()`` re-created the device state for another level: the new handle gets everything the
+        old one had -- tables, truncation horizon, the fused plugin program rebuilt against the new level's body / geom
+        ids (or the query cache for host plugins).  The reference re-creates model and data and keeps its Python plugin
+        loop (mujoco_parent.py:351-356)."""
+        MuJoCoParent._after_init_environment(self)
+        self._handle.set_max_steps(self.max_steps)
+        if hasattr(self, "_fused_allowed"):
+            self._setup_fused_program(self._fused_allowed)
 
     def _setup_fused_program(self, allowed: bool):
         """When every configured plugin belongs to the device vocabulary (dynamics.py) the plugin loop runs inside
@@ -336,6 +347,27 @@ class MuJoCoRL(MuJoCoParent):
         self.timestep = 0 if mask is None else self.timestep
         self._obs_cache = None
 
+    def _check_device_buffers(self, actions, obs, reward, term, trunc):
+        import torch
+        n_agent, obs_dim = len(self.agents), self._handle.size("obs_dim")
+        routed = max((len(self.agents_action_index[a]) for a in self.agents), default=0)
+        need = max(routed, self._first_action_space.shape[0] if self._program is not None else 0)
+        expect = {"actions": (actions, torch.float64, None), "obs": (obs, torch.float64, (self.n_env, n_agent, obs_dim)),
+                  "reward": (reward, torch.float64, (self.n_env, n_agent)), "term": (term, torch.uint8, (self.n_env, n_agent)),
+                  "trunc": (trunc, torch.uint8, (self.n_env, n_agent))}
+        for name, (tensor, dtype, shape) in expect.items():
+            if not isinstance(tensor, torch.Tensor):
+                raise Exception(f"step_batched: {name} must be a torch tensor when the actions are one")
+            if not tensor.is_cuda or tensor.device.index != self.device_id:
+                raise Exception(f"step_batched: {name} lives on {tensor.device}, the env batch on cuda:{self.device_id}")
+            if tensor.dtype != dtype or not tensor.is_contiguous():
+                raise Exception(f"step_batched: {name} must be a contiguous {dtype} tensor")
+            if shape is not None and tuple(tensor.shape) != shape:
+                raise Exception(f"step_batched: {name} has shape {tuple(tensor.shape)}, expected {shape}")
+        if actions.dim() != 3 or tuple(actions.shape[:2]) != (self.n_env, n_agent) or actions.shape[2] < max(need, 1):
+            raise Exception(f"step_batched: actions have shape {tuple(actions.shape)}, expected ({self.n_env}, {n_agent}, "
+                            f">= {max(need, 1)})")
+
     def step_batched(self, actions, obs=None, reward=None, term=None, trunc=None):
         """One step of every copy without per-agent dicts and without host plugins.
 
@@ -355,14 +387,15 @@ class MuJoCoRL(MuJoCoParent):
             self._handle.step_host(actions, self.skip_frames, obs, reward, term, trunc)
         else:
             import torch
-            if not (actions.is_cuda and actions.dtype == torch.float64 and actions.is_contiguous()):
-                raise Exception("step_batched needs a contiguous float64 CUDA tensor")
             dev = actions.device
             obs = torch.empty((self.n_env, n_agent, obs_dim), dtype=torch.float64, device=dev) if obs is None else obs
             reward = torch.empty((self.n_env, n_agent), dtype=torch.float64, device=dev) if reward is None else reward
             term = torch.empty((self.n_env, n_agent), dtype=torch.uint8, device=dev) if term is None else term
             trunc = torch.empty((self.n_env, n_agent), dtype=torch.uint8, device=dev) if trunc is None else trunc
-            self._handle.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            # the kernel gets raw addresses: a tensor of the wrong shape, type, layout or device would be an out-of-bounds
+            # device access, so every buffer is checked here
+            self._check_device_buffers(actions, obs, reward, term, trunc)
+            self.set_stream(torch.cuda.current_stream(dev).cuda_stream)
             self._handle.step_device(actions.data_ptr(), actions.shape[-1], self.skip_frames, obs.data_ptr(),
                                      reward.data_ptr(), term.data_ptr(), trunc.data_ptr())
         self.timestep += 1

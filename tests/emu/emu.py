@@ -8,7 +8,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "libmjrl_emu.so")
+# MJRL_EMU_SANITIZED=1 (set by tests/test_emu_sanitized.py for its child process, which preloads libasan): the
+# ASan + UBSan build of the same source
+_SANITIZED = os.environ.get("MJRL_EMU_SANITIZED") == "1"
+_LIB = os.path.join(_HERE, "_build", "libmjrl_emu_san.so" if _SANITIZED else "libmjrl_emu.so")
 _lib = None
 
 REGION_SHAPES = {
@@ -23,7 +26,7 @@ REGION_SHAPES = {
 def lib():
     global _lib
     if _lib is None:
-        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["sanitized"] if _SANITIZED else []), check=True)
         L = ctypes.CDLL(_LIB)
         L.emu_lds_total.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         L.emu_lds_offset.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]

@@ -1,14 +1,15 @@
 """``__graft_entry__.smoke()``: one small invocation of the hot path on cuda:0, checked against the CPU oracle.
 
-The oracle is used here only as the checker (it is test infrastructure, see oracle/ora_math.h)."""
+The oracle is used here only as the checker (it is test infrastructure, see oracle/ora_math.h); this module lives
+under tests/ -- nothing in the product package imports the oracle."""
 from __future__ import annotations
 
 import numpy as np
 
 
 def run(n_env: int = 4, n_steps: int = 20):
-    from . import levels
-    from .mujoco_rl import MuJoCoRL
+    from mjrl_amd import levels
+    from mjrl_amd.mujoco_rl import MuJoCoRL
     from oracle.oracle import OracleEnv
 
     agents = ["sender", "receiver"]

@@ -1,0 +1,60 @@
+"""The device step source under AddressSanitizer + UndefinedBehaviorSanitizer (CPU lane-emulation build, tests/emu
+`make sanitized`): every LDS access of a copy lands inside the copy's image -- the image is a hand-managed union of
+lifetimes (mjrl_step.h `Lay`), an index past its end is a heap overflow here and a silent neighbour-corrupting access on
+the GPU -- and no signed overflow / bad shift / misaligned access is executed.  GPU sanitizers are not available on the
+pool, so this is where they run.  The sanitized library needs libasan loaded first, hence the child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import __graft_entry__ as entry
+entry.load_package()
+from mjrl_amd import blob, levels, mjcf
+from tests.emu.emu import EmuEnv
+from tests.emu.batch import EmuBatch
+
+rng = np.random.default_rng(0)
+# short trajectories from just above the floor, so that contacts, limit rows, coupling rows and the cap paths are reached
+# within a few dozen steps (a lane switch costs a system call here; the unsanitized suite runs the long trajectories)
+for level, kw, steps in (("two_agent.xml", {}, 80), ("four_agent.xml", {}, 40), ("sensor_touch.xml", dict(nconmax=2, njmax=8), 20),
+                         ("two_agent_3sensors.xml", {}, 40), ("single_agent.xml", dict(lane_map=False), 40)):
+    model = mjcf.compile_mjcf(levels.level_path(level), **kw)
+    env = EmuEnv(model, blob.pack(model))
+    for j in range(model.njnt):
+        if model.jnt_type[j] == mjcf.JNT_FREE and not level.startswith("sensor_"):
+            env.qpos[model.jnt_qposadr[j] + 2] = 0.14
+    env.step(forward_only=True)
+    most = 0
+    for t in range(steps):
+        env.ctrl[:model.nu] = rng.uniform(-1, 1, model.nu)
+        most = max(most, env.step().ncon)
+    assert np.isfinite(env.qpos).all() and most > 0, (level, most)
+# the fused program, the gather / scatter tables and the in-launch reset
+batch = EmuBatch(levels.level_path("two_agent.xml"), ["sender", "receiver"], 2, language=True)
+obs, rew = np.zeros((2, 2, batch.obs_dim)), np.zeros((2, 2))
+term, trunc = np.zeros((2, 2), np.uint8), np.zeros((2, 2), np.uint8)
+for t in range(6):
+    batch.set_step_reset_mask(np.array([t == 3, t == 4], np.uint8))
+    batch.step_batched(rng.uniform(-1, 1, (2, 2, 9)), obs, rew, term, trunc)
+print("sanitized run ok")
+"""
+
+
+def test_device_source_is_clean_under_asan_and_ubsan():
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan is not installed")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-s", "sanitized"], check=True)
+    env = dict(os.environ, LD_PRELOAD=libasan, MJRL_EMU_SANITIZED="1",
+               ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0:exitcode=23",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=24")
+    res = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0 and "sanitized run ok" in res.stdout, (res.stdout + res.stderr)[-4000:]

@@ -1,49 +1,82 @@
-"""Turn the rocprofv3 output of tools/profile_run.sh (gpurun_out/prof_r01) into the committed summaries:
-profiles/r01_kernel_stats.csv (the --stats table of the default bench run) and profiles/r01_hbm_traffic.json (HBM
-bytes per launch of the step kernel from the FETCH_SIZE / WRITE_SIZE passes, corrected with the calibration copy as
-/opt/skills/guides/MI355X_MICROARCH.md prescribes)."""
+"""Turn the rocprofv3 output of tools/profile_run.sh (gpurun_out/prof_r02_<level>) into the committed summaries:
+profiles/r02_kernel_stats_<level>.csv (the --stats table of the exact driver command), profiles/r02_timed_window_<level>.json
+(the step kernel's launches of the TIMED region, taken from the kernel trace: the last `steps` launches -- pre-roll and
+warm-up launches come before them) and profiles/r02_hbm_traffic_<level>.json (HBM bytes per launch from the FETCH_SIZE /
+WRITE_SIZE passes, corrected with the calibration copy as /opt/skills/guides/MI355X_MICROARCH.md prescribes).
+Usage: profile_summary.py [level] [steps]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r01")
+level = sys.argv[1] if len(sys.argv) > 1 else "two_agent"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+src = os.path.join(ROOT, "gpurun_out", f"prof_r02_{level}")
 dst = os.path.join(ROOT, "profiles")
 STEP = "mjrl_step_kernel"          # matches the generic kernel and the specialised one (mjrl_step_kernel_spec)
-ENVS, ALGO_BYTES = 4096, 2524      # bench.py defaults: env copies per launch, algorithmic bytes per env-step
+COMMAND = f"python3 bench.py --gpus 1 --steps {steps} --warmup 5 --level {level}"
+
+bench_line = None
+for line in open(os.path.join(src, "stats.log")):
+    if line.startswith("{"):
+        bench_line = json.loads(line)
+envs = bench_line["config"]["envs_per_gpu"]
+algo = bench_line["roofline"]["algorithmic_bytes_per_env_step"]
 
 
-def counter(run, name, kernel):
+def counter(run, name, kernel, last=None):
     vals = []
     for path in glob.glob(os.path.join(src, run, "*", "*counter_collection.csv")):
-        for row in csv.DictReader(open(path)):
-            if kernel in row["Kernel_Name"] and row["Counter_Name"] == name:
-                vals.append(float(row["Counter_Value"]))
+        rows = [r for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        vals += [float(r["Counter_Value"]) for r in rows]
     if not vals:
         raise SystemExit(f"no {name} samples for {kernel} under {run}")
+    if last:
+        vals = vals[-last:]
     return sum(vals) / len(vals), len(vals)
 
 
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, "r01_kernel_stats.csv"))
-    name = [r["Name"] for r in csv.DictReader(open(stats[0])) if STEP in r["Name"]][0]
-else:
-    name = STEP
-fetch_kb, n = counter("pmc_FETCH_SIZE", "FETCH_SIZE", STEP)
-write_kb, _ = counter("pmc_WRITE_SIZE", "WRITE_SIZE", STEP)
+shutil.copy(stats[0], os.path.join(dst, f"r02_kernel_stats_{level}.csv"))
+row = [r for r in csv.DictReader(open(stats[0])) if STEP in r["Name"]][0]
+trace = glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))[0]
+launches = [r for r in csv.DictReader(open(trace)) if STEP in r["Kernel_Name"]]
+launches.sort(key=lambda r: int(r["Start_Timestamp"]))
+dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in launches]
+timed = dur[-steps:]
+window = {
+    "command": f"rocprofv3 --kernel-trace --stats -- {COMMAND}   [tools/profile_run.sh, tools/profile_summary.py]",
+    "kernel": row["Name"], "launches_total": len(dur), "all_launches_average_ns": sum(dur) / len(dur),
+    "stats_table_average_ns": float(row["AverageNs"]),
+    "timed_launches": steps, "timed_average_ns": sum(timed) / len(timed), "timed_min_ns": min(timed), "timed_max_ns": max(timed),
+    "first_launch_of_the_timed_region_start_ns": int(launches[-steps]["Start_Timestamp"]),
+    "timed_region_span_ns_per_step": (int(launches[-1]["End_Timestamp"]) - int(launches[-steps]["Start_Timestamp"])) / steps,
+    "bench_line": {k: bench_line[k] for k in ("value", "ms_per_step", "steps", "warmup")},
+    "bench_roofline": bench_line["roofline"],
+    "roofline_from_this_profile": {"algorithmic_bytes_per_launch": envs * algo,
+                                   "achieved_GBps": envs * algo / (sum(timed) / len(timed)),
+                                   "frac_of_8000_GBps": envs * algo / (sum(timed) / len(timed)) / 8000.0},
+    "note": "pre-roll (1024) and warm-up launches precede the timed ones in the trace; the first ~170 pre-roll launches run "
+            "with every copy still airborne and are lighter, so the all-launch average sits slightly below the timed one",
+}
+json.dump(window, open(os.path.join(dst, f"r02_timed_window_{level}.json"), "w"), indent=1)
+print(json.dumps(window, indent=1))
+
+fetch_kb, n = counter("pmc_FETCH_SIZE", "FETCH_SIZE", STEP, last=steps)
+write_kb, _ = counter("pmc_WRITE_SIZE", "WRITE_SIZE", STEP, last=steps)
 cal_fetch, _ = counter("calib_FETCH_SIZE", "FETCH_SIZE", "copy")
 cal_write, _ = counter("calib_WRITE_SIZE", "WRITE_SIZE", "copy")
 CAL_BYTES = 512 << 20
 fc, wc = CAL_BYTES / (cal_fetch * 1024), CAL_BYTES / (cal_write * 1024)
 hbm = fetch_kb * 1024 * fc + write_kb * 1024 * wc
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-double-buffer --steps 256   [tools/profile_run.sh, tools/profile_summary.py]",
-    "kernel": name, "envs_per_launch": ENVS, "launches_sampled": n,
+    "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- {COMMAND} --no-cpu-baseline   [tools/profile_run.sh, tools/profile_summary.py]",
+    "kernel": row["Name"], "envs_per_launch": envs, "launches_sampled": n, "which": "the launches of the timed region",
     "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
     "calibration": {"bytes_read": CAL_BYTES, "bytes_written": CAL_BYTES, "FETCH_SIZE_KB": cal_fetch, "WRITE_SIZE_KB": cal_write,
                     "note": "tools/calib_copy.hip: 8 B/lane coalesced copy of 512 MiB each way; FETCH_SIZE reports half of the bytes "
                             "read (as MI355X_MICROARCH.md documents), WRITE_SIZE is exact",
                     "fetch_correction": fc, "write_correction": wc},
-    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": ENVS * ALGO_BYTES,
-    "ratio_to_algorithmic": hbm / (ENVS * ALGO_BYTES),
+    "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": envs * algo,
+    "ratio_to_algorithmic": hbm / (envs * algo),
 }
-json.dump(out, open(os.path.join(dst, "r01_hbm_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"r02_hbm_traffic_{level}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
