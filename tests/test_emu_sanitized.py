@@ -24,8 +24,8 @@ from tests.emu.batch import EmuBatch
 rng = np.random.default_rng(0)
 # short trajectories from just above the floor, so that contacts, limit rows, coupling rows and the cap paths are reached
 # within a few dozen steps (a lane switch costs a system call here; the unsanitized suite runs the long trajectories)
-for level, kw, steps in (("two_agent.xml", {}, 80), ("four_agent.xml", {}, 40), ("sensor_touch.xml", dict(nconmax=2, njmax=8), 20),
-                         ("two_agent_3sensors.xml", {}, 40), ("single_agent.xml", dict(lane_map=False), 40)):
+for level, kw, steps in (("two_agent.xml", {}, 240), ("four_agent.xml", {}, 160), ("sensor_touch.xml", dict(nconmax=2, njmax=8), 60),
+                         ("two_agent_3sensors.xml", {}, 120), ("single_agent.xml", dict(lane_map=False), 120)):
     model = mjcf.compile_mjcf(levels.level_path(level), **kw)
     env = EmuEnv(model, blob.pack(model))
     for j in range(model.njnt):
