@@ -61,11 +61,32 @@ int mjrl_set_max_steps(mjrl_env* env, int max_steps);   /* truncation horizon, m
  *   kind 1 LANGUAGE      i1 action slot, i2 store slot, i3 extra-obs index   (README.md:109-136, 4-tuple form)
  *   kind 2 DIST_REWARD   i1 target kind (0 body xipos, 1 geom xpos), i2 target id, i3 store slot or -1, i4 mode; f0 scale
  *   kind 3 DIST_DONE     i1 target kind, i2 target id; f0 threshold
+ *          (kinds 2, 3) target kind 2 = the agent's current target: i2 tag, i5 store slot holding its index in the tag's list
+ *   kind 4 TARGET        i1 tag, i2 store slot of the current target's index, i3 store slot of the inventory or -1,
+ *                        i4 extra-obs index, i5 store slot of the distance or -1; f0 threshold, f1 reward, f2 seed
+ *                        (Testing/EnvironmentDynamic.py:17-32 target switching; Testing/Pick_Up_Dynamic.py:15-41 with the
+ *                        inventory toggle): obs = the current target's position (3) [+ inventory]
  * n_slot doubles of device data store per (env, agent) (NaN = key absent; cleared by mjrl_reset, mujoco_rl.py:312),
  * n_extra_obs observation values appended after each agent's physical observation (obs_dim grows by it).
  * Must be called after mjrl_set_gather_tables. */
 int mjrl_set_program(mjrl_env* env, int n_op, const int32_t* prog_i, const double* prog_f, int n_slot,
                      int n_extra_obs, const int32_t* agent_body);
+
+/* Object tags of the level's info JSON as device tables (mujoco_rl.py:93-112 __instantiateJson, :355-378 filter_by_tag):
+ * tag t names tag_num[t] objects, listed in filter_by_tag's order in tag_ref (concatenated over the tags); an entry is
+ * kind << 16 | id with kind 0 = body (position xipos), 1 = geom (position xpos) -- the way get_data / distance resolve a
+ * name (mujoco_parent.py:404-416, 440-446).  Ops of the fused program refer to a tag by its index.  Call before
+ * mjrl_set_program. */
+int mjrl_set_tag_tables(mjrl_env* env, int n_tag, const int32_t* tag_num, const int32_t* tag_ref);
+/* Global id of copy 0 (a shard of a larger batch): on-device random choices (OP_TARGET, level variants) are keyed on
+ * the global copy id, so a copy's episode does not depend on how the batch is sharded. */
+int mjrl_set_env_base(mjrl_env* env, int first_env_id);
+/* Per-copy level variants: an xmlPath list whose levels differ in geom colours only (Testing/levels/Model2-10.xml) is
+ * one model plus n_variant colour tables rgba [n_variant][ngeom][4].  Every reset of a copy (mjrl_reset*, in-launch
+ * reset) draws its variant like the reference's random.choice(xml_paths) at reset (mujoco_parent.py:351-356), keyed on
+ * (seed, global copy id, episode count); the cameras render a copy in its variant's colours.  Fields "variant" and
+ * "episode" (int32 [n_env]) are readable and writable through mjrl_get_field / mjrl_set_field.  n_variant 0 turns it off. */
+int mjrl_set_variants(mjrl_env* env, int n_variant, const double* rgba, unsigned long long seed);
 
 /* Sizes a caller needs to allocate buffers: "nq","nv","nu","nbody","ngeom","nsensordata","obs_dim",
  * "n_agent","n_env","lds_doubles","ncon_stride", ...; -1 for an unknown name. */

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
-    "mjrl_reset_device", "mjrl_set_step_reset_mask",
+    "mjrl_reset_device", "mjrl_set_step_reset_mask", "mjrl_set_tag_tables", "mjrl_set_env_base", "mjrl_set_variants",
 ]
 
 _lib = None
@@ -54,6 +54,9 @@ def load():
     L.mjrl_reset.argtypes = [vp, vp, vp]
     L.mjrl_reset_device.argtypes = [vp, vp, vp]
     L.mjrl_set_step_reset_mask.argtypes = [vp, vp]
+    L.mjrl_set_tag_tables.argtypes = [vp, ci, ip, ip]
+    L.mjrl_set_env_base.argtypes = [vp, ci]
+    L.mjrl_set_variants.argtypes = [vp, ci, vp, ctypes.c_ulonglong]
     L.mjrl_step_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.mjrl_step_host.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.mjrl_get_field.argtypes = [vp, ctypes.c_char_p, vp, sz]
@@ -194,6 +197,25 @@ class Handle:
                 raise Exception(f"reset mask has {m.size} entries for {self.n_env} env copies")
         self._check(self._lib.mjrl_reset(self._h, _host_ptr(m), ctypes.c_void_p(d_obs or 0)))
 
+    def set_tag_tables(self, tags):
+        """``tags``: list (one entry per tag, in tag-index order) of lists of (kind, id) pairs, kind 0 body / 1 geom."""
+        counts, cp = _i32([len(t) for t in tags])
+        flat, fp = _i32([(k << 16) | i for t in tags for k, i in t])
+        self._check(self._lib.mjrl_set_tag_tables(self._h, len(tags), cp, fp))
+
+    def set_env_base(self, first_env_id: int):
+        self._check(self._lib.mjrl_set_env_base(self._h, int(first_env_id)))
+
+    def set_variants(self, rgba, seed: int = 0):
+        """``rgba``: ``[n_variant, ngeom, 4]`` colour tables (None / empty: off)."""
+        if rgba is None or len(rgba) == 0:
+            self._check(self._lib.mjrl_set_variants(self._h, 0, None, 0))
+            return
+        arr = np.ascontiguousarray(np.asarray(rgba, dtype=np.float64))
+        if arr.ndim != 3 or arr.shape[1:] != (self.size("ngeom"), 4):
+            raise Exception(f"variant colours have shape {arr.shape}, expected (n_variant, {self.size('ngeom')}, 4)")
+        self._check(self._lib.mjrl_set_variants(self._h, arr.shape[0], _host_ptr(arr), int(seed)))
+
     def reset_device(self, d_mask: int | None, d_obs: int | None = None):
         """Reset the copies flagged in the device byte mask at address ``d_mask`` (None: all); asynchronous."""
         self._check(self._lib.mjrl_reset_device(self._h, ctypes.c_void_p(d_mask or 0), ctypes.c_void_p(d_obs or 0)))
@@ -219,6 +241,8 @@ class Handle:
             out = np.zeros(self.n_env, np.int32)
         elif name == "solver_stats":
             out = np.zeros((self.n_env, 4), np.int32)
+        elif name in ("variant", "episode"):
+            out = np.zeros(self.n_env, np.int32)
         elif name == "store":
             out = np.zeros((self.n_env, max(self.size("n_agent"), 1), max(self.size("n_slot"), 0)), np.float64)
         else:
@@ -227,7 +251,7 @@ class Handle:
         return out
 
     def set_field(self, name: str, value):
-        dtype = np.int32 if name == "timestep" else np.float64
+        dtype = np.int32 if name in ("timestep", "variant", "episode") else np.float64
         arr = np.ascontiguousarray(np.asarray(value, dtype=dtype))
         self._check(self._lib.mjrl_set_field(self._h, name.encode(), _host_ptr(arr), arr.nbytes))
 

@@ -110,6 +110,32 @@ def pack(model) -> bytes:
     return b"".join(out)
 
 
+def section_range(blob: bytes, name: str) -> tuple:
+    """Byte range ``(start, stop)`` of a float64 section inside a packed blob."""
+    n = len(SIZE_FIELDS)
+    sizes = dict(zip(SIZE_FIELDS, struct.unpack_from(f"<{n}i", blob, 8)))
+    off = 8 + 4 * n + 8 * len(OPT_FIELDS)
+    for field, expr in F64_FIELDS:
+        nbytes = 8 * eval(expr, {}, sizes)
+        if field == name:
+            return off, off + nbytes
+        off += nbytes
+    raise KeyError(name)
+
+
+def same_physics(blob_a: bytes, blob_b: bytes) -> bool:
+    """True when two packed models differ at most in geom colours -- and agree on which geoms are transparent, because a
+    rangefinder ignores those.  Such levels (Testing/levels/Model2-10.xml) are one model with colour variants."""
+    if len(blob_a) != len(blob_b):
+        return False
+    lo, hi = section_range(blob_a, "geom_rgba")
+    if blob_a[:lo] != blob_b[:lo] or blob_a[hi:] != blob_b[hi:]:
+        return False
+    ca = np.frombuffer(blob_a[lo:hi], np.float64).reshape(-1, 4)
+    cb = np.frombuffer(blob_b[lo:hi], np.float64).reshape(-1, 4)
+    return bool(np.array_equal(ca[:, 3] == 0, cb[:, 3] == 0))
+
+
 def emit_c_header(prefix: str) -> str:
     """X-macro description of the blob for C; ``prefix`` keeps the product and oracle copies apart."""
     p = prefix.upper()

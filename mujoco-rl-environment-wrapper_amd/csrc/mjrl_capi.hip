@@ -28,9 +28,15 @@ __global__ __launch_bounds__(64) void mjrl_step_kernel(const DevModel* __restric
 __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
                                   int* timestep, const unsigned char* mask, int n_env, double* store, int store_per_env,
                                   const double* warm0, const double* sens0, const int32_t* gather, int n_agent, int obs_dim,
-                                  double* obs) {
+                                  double* obs, int* variant, int* episode, int n_variant, unsigned long long variant_seed,
+                                  int env_base) {
   int env = blockIdx.x;
   if (env >= n_env || (mask && !mask[env])) return;
+  if (variant && threadIdx.x == 0) {         // a new episode: a new level variant (random.choice, mujoco_parent.py:352)
+    const int ep = episode[env] + 1;
+    episode[env] = ep;
+    variant[env] = mj::pick_of(mj::mix64(variant_seed, (unsigned long long)(env_base + env), 0ull, (unsigned long long)ep, 2), n_variant);
+  }
   // an empty data store (mujoco_rl.py:312): every slot "absent"
   for (int i = threadIdx.x; i < store_per_env; i += blockDim.x) store[(size_t)env * store_per_env + i] = __longlong_as_double(0x7FF8000000000000ll);
   for (int i = threadIdx.x; i < m.nq; i += blockDim.x) qpos[(size_t)env * m.nq + i] = m.qpos0[i];
@@ -57,7 +63,8 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
 // geom-type switch is wave-uniform.  Camera convention of the reference's renderer: looks along -z, +x right, +y up,
 // vertical field of view fovy, rows stored bottom-up (glReadPixels order), uint8 RGB.
 __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* qpos, int n_env, int width, int height,
-                                                         int tiles, unsigned char* rgb) {
+                                                         int tiles, unsigned char* rgb, const int* variant,
+                                                         const double* variant_rgba) {
   // grid (n_env, ncam * tiles): a wave renders a group of 8x8 pixel blocks of one camera of one env copy -- with one
   // wave per copy a batch of 512 copies (BASELINE config 5) left three quarters of the chip's wave slots empty.
   // Every wave redoes the copy's kinematics.
@@ -96,7 +103,10 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   auto pixel_ray = [&](real px, real py) {        // px, py in pixel units, pixel centres at +0.5
     return normalized(mul(cm, v3((2.0 * px / width - 1.0) * t * aspect, (2.0 * py / height - 1.0) * t, -1.0)), 0);
   };
-  const bool my_geom = L < m.ngeom && m.geom_rgba[4 * (L < m.ngeom ? L : 0) + 3] != 0;
+  // the copy's colours: its level variant's (mjrl_set_variants), else the model's
+  const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
+  auto rgba_of = [&](int g, int k) { return rgba_tab ? rgba_tab[4 * g + k] : (double)m.geom_rgba[4 * g + k]; };
+  const bool my_geom = L < m.ngeom && rgba_of(L < m.ngeom ? L : 0, 3) != 0;
   const int my_type = my_geom ? m.geom_type[L] : -1;
   const real my_rb = my_geom ? m.geom_rbound[L] : 0.0;
   const V3 my_rel = (my_geom ? ld3(S + l.gpos + 3 * L) : cp) - cp;
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
       V3 n = geom_normal(m.geom_type[hit], ld3(S + l.gpos + 3 * hit), gm, ld3(S + l.gsize + 3 * hit), cp + vec * best);
       real shade = 0.4 + 0.6 * fmax(-dot(n, vec), 0.0);
       for (int k = 0; k < 3; k++)
-        out[k] = (unsigned char)(255.0 * fmin(fmax(m.geom_rgba[4 * hit + k], 0.0), 1.0) * shade + 0.5);
+        out[k] = (unsigned char)(255.0 * fmin(fmax(rgba_of(hit, k), 0.0), 1.0) * shade + 0.5);
     }
     if (inside) { img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2]; }
   }
@@ -177,6 +187,13 @@ struct mjrl_env {
   unsigned char* d_mask = nullptr;
   // reset image: what mj_forward leaves at the reset state (the same for every copy), computed once at create
   double *reset_warm = nullptr, *reset_sens = nullptr;
+  // object tags (mjrl_set_tag_tables), global id of copy 0, per-copy level variants (mjrl_set_variants)
+  int32_t *d_tag_adr = nullptr, *d_tag_num = nullptr, *d_tag_ref = nullptr;
+  int n_tag = 0, env_base = 0;
+  std::vector<int32_t> h_tag_num;
+  int *variant = nullptr, *episode = nullptr, n_variant = 0;
+  unsigned long long variant_seed = 0;
+  double* variant_rgba = nullptr;         // [n_variant][ngeom][4]
   const unsigned char* step_reset_mask = nullptr;   // caller-owned device mask of the in-launch reset (mjrl_set_step_reset_mask)
   // tables
   int n_agent = 0, obs_dim = 0, scatter_mode = 0, max_steps = 1024;
@@ -242,7 +259,7 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  void* ptrs[] = {e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia, e->overflow};
@@ -256,7 +273,8 @@ static int launch_reset(mjrl_env* e, const unsigned char* d_mask, double* d_obs 
   if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "reset: observations requested but no gather table is set");
   hipLaunchKernelGGL(mjrl_reset_kernel, dim3(e->n_env), dim3(64), 0, e->stream, e->dm, e->qpos, e->qvel, e->ctrl, e->warm,
                      e->sens, e->timestep, d_mask, e->n_env, e->store, e->n_agent * e->n_slot, e->reset_warm, e->reset_sens,
-                     e->d_gather, e->n_agent, e->obs_dim, d_obs);
+                     e->d_gather, e->n_agent, e->obs_dim, d_obs, e->variant, e->episode, e->n_variant, e->variant_seed,
+                     e->env_base);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }
@@ -383,13 +401,19 @@ int mjrl_set_program(mjrl_env* e, int n_op, const int32_t* prog_i, const double*
   if (!e->n_agent || e->h_obs_len.empty()) MJRL_FAIL(e, 1, "set_program: set the gather tables first");
   if (e->n_agent > mj::MAX_AGENT) MJRL_FAIL(e, 1, "set_program: at most %d agents", (int)mj::MAX_AGENT);
   if (n_op < 0 || n_slot < 0 || n_extra_obs < 0) MJRL_FAIL(e, 1, "set_program: negative size");
+  auto pf_ok = [](double seed) { return seed >= 0 && seed < 9007199254740992.0 && seed == (double)(unsigned long long)seed; };
   for (int op = 0; op < n_op; op++) {
     const int32_t* pi = prog_i + 8 * op;
     bool ok = true;
     if (pi[0] == mj::OP_LANGUAGE) ok = pi[2] >= 0 && pi[2] < n_slot && pi[3] >= 0 && pi[3] < n_extra_obs && pi[1] >= 0 && e->n_agent >= 2;
-    else if (pi[0] == mj::OP_DIST_REWARD) ok = pi[3] < n_slot && (pi[4] == 0 || pi[3] >= 0) && pi[2] >= 0 && pi[2] < (pi[1] == 0 ? e->hm.nbody : e->hm.ngeom);
-    else if (pi[0] == mj::OP_DIST_DONE) ok = pi[2] >= 0 && pi[2] < (pi[1] == 0 ? e->hm.nbody : e->hm.ngeom);
-    else ok = false;
+    else if (pi[0] == mj::OP_DIST_REWARD || pi[0] == mj::OP_DIST_DONE) {
+      if (pi[1] == 2) ok = pi[2] >= 0 && pi[2] < e->n_tag && e->h_tag_num[pi[2]] > 0 && pi[5] >= 0 && pi[5] < n_slot;
+      else ok = (pi[1] == 0 || pi[1] == 1) && pi[2] >= 0 && pi[2] < (pi[1] == 0 ? e->hm.nbody : e->hm.ngeom);
+      if (pi[0] == mj::OP_DIST_REWARD) ok = ok && pi[3] < n_slot && (pi[4] == 0 || pi[3] >= 0);
+    } else if (pi[0] == mj::OP_TARGET) {
+      ok = pi[1] >= 0 && pi[1] < e->n_tag && e->h_tag_num[pi[1]] > 0 && pi[2] >= 0 && pi[2] < n_slot && pi[3] < n_slot &&
+           pi[5] < n_slot && pi[4] >= 0 && pi[4] + (pi[3] >= 0 ? 4 : 3) <= n_extra_obs && pf_ok(prog_f[4 * op + 2]);
+    } else ok = false;
     if (!ok) MJRL_FAIL(e, 2, "set_program: op %d (kind %d) is malformed", op, pi[0]);
   }
   for (int a = 0; a < e->n_agent; a++)
@@ -471,6 +495,61 @@ int mjrl_set_scatter_tables(mjrl_env* e, int n_agent, int mode, const int32_t* n
   return 0;
 }
 
+int mjrl_set_tag_tables(mjrl_env* e, int n_tag, const int32_t* tag_num, const int32_t* tag_ref) {
+  MJRL_ENTER(e);
+  if (n_tag < 0) MJRL_FAIL(e, 1, "set_tag_tables: negative tag count");
+  std::vector<int32_t> adr(std::max(n_tag, 1), 0), num(std::max(n_tag, 1), 0);
+  int total = 0;
+  for (int t = 0; t < n_tag; t++) {
+    if (tag_num[t] < 0) MJRL_FAIL(e, 2, "set_tag_tables: tag %d has a negative object count", t);
+    adr[t] = total; num[t] = tag_num[t]; total += tag_num[t];
+  }
+  for (int k = 0; k < total; k++) {
+    const int kind = tag_ref[k] >> 16, id = tag_ref[k] & 0xFFFF;
+    if (!((kind == 0 && id < e->hm.nbody) || (kind == 1 && id < e->hm.ngeom)) || tag_ref[k] < 0)
+      MJRL_FAIL(e, 2, "set_tag_tables: entry %d (kind %d, id %d) names no body / geom of the level", k, kind, id);
+  }
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  for (void** p : {(void**)&e->d_tag_adr, (void**)&e->d_tag_num, (void**)&e->d_tag_ref})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  MJRL_HIP(e, hipMalloc(&e->d_tag_adr, sizeof(int32_t) * adr.size()));
+  MJRL_HIP(e, hipMalloc(&e->d_tag_num, sizeof(int32_t) * num.size()));
+  MJRL_HIP(e, hipMalloc(&e->d_tag_ref, sizeof(int32_t) * std::max(total, 1)));
+  MJRL_HIP(e, hipMemcpy(e->d_tag_adr, adr.data(), sizeof(int32_t) * adr.size(), hipMemcpyHostToDevice));
+  MJRL_HIP(e, hipMemcpy(e->d_tag_num, num.data(), sizeof(int32_t) * num.size(), hipMemcpyHostToDevice));
+  if (total) MJRL_HIP(e, hipMemcpy(e->d_tag_ref, tag_ref, sizeof(int32_t) * total, hipMemcpyHostToDevice));
+  e->n_tag = n_tag;
+  e->h_tag_num.assign(num.begin(), num.begin() + n_tag);
+  return 0;
+}
+
+int mjrl_set_env_base(mjrl_env* e, int first_env_id) {
+  MJRL_ENTER(e);
+  if (first_env_id < 0) MJRL_FAIL(e, 1, "set_env_base: negative id");
+  e->env_base = first_env_id;
+  return 0;
+}
+
+int mjrl_set_variants(mjrl_env* e, int n_variant, const double* rgba, unsigned long long seed) {
+  MJRL_ENTER(e);
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  for (void** p : {(void**)&e->variant, (void**)&e->episode, (void**)&e->variant_rgba})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  e->n_variant = 0;
+  if (n_variant <= 0) return 0;
+  if (!rgba) MJRL_FAIL(e, 1, "set_variants: no colour table");
+  const size_t n = (size_t)n_variant * 4 * e->hm.ngeom;
+  MJRL_HIP(e, hipMalloc(&e->variant, sizeof(int) * e->n_env));
+  MJRL_HIP(e, hipMalloc(&e->episode, sizeof(int) * e->n_env));
+  MJRL_HIP(e, hipMalloc(&e->variant_rgba, sizeof(double) * std::max<size_t>(n, 1)));
+  MJRL_HIP(e, hipMemset(e->variant, 0, sizeof(int) * e->n_env));
+  MJRL_HIP(e, hipMemset(e->episode, 0, sizeof(int) * e->n_env));
+  MJRL_HIP(e, hipMemcpy(e->variant_rgba, rgba, sizeof(double) * n, hipMemcpyHostToDevice));
+  e->n_variant = n_variant;
+  e->variant_seed = seed;
+  return 0;
+}
+
 int mjrl_size(const mjrl_env* e, const char* name) {
 #define X(field) if (strcmp(name, #field) == 0) return e->hm.field;
   MJRL_SIZE_FIELDS(X)
@@ -485,6 +564,9 @@ int mjrl_size(const mjrl_env* e, const char* name) {
     return n;
   }
   if (!strcmp(name, "n_slot")) return e->n_slot;
+  if (!strcmp(name, "n_tag")) return e->n_tag;
+  if (!strcmp(name, "n_variant")) return e->n_variant;
+  if (!strcmp(name, "env_base")) return e->env_base;
   if (!strcmp(name, "n_extra_obs")) return e->n_extra;
   if (!strcmp(name, "lds_doubles")) return e->lay.total;
   if (!strcmp(name, "con_stride")) return mj::CON_STRIDE;
@@ -546,6 +628,9 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.forward_only = forward_only;
   a.stamps = d_stamps;
   a.timeline = d_timeline;
+  a.tag_adr = e->d_tag_adr; a.tag_num = e->d_tag_num; a.tag_ref = e->d_tag_ref;
+  a.env_base = e->env_base;
+  a.variant = e->variant; a.episode = e->episode; a.n_variant = e->n_variant; a.variant_seed = e->variant_seed;
   a.reset_mask = forward_only ? nullptr : e->step_reset_mask;
   a.reset_warm = e->reset_warm;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
@@ -562,7 +647,8 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     const bool last = f == launches - 1;
     a.skip_frames = skip_frames > 0 ? 1 : 0;
     a.more_frames = last ? 0 : 1;
-    if (f > 0) { a.scatter = nullptr; a.reset_mask = nullptr; }
+    if (f > 0) a.scatter = nullptr;
+    a.first_frame = f == 0;
     a.dbg = last ? d_dbg : nullptr;
     a.frames = last ? e->frames : nullptr;
     a.lpt_count_in = nullptr; a.lpt_list_in = nullptr; a.lpt_count_out = nullptr; a.lpt_list_out = nullptr;
@@ -711,6 +797,8 @@ static int find_field(mjrl_env* e, const char* name, field_ref* f) {
   else if (!strcmp(name, "sensordata")) *f = {e->sens, sizeof(double) * n * m.nsensordata};
   else if (!strcmp(name, "timestep")) *f = {e->timestep, sizeof(int) * n};
   else if (!strcmp(name, "solver_stats")) *f = {e->stats, sizeof(int) * 4 * n};
+  else if (!strcmp(name, "variant") && e->variant) *f = {e->variant, sizeof(int) * n};
+  else if (!strcmp(name, "episode") && e->episode) *f = {e->episode, sizeof(int) * n};
   else if (!strcmp(name, "store")) *f = {e->store, sizeof(double) * n * e->n_agent * e->n_slot};
   else MJRL_FAIL(e, 4, "unknown field '%s'", name);
   return 0;
@@ -738,7 +826,7 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
   int tiles = (int)((target + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
   tiles = std::max(1, std::min(tiles, std::max(1, nblock / 4)));
   hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), lds_bytes, e->stream, e->dm, e->qpos,
-                     e->n_env, width, height, tiles, d_rgb);
+                     e->n_env, width, height, tiles, d_rgb, e->variant, e->variant_rgba);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }

@@ -146,6 +146,7 @@ struct StepArgs {
   // computed once per model at create), step counter 0, an empty data store -- i.e. `env.reset(); env.step(a)` of the
   // reference's sampling loops (fps_benchmark.py:33-38, mujoco_rl.py:291-331) in one launch.
   const unsigned char* reset_mask;   // [n_env] device bytes, may be null
+  int first_frame;                   // 1 in the first launch of a step (a flagged copy loads the reset image only there)
   // what the copy's last physics frame did: [n_env][4] = contacts, constraint rows, solver sweeps, cap-warning bits
   // (data.ncon, data.nefc, data.solver_iter, data.warning of MjData); may be null
   int* stats;
@@ -159,6 +160,19 @@ struct StepArgs {
   const int32_t* agent_body;   // [n_agent] body id of each agent
   const int32_t* agent_obs_len;   // [n_agent] length of the physical part of the agent's observation
   real* store;                 // [n_env][n_agent][n_slot] device data store; NaN = key not present
+  // Object tags of the level's info JSON (mujoco_rl.py:93-112, 355-378) as tables: tag t names the objects
+  // tag_ref[tag_adr[t] .. + tag_num[t]), in filter_by_tag's order; an entry is kind << 16 | id (kind 0 body -> xipos,
+  // 1 geom -> xpos, as get_data / distance resolve a name, mujoco_parent.py:404-416, 440-446)
+  const int32_t* tag_adr;
+  const int32_t* tag_num;
+  const int32_t* tag_ref;
+  int env_base;                // global id of copy 0 (sharded batches): random choices are keyed on the global copy id
+  // Per-copy level variant (an xmlPath list whose levels differ in colours only, Testing/levels/Model2-10.xml): chosen at
+  // every reset like the reference's random.choice (mujoco_parent.py:352), keyed on (seed, global copy id, episode)
+  int* variant;                // [n_env], may be null
+  int* episode;                // [n_env] resets so far
+  int n_variant;
+  unsigned long long variant_seed;
   // Optional copy of the forward pass's frames for host-side plugin queries (data.body().xipos, data.contact ...,
   // mujoco_parent.py:404-416, 472-475): [n_env][frame_doubles] = xpos | xquat | gpos | gquat | ncon | contact geoms.
   // The reference reads those after mj_step, i.e. as the forward pass inside the step left them (pre-integration).
@@ -191,8 +205,30 @@ enum {
   OP_DIST_REWARD = 2,     // i1 target kind (0 body xipos, 1 geom xpos), i2 target id, i3 store slot (-1 none), i4 mode; f0 scale
                           //   mode 0: reward += scale * (-dist);  mode 1: reward += scale * (previous dist - dist), store = dist
   OP_DIST_DONE = 3,       // i1 target kind, i2 target id; f0 threshold: terminated |= dist < threshold
+                          //   (both DIST ops) target kind 2: the agent's CURRENT TARGET -- i2 = tag, i5 = store slot that holds
+                          //   its index in the tag's list (kept by an OP_TARGET); the op does nothing while that slot is empty
+  OP_TARGET = 4,          // Target-seeking dynamics of Testing/EnvironmentDynamic.py:17-32 and Testing/Pick_Up_Dynamic.py:15-41:
+                          //   i1 tag, i2 store slot of the current target's index, i3 store slot of the inventory (-1: none),
+                          //   i4 extra-obs index, i5 store slot of the distance (-1: none); f0 threshold, f1 reward, f2 seed.
+                          //   empty slot -> choose a target (and inventory = 0); dist(agent, target) < threshold -> toggle the
+                          //   inventory, reward += f1, choose again, store the distance to the new target;
+                          //   obs = xipos / xpos of the current target (3) [+ inventory]
   MAX_AGENT = 8
 };
+
+// The counter-based generator behind every on-device random choice (splitmix64 finaliser over a linear key): a pure
+// function of (seed, global copy id, agent, episode step, salt), so the host plugin of the same name (dynamics.py) and
+// any shard of the batch draw the same numbers.
+__host__ __device__ inline unsigned long long mix64(unsigned long long seed, unsigned long long env, unsigned long long agent,
+                                                    unsigned long long step, unsigned long long salt) {
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + env * 0xBF58476D1CE4E5B9ull + agent * 0x94D049BB133111EBull +
+                         step * 0xD6E8FEB86659FD93ull + salt * 0xA0761D6478BD642Full;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+__host__ __device__ inline int pick_of(unsigned long long z, int n) { return n > 0 ? (int)((z >> 33) % (unsigned long long)n) : 0; }
 
 enum { ST_LOAD = 0, ST_KIN, ST_COM, ST_CRB, ST_FACTOR, ST_GEOM, ST_COLLIDE, ST_VEL, ST_SMOOTH, ST_ROWS, ST_PROJECT, ST_PGS,
        ST_SENSORS, ST_EULER, ST_STORE, ST_PGS_WARM, ST_PGS_LISTS, ST_PGS_SWEEPS, ST_ROWS_LIMITS, ST_ROWS_ADDR, ST_PGS_SETUP,
@@ -2017,7 +2053,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
 #define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
   // state in: the copy's rows, or the reset image when the copy is flagged for an in-launch reset
   const bool resetting = a.reset_mask != nullptr && !a.forward_only && wv::first_int((int)a.reset_mask[env]) != 0;
-  if (resetting) {
+  if (resetting && a.first_frame) {
     MJ_FOR(i, m.nq) S[l.qpos + i] = m.qpos0[i];
     MJ_FOR(i, m.nv) { S[l.qvel + i] = 0; S[l.warm + i] = a.reset_warm[i]; }
     MJ_FOR(i, m.nu) S[l.ctrl + i] = 0;
@@ -2206,6 +2242,15 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     const int32_t* agent_body = ops_staged ? (const int32_t*)(TI + 2 * t_ag + a.n_agent) : a.agent_body;
     if (resetting && !ops_staged && store)      // (the staged copy of the row was cleared when it was fetched)
       for (int k = 0; k < a.n_agent * a.n_slot; k++) store[k] = __builtin_nan("");
+    // position a target reference stands for: body -> xipos, geom -> xpos (frames of this step's forward pass)
+    auto ref_pos = [&](int ref) {
+      const int kind = ref >> 16, id = ref & 0xFFFF;
+      V3 t;
+      if (kind == 0) t = ld3(S + l.xpos + 3 * id) + rot(ldq(S + l.xquat + 4 * id), ld3(m.body_ipos + 3 * id));
+      else { Quat tq; geom_frame(m, l, S, id, t, tq); }
+      return t;
+    };
+    const unsigned long long genv = (unsigned long long)(a.env_base + env);
     for (int op = 0; op < a.n_op; op++) {
       const int32_t* pi = prog_i + 8 * op;
       const real* pf = prog_f + 4 * op;
@@ -2217,12 +2262,45 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
           real heard = other < a.n_agent ? store[other * a.n_slot + pi[2]] : 0.0;
           if (heard != heard) heard = 0.0;
           if (a.obs) a.obs[((size_t)env * a.n_agent + ag) * a.obs_dim + obs_len[ag] + pi[3]] = heard;
+        } else if (pi[0] == OP_TARGET) {
+          const int body = agent_body[ag];
+          const int adr = a.tag_adr[pi[1]], num = a.tag_num[pi[1]];
+          const unsigned long long seed = (unsigned long long)pf[2];
+          real* cur_slot = store + ag * a.n_slot + pi[2];
+          real* inv_slot = pi[3] >= 0 ? store + ag * a.n_slot + pi[3] : nullptr;
+          if (*cur_slot != *cur_slot) {            // first call of the episode: choose a target, empty the inventory
+            *cur_slot = (real)pick_of(mix64(seed, genv, (unsigned long long)ag, (unsigned long long)ts, 0), num);
+            if (inv_slot) *inv_slot = 0.0;
+          }
+          int cur = (int)*cur_slot;
+          V3 p = ld3(S + l.xpos + 3 * body) + rot(ldq(S + l.xquat + 4 * body), ld3(m.body_ipos + 3 * body));
+          V3 t = ref_pos(a.tag_ref[adr + cur]);
+          V3 d3 = p - t;
+          real dist = sqrt(dot(d3, d3));
+          if (dist < pf[0]) {
+            if (inv_slot) *inv_slot = 1.0 - *inv_slot;
+            rew[ag] += pf[1];
+            cur = pick_of(mix64(seed, genv, (unsigned long long)ag, (unsigned long long)ts, 1), num);
+            *cur_slot = (real)cur;
+            t = ref_pos(a.tag_ref[adr + cur]);
+            if (pi[5] >= 0) { V3 e3 = p - t; store[ag * a.n_slot + pi[5]] = sqrt(dot(e3, e3)); }
+          }
+          if (a.obs) {
+            real* o = a.obs + ((size_t)env * a.n_agent + ag) * a.obs_dim + obs_len[ag] + pi[4];
+            o[0] = t.x; o[1] = t.y; o[2] = t.z;
+            if (inv_slot) o[3] = *inv_slot;
+          }
         } else {
           int body = agent_body[ag];
           V3 p = ld3(S + l.xpos + 3 * body) + rot(ldq(S + l.xquat + 4 * body), ld3(m.body_ipos + 3 * body));
           V3 t;
-          if (pi[1] == 0) t = ld3(S + l.xpos + 3 * pi[2]) + rot(ldq(S + l.xquat + 4 * pi[2]), ld3(m.body_ipos + 3 * pi[2]));
-          else { Quat tq; geom_frame(m, l, S, pi[2], t, tq); }
+          if (pi[1] == 2) {
+            const real held = store[ag * a.n_slot + pi[5]];
+            if (held != held) continue;            // no current target yet
+            t = ref_pos(a.tag_ref[a.tag_adr[pi[2]] + (int)held]);
+          } else {
+            t = ref_pos((pi[1] << 16) | pi[2]);
+          }
           V3 d3 = p - t;
           real dist = sqrt(dot(d3, d3));
           if (pi[0] == OP_DIST_REWARD) {
@@ -2247,6 +2325,11 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   wv::sync();
   if (ops_staged && a.store && L < n_store_row) a.store[(size_t)env * n_store_row + L] = S[l.bias + t_store + L];
   if (L == 0) a.timestep[env] = ts + 1;
+  if (resetting && a.variant && L == 0) {          // a new episode: a new level variant, as mjrl_reset chooses it
+    const int ep = a.episode[env] + 1;
+    a.episode[env] = ep;
+    a.variant[env] = pick_of(mix64(a.variant_seed, (unsigned long long)(a.env_base + env), 0ull, (unsigned long long)ep, 2), a.n_variant);
+  }
   MJ_STAMP(ST_TAIL)
   if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
   MJ_TIMELINE

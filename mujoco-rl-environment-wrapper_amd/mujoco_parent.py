@@ -117,7 +117,7 @@ class DataView:
 class MuJoCoParent:
     def __init__(self, xml_paths, export_path: str = None, render: bool = False, free_joint: bool = False,
                  agent_cameras: bool = False, sensor_resolution=(64, 64), n_env: int = 1, device_id: int = 0,
-                 nconmax: int = None, njmax: int = None):
+                 nconmax: int = None, njmax: int = None, first_env_id: int = 0, variant_seed: int = 0):
         self.xml_paths = xml_paths
         self.export_path = export_path
         self.render = render
@@ -127,6 +127,8 @@ class MuJoCoParent:
         self.n_env = int(n_env)
         self.device_id = int(device_id)
         self._nconmax, self._njmax = nconmax, njmax
+        self.first_env_id, self._variant_seed = int(first_env_id), int(variant_seed)
+        self._variants = None
         self.rgb_sensors = {}
         self.frame = 0
         self._skip_frames_hint = 1
@@ -142,6 +144,7 @@ class MuJoCoParent:
             self.xml_dict = xmldict.parse(fh.read())
         self._handle = None
         self._stream = None
+        self._detect_variants()
         self._init_environment()
         self.agents_action_index = {}
         self.agents_observation_index = {}
@@ -149,6 +152,22 @@ class MuJoCoParent:
         self._obs_cache = None
 
     # ------------------------------------------------------------------ model / device state
+    def _detect_variants(self):
+        """An ``xmlPath`` list whose levels are one model in different colours (Testing/levels/Model2-10.xml differ in the
+        boxes' rgba only) does not need a new model per reset (mujoco_parent.py:351-356): the batch keeps ONE model and
+        every copy draws its own variant at each of its resets (mjrl_set_variants).  Levels that differ in structure keep
+        the reference's behaviour: reset() switches the whole batch to one randomly chosen level."""
+        if not isinstance(self.xml_paths, list) or len(set(self.xml_paths)) < 2:
+            return
+        paths = list(dict.fromkeys(self.xml_paths))
+        models = [mjcf.compile_mjcf(p, nconmax=self._nconmax, njmax=self._njmax) for p in paths]
+        blobs = [blob.pack(m) for m in models]
+        if all(blob.same_physics(blobs[0], b) for b in blobs[1:]):
+            self._variants = {"paths": paths, "rgba": np.stack([np.asarray(m.geom_rgba, np.float64).reshape(-1, 4) for m in models])}
+            self.xml_path = paths[0]
+            with open(self.xml_path, "r") as fh:
+                self.xml_dict = xmldict.parse(fh.read())
+
     def _init_environment(self):
         """Counterpart of mujoco_parent.py:119-137: compile the level and create the device copies."""
         self._compiled = mjcf.compile_mjcf(self.xml_path, nconmax=self._nconmax, njmax=self._njmax)
@@ -158,6 +177,10 @@ class MuJoCoParent:
         self._handle = _capi.Handle(self._blob, self.n_env, self.device_id)
         if self._stream is not None:
             self._handle.set_stream(self._stream)
+        if self.first_env_id:
+            self._handle.set_env_base(self.first_env_id)
+        if self._variants is not None:
+            self._handle.set_variants(self._variants["rgba"], self._variant_seed)
         self.model = ModelView(self._compiled)
         self.data = DataView(self)
 
@@ -317,7 +340,7 @@ class MuJoCoParent:
 
     def reset(self):
         """mj_resetData + mj_forward for every copy (mujoco_parent.py:341-358)."""
-        if isinstance(self.xml_paths, list):
+        if isinstance(self.xml_paths, list) and self._variants is None:
             chosen = random.choice(self.xml_paths)
             if chosen != self.xml_path:
                 self.xml_path = chosen
@@ -325,8 +348,17 @@ class MuJoCoParent:
                 self._after_init_environment()
         self.cap_overflows(report=True)
         self._handle.reset()
+        if self._variants is not None:
+            # every copy drew its own level variant; `xml_path` names copy 0's (with one copy: the reference's attribute)
+            self.xml_path = self._variants["paths"][int(self.variant_ids()[0])]
         self._obs_cache = None
         return self.get_sensor_data()
+
+    def variant_ids(self) -> np.ndarray:
+        """Index (into the de-duplicated ``xmlPath`` list) of the level variant every copy currently runs."""
+        if self._variants is None:
+            return np.zeros(self.n_env, np.int32)
+        return self._handle.get_field("variant")
 
     def cap_overflows(self, report: bool = False) -> tuple:
         """(frames cut at nconmax, frames cut at njmax) over all copies since the last call -- MuJoCo's

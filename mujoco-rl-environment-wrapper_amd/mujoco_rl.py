@@ -3,7 +3,9 @@
 Same ``config_dict`` keys and defaults (mujoco_rl.py:51-64), same ``reset()`` / ``step()`` return structure,
 same environmentDynamics / rewardFunctions / doneFunctions plugin contract (4-tuple ``dynamic``), same call
 order (dynamic-major, agent-minor; rewards after all dynamics; truncation before the counter moves).
-Extra keys: ``numEnvs`` (default 1), ``deviceId`` (default 0), ``nconmax`` / ``njmax``.
+Extra keys: ``numEnvs`` (default 1), ``deviceId`` (default 0), ``nconmax`` / ``njmax``, ``firstEnvId`` (global id of
+copy 0 when the batch is a shard; on-device random choices are keyed on the global copy id), ``variantSeed``,
+``fusedPlugins`` (default True).
 
 With ``numEnvs == 1`` every value has the reference's shape, so the loops of
 benchmarking/different_env_configs/fps_benchmark.py:33-41 run unchanged.  With more copies each per-agent
@@ -54,7 +56,8 @@ class MuJoCoRL(MuJoCoParent):
                               free_joint=self.free_joint, agent_cameras=self.agent_cameras,
                               sensor_resolution=sensor_resolution, n_env=config_dict.get("numEnvs", 1),
                               device_id=config_dict.get("deviceId", 0), nconmax=config_dict.get("nconmax"),
-                              njmax=config_dict.get("njmax"))
+                              njmax=config_dict.get("njmax"), first_env_id=config_dict.get("firstEnvId", 0),
+                              variant_seed=config_dict.get("variantSeed", 0))
         self._handle.set_max_steps(self.max_steps)
         self._load_info_json()
 
@@ -94,6 +97,8 @@ class MuJoCoRL(MuJoCoParent):
         for agent in self.agents:
             if agent not in names:
                 raise Exception(f"agent {agent} is not a body of the level")
+        if self._program.tags:
+            self._handle.set_tag_tables([self.tag_refs(tag) for tag in self._program.tags])
         pi, pf = self._program.arrays()
         self._handle.set_program(pi, pf, len(self._program.slots), self._program.n_extra,
                                  [names.index(agent) for agent in self.agents])
@@ -318,17 +323,35 @@ class MuJoCoRL(MuJoCoParent):
     def observation_space(self, agent: str):
         return self._observation_space[agent]
 
-    def filter_by_tag(self, tag: str) -> list:
-        """mujoco_rl.py:355-378."""
+    def tagged_names(self, tag: str) -> list:
+        """Names of the objects that carry ``tag``, in the order ``filter_by_tag`` visits them: the environment's objects,
+        then every area's (mujoco_rl.py:364-377)."""
         found = []
         groups = [self.info_json["environment"]["objects"]]
-        groups += [self.info_json["areas"][area]["objects"] for area in self.info_json.get("areas", {})]
+        groups += [self.info_json["areas"][area]["objects"] for area in self.info_json["areas"]]
         for objects in groups:
-            for name, record in objects.items():
-                tags = record.get("tags") if isinstance(record, dict) else None
-                if tags is not None and tag in tags:
-                    found.append(self.get_data(name))
+            for name in objects:
+                if "tags" in objects[name].keys() and objects[name]["tags"] is not None and tag in objects[name]["tags"]:
+                    found.append(name)
         return found
+
+    def filter_by_tag(self, tag: str) -> list:
+        """mujoco_rl.py:355-378."""
+        return [self.get_data(name) for name in self.tagged_names(tag)]
+
+    def tag_refs(self, tag: str) -> list:
+        """The device form of a tag (mjrl_set_tag_tables): ``(kind, id)`` per tagged object, kind 0 = body (its position is
+        xipos), 1 = geom (xpos) -- resolved like ``get_data`` resolves a name (body first, mujoco_parent.py:404-426)."""
+        names = self._compiled.names
+        refs = []
+        for name in self.tagged_names(tag):
+            if name in names["body"]:
+                refs.append((0, names["body"].index(name)))
+            elif name in names["geom"]:
+                refs.append((1, names["geom"].index(name)))
+            else:
+                raise KeyError(f"Invalid name '{name}'")
+        return refs
 
     def get_data(self, name: str) -> dict:
         """mujoco_rl.py:380-395: physics record merged with the info-JSON attributes."""

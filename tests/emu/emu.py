@@ -36,6 +36,8 @@ def lib():
                                ctypes.c_int, ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int, P, P, P, P, P, P]
         L.emu_set_step_reset.argtypes = [ctypes.c_int, P]
         L.emu_set_step_reset.restype = None
+        L.emu_set_tags.argtypes = [P, P, P, ctypes.c_int]
+        L.emu_set_tags.restype = None
         _lib = L
     return _lib
 
@@ -147,6 +149,13 @@ class EmuEnv:
         """``program``: dict(prog_i, prog_f, n_slot, agent_body, agent_obs_len, store, reward, term, trunc) for the
         fused plugin ops.  ``reset_warm``: the first frame starts from the reset image (in-launch reset) with this warm
         start."""
+        tags = None if program is None else program.get("tags")
+        if tags is not None:                 # list of lists of (kind, id); program["env_base"]: global id of this copy
+            num = np.array([len(t) for t in tags] or [0], np.int32)
+            adr = np.concatenate([[0], np.cumsum(num)[:-1]]).astype(np.int32)
+            ref = np.array([(k << 16) | i for t in tags for k, i in t] or [0], np.int32)
+            self._tags = (adr, num, ref)
+            lib().emu_set_tags(_p(adr), _p(num), _p(ref), int(program.get("env_base", 0)))
         if reset_warm is not None:
             self._reset_warm = np.ascontiguousarray(reset_warm, dtype=np.float64)
             lib().emu_set_step_reset(1, _p(self._reset_warm))

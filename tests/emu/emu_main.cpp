@@ -142,6 +142,13 @@ static unsigned char g_reset_flag = 0;
 static const double* g_reset_warm = nullptr;
 void emu_set_step_reset(int flag, const double* reset_warm) { g_reset_flag = flag ? 1 : 0; g_reset_warm = reset_warm; }
 
+// object-tag tables and the global id of the copy for the following emu_step calls (mjrl_set_tag_tables / mjrl_set_env_base)
+static const int32_t *g_tag_adr = nullptr, *g_tag_num = nullptr, *g_tag_ref = nullptr;
+static int g_env_base = 0;
+void emu_set_tags(const int32_t* adr, const int32_t* num, const int32_t* ref, int env_base) {
+  g_tag_adr = adr; g_tag_num = num; g_tag_ref = ref; g_env_base = env_base;
+}
+
 // one env copy, `nsteps` step() calls with the same actions; state arrays are updated in place
 int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
              int* timestep, const double* actions, const int32_t* scatter, int n_agent, int act_dim, int scatter_mode,
@@ -163,6 +170,7 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.reward = reward; a.term = term; a.trunc = trunc;
   a.prog_i = prog_i; a.prog_f = prog_f; a.n_op = forward_only ? 0 : n_op; a.n_slot = n_slot;
   a.agent_body = agent_body; a.agent_obs_len = agent_obs_len; a.store = store;
+  a.tag_adr = g_tag_adr; a.tag_num = g_tag_num; a.tag_ref = g_tag_ref; a.env_base = g_env_base;
   a.max_steps = max_steps; a.n_env = 1;
   a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;
   emu::cur_env = 0;
@@ -174,8 +182,9 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
       b.skip_frames = skip_frames > 0 ? 1 : 0;
       b.more_frames = f < launches - 1;
       if (f > 0) b.scatter = nullptr;
+      b.first_frame = f == 0;
       if (b.more_frames) { b.dbg = nullptr; b.frames = nullptr; }
-      if (s == 0 && f == 0 && g_reset_flag) { b.reset_mask = &g_reset_flag; b.reset_warm = g_reset_warm; }
+      if (s == 0 && g_reset_flag) { b.reset_mask = &g_reset_flag; b.reset_warm = g_reset_warm; }
       if (emu::run_wave(m, b, lds.data())) return 2;
     }
   }

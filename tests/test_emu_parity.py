@@ -450,3 +450,73 @@ def test_in_launch_reset_equals_reset_then_step():
     ora.ctrl[scatter.reshape(-1)] = actions.reshape(-1)
     ora.step()
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-12)
+
+
+def test_target_and_pick_up_ops_follow_their_reference_dynamics():
+    """OP_TARGET with an inventory (Testing/Pick_Up_Dynamic.py:15-41) plus a distance-decrease reward and a done on the
+    agent's CURRENT target (target kind 2; Testing/SingleAgentTest.py:41-48), against a transcription of those plugins
+    with the random choices drawn from the Python mix64 (dynamics.py) -- so this also pins the device generator."""
+    from mjrl_amd import dynamics
+    model, ora, emu = pair("two_agent.xml")
+    names = model.names["body"]
+    bodies = np.array([names.index("sender"), names.index("receiver")], np.int32)
+    geoms = model.names["geom"]
+    tags = [[(0, names.index("reference")), (0, names.index("choice_1")), (1, geoms.index("border5_geom")), (0, names.index("choice_2"))]]
+    scatter = np.array([[2, 3, 4, 5, 6, 7, 0, 1], [10, 11, 12, 13, 14, 15, 8, 9]], np.int32)
+    gather = np.full((2, 63), -1, np.int32)
+    for a in range(2):
+        gather[a, 0] = a
+        gather[a, 1:31] = (1 << 24) | np.arange(30)
+        gather[a, 31:59] = (2 << 24) | np.arange(28)
+        gather[a, 59:63] = -2
+    seed, thr, env_base = 12345, 9.0, 4096 + 17
+    # slots: 0 current_target, 1 inventory, 2 distance
+    prog_i = np.array([[4, 0, 0, 1, 0, 2, 0, 0], [2, 2, 0, 2, 1, 0, 0, 0], [3, 2, 0, 0, 0, 0, 0, 0]], np.int32)
+    prog_f = np.array([[thr, 1.0, seed, 0], [2.0, 0, 0, 0], [2.5, 0, 0, 0]], np.float64)
+    program = dict(prog_i=prog_i, prog_f=prog_f, n_slot=3, agent_body=bodies, agent_obs_len=np.array([59, 59], np.int32),
+                   store=np.full((2, 3), np.nan), reward=np.zeros(2), term=np.zeros(2, np.uint8), trunc=np.zeros(2, np.uint8),
+                   tags=tags, env_base=env_base)
+    obs = np.zeros((2, 63))
+    rng = np.random.default_rng(4)
+    store = [dict(), dict()]
+
+    def place(ref):
+        kind, ident = ref
+        return ora.xipos[ident] if kind == 0 else ora.geom_xpos[ident]
+
+    toggles = 0
+    for step in range(30):
+        actions = rng.uniform(-1, 1, (2, 8))
+        emu.step(actions=actions, scatter=scatter, n_agent=2, gather=gather, obs=obs, program=program)
+        for a in range(2):
+            ora.ctrl[scatter[a]] = actions[a]
+        ora.step()
+        rewards, dones = [0.0, 0.0], [False, False]
+        for a in range(2):                                   # the dynamic, agent-minor
+            st = store[a]
+            if "current_target" not in st:
+                st["current_target"] = int(dynamics.pick_of(dynamics.mix64(seed, env_base, a, step, 0), 4))
+                st["inventory"] = 0.0
+            here = ora.xipos[bodies[a]]
+            dist = np.linalg.norm(here - place(tags[0][st["current_target"]]))
+            if dist < thr:
+                st["inventory"] = 1.0 - st["inventory"]
+                rewards[a] += 1.0
+                toggles += 1
+                st["current_target"] = int(dynamics.pick_of(dynamics.mix64(seed, env_base, a, step, 1), 4))
+                st["distance"] = np.linalg.norm(here - place(tags[0][st["current_target"]]))
+            expect = np.concatenate([place(tags[0][st["current_target"]]), [st["inventory"]]])
+            assert np.allclose(obs[a, 59:63], expect, atol=1e-12), (step, a)
+        for a in range(2):                                   # the reward function
+            dist = np.linalg.norm(ora.xipos[bodies[a]] - place(tags[0][store[a]["current_target"]]))
+            if "distance" in store[a]:
+                rewards[a] += 2.0 * (store[a]["distance"] - dist)
+            store[a]["distance"] = dist
+        for a in range(2):                                   # the done function
+            dones[a] = np.linalg.norm(ora.xipos[bodies[a]] - place(tags[0][store[a]["current_target"]])) < 2.5
+        assert np.allclose(program["reward"], rewards, atol=1e-10), step
+        assert list(program["term"].astype(bool)) == dones
+        for a in range(2):
+            assert program["store"][a, 0] == store[a]["current_target"] and program["store"][a, 1] == store[a]["inventory"]
+            assert np.isclose(program["store"][a, 2], store[a]["distance"], atol=1e-12)
+    assert 4 <= toggles < 60

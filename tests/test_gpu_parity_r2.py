@@ -370,3 +370,139 @@ def test_step_batched_rejects_buffers_that_would_fault():
     with pytest.raises(Exception, match="lives on"):
         env.step_batched(good, reward=torch.zeros((8, 2), dtype=torch.float64))
     env.close()
+
+
+# --------------------------------------------------------------------------- info-JSON tags, target / pick-up ops
+INFO_JSON = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "two_agent_info.json")
+
+
+def test_tag_ops_fused_equal_the_host_plugin_loop():
+    """the info JSON's tags as device tables.  PickUpDynamic (Testing/Pick_Up_Dynamic.py:15-41) with a
+    distance-decrease reward and a done on the agent's current target, once as ops of the step kernel and once through
+    the host plugin loop on the same GPU physics; the host side goes through filter_by_tag / get_data."""
+    from mjrl_amd.dynamics import PickUpDynamic, TargetDistanceReward, TargetReached
+
+    class Pick(PickUpDynamic):
+        threshold, seed = 5.0, 99
+
+    def make_env(fused):
+        return MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "infoJson": INFO_JSON, "agents": AGENTS, "numEnvs": 6,
+                         "environmentDynamics": [Pick], "fusedPlugins": fused, "firstEnvId": 4096,
+                         "rewardFunctions": [TargetDistanceReward(current_target_of="target", mode="delta", scale=3.0)],
+                         "doneFunctions": [TargetReached(current_target_of="target", threshold=3.0)]})
+    fused, host = make_env(True), make_env(False)
+    assert fused._program is not None and fused._program.tags == ["target"] and host._program is None
+    assert fused._handle.size("n_tag") == 1 and fused._handle.size("env_base") == 4096
+    assert fused.observation_space("sender").shape == (59 + 4,) and fused.action_space("sender").shape == (8,)
+    found = host.filter_by_tag("target")
+    assert [d["name"] for d in found] == ["reference", "choice_1", "choice_2"] and found[0]["class"] == "Cube"
+    np.random.seed(0); fused.reset()
+    np.random.seed(0); host.reset()
+    rng = np.random.default_rng(3)
+    toggled = 0
+    for step in range(40):
+        action = {a: rng.uniform(-1, 1, (6, 8)) for a in AGENTS}
+        f, h = fused.step(action), host.step(action)
+        for a in AGENTS:
+            assert np.allclose(f[0][a], h[0][a], atol=1e-12), (step, a)
+            assert np.array_equal(f[0][a][:, 62], h[0][a][:, 62])                 # inventory
+            assert np.allclose(f[1][a], h[1][a], atol=1e-10)
+            assert np.array_equal(f[2][a], h[2][a])
+            toggled += int((f[1][a] >= 1.0 - 1e-9).sum())
+        assert np.array_equal(f[2]["__all__"], h[2]["__all__"])
+    assert toggled > 0
+    store = fused.device_store
+    for a in AGENTS:
+        assert np.array_equal(store[a]["current_target"], np.asarray(host.data_store[a]["current_target"], np.float64))
+        assert np.array_equal(store[a]["inventory"], host.data_store[a]["inventory"])
+    # copies draw different targets (keyed on the global copy id)
+    assert len(set(store["receiver"]["current_target"].tolist()) | set(store["sender"]["current_target"].tolist())) > 1
+    fused.close(); host.close()
+
+
+# --------------------------------------------------------------------------- per-copy level variants
+def test_per_copy_level_variants(tmp_path):
+    """an xmlPath list of levels that differ in colours only (Testing/levels/Model2-10.xml) is one model
+    with per-copy colour variants drawn at every reset of a copy (mujoco_parent.py:351-356).  A copy's physics does not
+    depend on its variant; its camera pixels do."""
+    from mjrl_amd.dynamics import mix64, pick_of
+    text = open(levels.level_path("two_agent.xml")).read()
+    paths = []
+    for k, colour in enumerate(("0 .9 0 1", "0.9 0 0 1", "0 0 0.9 1")):
+        p = tmp_path / f"Model{k + 2}.xml"
+        p.write_text(text.replace('rgba="0 .9 0 1"', f'rgba="{colour}"'))
+        paths.append(str(p))
+    n_env = 48
+    env = MuJoCoRL({"xmlPath": paths, "agents": AGENTS, "numEnvs": n_env, "agentCameras": True, "variantSeed": 5})
+    assert env._variants is not None and env._handle.size("n_variant") == 3
+    handle = env._handle
+    env.reset()
+    assert env._handle is handle                                    # no model switch, no new device state
+    ids = env.variant_ids()
+    assert np.array_equal(ids, pick_of(mix64(5, np.arange(n_env), 0, 1, 2), 3)) and set(ids) == {0, 1, 2}
+    assert env.xml_path == paths[ids[0]]
+    act = np.random.default_rng(0).uniform(-1, 1, (30, 2, 8))
+    for t in range(30):
+        env.step({a: np.tile(act[t, k], (n_env, 1)) for k, a in enumerate(AGENTS)})
+    qpos = env._handle.get_field("qpos")
+    assert np.array_equal(qpos, np.tile(qpos[0], (n_env, 1)))       # the physics does not know the variant
+    images = env._handle.render(64, 64)
+    by_variant = {v: images[np.flatnonzero(ids == v)[0]] for v in (0, 1, 2)}
+    for e in range(n_env):
+        assert np.array_equal(images[e], by_variant[ids[e]])        # same state + same variant -> same bytes
+    assert not np.array_equal(by_variant[0], by_variant[1]) and not np.array_equal(by_variant[1], by_variant[2])
+    # a masked reset starts a new episode for the flagged copies only: they draw again
+    mask = np.zeros(n_env, np.uint8)
+    mask[::3] = 1
+    env._handle.reset(mask)
+    ids2 = env.variant_ids()
+    assert np.array_equal(ids2[mask == 0], ids[mask == 0])
+    expect = pick_of(mix64(5, np.arange(n_env), 0, 2, 2), 3)
+    assert np.array_equal(ids2[mask == 1], expect[mask == 1])
+    assert np.array_equal(env._handle.get_field("episode"), 1 + mask.astype(np.int32))
+    # the in-launch reset draws the same way
+    import torch
+    m = torch.from_numpy(mask).cuda()
+    env._handle.set_step_reset_mask(m.data_ptr())
+    env.step_batched(torch.zeros((n_env, 2, 8), dtype=torch.float64, device="cuda"))
+    env._handle.set_step_reset_mask(None)
+    torch.cuda.synchronize()
+    expect3 = pick_of(mix64(5, np.arange(n_env), 0, 3, 2), 3)
+    ids3 = env.variant_ids()
+    assert np.array_equal(ids3[mask == 1], expect3[mask == 1]) and np.array_equal(ids3[mask == 0], ids[mask == 0])
+    env.close()
+    # levels that differ in structure keep the reference's whole-batch switch
+    other = MuJoCoRL({"xmlPath": [levels.level_path("two_agent.xml"), levels.level_path("two_agent_2sensors.xml")],
+                      "agents": AGENTS, "numEnvs": 2})
+    assert other._variants is None
+    other.close()
+
+
+# --------------------------------------------------------------------------- vector-env adapter against the oracle (8f rank 1)
+def test_batched_vector_env_follows_the_oracle_through_autoresets():
+    from mjrl_amd.wrappers import BatchedVectorEnv
+    n_env, horizon = 5, 6
+    vec = BatchedVectorEnv(MuJoCoRL({"xmlPath": levels.level_path("single_agent.xml"), "agents": ["sender"],
+                                     "numEnvs": n_env, "maxSteps": horizon}))
+    obs, _ = vec.reset()
+    env = vec.environment
+    oras = [OracleEnv(env._blob) for _ in range(n_env)]
+    first = np.stack([np.concatenate([o.sensordata[[0]], o.qpos, o.qvel]) for o in oras])
+    assert np.allclose(obs, first, atol=1e-12)
+    rng = np.random.default_rng(6)
+    idx = env.agents_action_index["sender"]
+    for step in range(1, 3 * horizon + 3):
+        act = rng.uniform(-1, 1, (n_env, 8))
+        obs, rew, term, trunc, info = vec.step(act)
+        for e, o in enumerate(oras):
+            o.ctrl[idx] = act[e]
+            o.step()
+        expect = np.stack([np.concatenate([o.sensordata[[0]], o.qpos, o.qvel]) for o in oras])
+        if step % (horizon + 1) == 0:           # call max_steps + 1 truncates (mujoco_rl.py:412): autoreset
+            assert trunc.all() and np.allclose(info["final_observation"], expect, atol=1e-9)
+            for o in oras:
+                o.reset()
+            assert np.allclose(obs, first, atol=1e-12)
+        else:
+            assert not trunc.any() and np.allclose(obs, expect, atol=1e-9)
+    vec.close()
