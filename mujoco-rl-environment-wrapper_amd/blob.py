@@ -72,11 +72,13 @@ def _sizes(model) -> dict:
     s = {k: int(getattr(model, k)) for k in SIZE_FIELDS if hasattr(model, k) and not k.startswith("reserved")
          and k != "maxdepth"}
     s["maxdepth"] = int(model.body_depth.max()) if model.nbody else 0
-    # narrow-phase work items one candidate pair can need (plane-box 8, capsule-capsule 4, capsule ends 2)
+    # narrow-phase work items one candidate pair can need (box-box 16, plane-box 8, capsule-capsule 4, capsule ends 2);
+    # 16 also tells the kernels that the level has box-box pairs at all (the routine is compiled out of a specialised
+    # kernel otherwise)
     kmax = 1
     for g1, g2 in model.pair_geom:
         t = (int(model.geom_type[g1]), int(model.geom_type[g2]))
-        kmax = max(kmax, {(0, 3): 2, (0, 6): 8, (3, 3): 4, (3, 6): 2}.get(t, 1))
+        kmax = max(kmax, {(0, 3): 2, (0, 6): 8, (3, 3): 4, (3, 6): 2, (6, 6): 16}.get(t, 1))
     s["pair_kmax"] = kmax
     s["has_accel"] = int(any(int(t) == 1 for t in model.sensor_type))     # accelerometers keep cacc/cdof_dot alive
     # narrow-phase work-item list: room for every pair that can plausibly pass the bounding-sphere test at once

@@ -296,7 +296,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   if (m.maxdofdepth + 1 > mj::MAX_DOF_DEPTH) return fail(3, "mjrl_create: kinematic chains deeper than 8 dofs are not supported");
   if (m.nconmax > 64 || m.nconmax < 1) return fail(3, "mjrl_create: nconmax must be in 1..64");
   if (m.njmax > 511 || m.njmax < 1) return fail(3, "mjrl_create: njmax must be in 1..511");
-  if (m.pair_kmax != 1 && m.pair_kmax != 2 && m.pair_kmax != 4 && m.pair_kmax != 8) return fail(3, "mjrl_create: bad pair_kmax");
+  if (m.pair_kmax != 1 && m.pair_kmax != 2 && m.pair_kmax != 4 && m.pair_kmax != 8 && m.pair_kmax != 16)
+    return fail(3, "mjrl_create: bad pair_kmax");
   if (m.integrator != 0) return fail(3, "mjrl_create: only the Euler integrator is implemented");
   mj::make_layout(m, e->lay);
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);

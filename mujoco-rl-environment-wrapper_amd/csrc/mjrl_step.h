@@ -658,6 +658,20 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
         V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
         real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
         pass = !(ex * ex + ey * ey + ez * ez > bound * bound);
+      } else if (m.pair_kmax >= 16 && t1 == GEOM_BOX && t2 == GEOM_BOX) {
+        // the same both ways: each box's bounding sphere (+ margin) against the other box (bound = rb1 + rb2 + margin)
+        pass = !(dot(dif, dif) > bound * bound);
+        if (pass) {
+          const real rb1 = m.geom_rbound[g1], rb2 = m.geom_rbound[g2];
+          V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
+          real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
+          const real r1 = bound - rb2;
+          pass = !(ex * ex + ey * ey + ez * ez > r1 * r1);
+          loc = mulT(qmat(ldq(S + l.gquat + 4 * g1)), dif); bs = ld3(S + l.gsize + 3 * g1);
+          ex = fmax(fabs(loc.x) - bs.x, 0.0); ey = fmax(fabs(loc.y) - bs.y, 0.0); ez = fmax(fabs(loc.z) - bs.z, 0.0);
+          const real r2 = bound - rb1;
+          pass = pass && !(ex * ex + ey * ey + ez * ez > r2 * r2);
+        }
       } else {
         pass = !(dot(dif, dif) > bound * bound);
       }
@@ -670,15 +684,17 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
         }
       }
     }
-    // exclusive prefix of the item counts (1, 2, 4 or 8 per lane) from four ballots; most chunks have no survivor
+    // exclusive prefix of the item counts (1, 2, 4, 8 or 16 per lane) from ballots; most chunks have no survivor
     unsigned long long b1 = wv::ballot(items >= 1);
     if (b1 == 0ull) continue;
     unsigned long long lower = (1ull << L) - 1ull;
     unsigned long long b2 = wv::ballot(items >= 2), b4 = wv::ballot(items >= 4), b8 = wv::ballot(items >= 8);
-    int off = nitem + wv::popc(b1 & lower) + wv::popc(b2 & lower) + 2 * wv::popc(b4 & lower) + 4 * wv::popc(b8 & lower);
+    unsigned long long b16 = m.pair_kmax >= 16 ? wv::ballot(items >= 16) : 0ull;
+    int off = nitem + wv::popc(b1 & lower) + wv::popc(b2 & lower) + 2 * wv::popc(b4 & lower) + 4 * wv::popc(b8 & lower) +
+              8 * wv::popc(b16 & lower);
     for (int k = 0; k < items; k++)
-      if (off + k < m.nitemmax) I[l.i_item + off + k] = (p << 3) | k;
-    nitem += wv::popc(b1) + wv::popc(b2) + 2 * wv::popc(b4) + 4 * wv::popc(b8);
+      if (off + k < m.nitemmax) I[l.i_item + off + k] = (p << 4) | k;
+    nitem += wv::popc(b1) + wv::popc(b2) + 2 * wv::popc(b4) + 4 * wv::popc(b8) + 8 * wv::popc(b16);
   }
   if (nitem > m.nitemmax) { nitem = m.nitemmax; warn |= 4; }
   wv::sync();
@@ -691,14 +707,14 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
     int g1 = 0, g2 = 0;
     real margin = 0, gap = 0;
     if (it < nitem) {
-      int code = I[l.i_item + it], p = code >> 3, k = code & 7;
+      int code = I[l.i_item + it], p = code >> 4, k = code & 15;
       int word = m.pair_word[p];
       g1 = word & 255; g2 = (word >> 8) & 255;
       margin = m.pair_margin[p];
       gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
       hit = collide_item((word >> 16) & 15, (word >> 20) & 15, ld3(S + l.gpos + 3 * g1), qmat(ldq(S + l.gquat + 4 * g1)),
                          ld3(S + l.gsize + 3 * g1), ld3(S + l.gpos + 3 * g2), qmat(ldq(S + l.gquat + 4 * g2)),
-                         ld3(S + l.gsize + 3 * g2), margin, k, rc);
+                         ld3(S + l.gsize + 3 * g2), margin, k, rc, m.pair_kmax >= 16);
     }
     unsigned long long mask = wv::ballot(hit);
     if (hit) {
@@ -1339,11 +1355,15 @@ struct SchedArgs {
 template <int NP>       // 16: one position per lane; 32: two (more than 256 registers: for images that hold a CU to 4 copies anyway)
 __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool dof, SchedArgs w, int* iter_io) {
   const int k = L & 15, mytree = L >> 4;
+  // (the sweep length is wave-uniform -- lane 0's, tree 0 always exists --; the rows of 16 lanes of a tree the model does
+  // not have come in with length 0 and hold no list: treated as a tree they would walk tree 0's list on their own,
+  // write their forces over the real ones and add to the sweep's improvement)
+  const bool mine = w.len > 0;
   const int len = wv::first_int(w.len), iterations = wv::first_int(w.iterations);
   int iter = wv::first_int(*iter_io);
   const unsigned char* t8 = (const unsigned char*)(S + w.o_tab);
   auto dof_tree = [&](int d) { return w.tab_bytes ? (int)t8[w.tab_dtree + d] : (int)((const unsigned short*)t8)[w.tab_dtree + d]; };
-  auto entry = [&](int p) { return p < len ? I[w.o_rowid + w.base + p] : -1; };
+  auto entry = [&](int p) { return (mine && p < len) ? I[w.o_rowid + w.base + p] : -1; };
   auto coef = [&](int r, int info) -> real {
     const int rt = (info >> CHAIN_BITS) - 2;
     const int sl = rt >= 0 ? (rt == mytree ? k : -1) : row_slot(info, w.below, w.depth);

@@ -184,7 +184,11 @@ class TargetDistanceReward(_Target):
             reward = self.scale * (-dist)
         else:
             prev = store.get(self.key)
-            reward = 0.0 * dist if prev is None else self.scale * (prev - dist)
+            if prev is None:
+                reward = 0.0 * dist
+            else:       # (with several copies the key may be set for some of them only: NaN = absent, as on the device)
+                prev = np.asarray(prev, dtype=np.float64)
+                reward = np.where(np.isnan(prev), 0.0, self.scale * (prev - dist))
         store[self.key] = dist
         return float(reward) if np.ndim(reward) == 0 else reward
 

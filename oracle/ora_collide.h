@@ -5,7 +5,9 @@
  * the normal points from geom1 to geom2, dist<0 is penetration, pos is the midpoint between
  * the two surfaces, and the pair is ordered so that type(geom1) <= type(geom2).
  * The capsule-box routine is a from-scratch geometric construction (closest point of the
- * segment to the box, plus end caps), not a restatement of MuJoCo's feature walk.
+ * segment to the box, plus end caps), not a restatement of MuJoCo's feature walk.  The box-box routine
+ * is likewise this repo's own: separating-axis test over the 15 axes, then either the clipped face
+ * manifold (incident face against the reference face, up to 8 points) or one edge-edge contact.
  */
 #ifndef ORA_COLLIDE_H
 #define ORA_COLLIDE_H
@@ -257,6 +259,175 @@ static inline int ora_capsule_box(ora_rawcon* c, const double* cpos, const doubl
     n += ora_sphere_box(c + n, pt, r, bpos, bmat, bsize, margin);
   }
   for (int k = 0; k < n; k++) v3_copy(c[k].frame + 3, axis_w);
+  return n;
+}
+
+
+/* ---- box against box.
+ * Separating-axis test over the 6 face normals and the 9 edge cross products; the axis of least penetration decides.
+ * A face axis: the manifold is the incident face (the face of the other box most anti-parallel to the reference normal)
+ * clipped against the reference face's rectangle -- written as 12 independent candidates so that the device evaluates
+ * them one per lane: for every incident edge its entry point into the rectangle (the edge's start vertex when that lies
+ * inside) and, where the edge leaves the rectangle before its end, its exit point (items 0..7); the four corners of the
+ * reference face that lie strictly inside the incident face's projection (items 8..11).  An edge axis (only when it
+ * separates distinctly better than every face axis): one contact between the closest points of the two supporting edges
+ * (item 12).  Candidates farther than the margin are dropped.  ora_box_box_item returns 1 when item k yields a contact. */
+static inline int ora_box_box_item(ora_rawcon* c, int k, const double* p1, const double* m1, const double* s1,
+                                   const double* p2, const double* m2, const double* s2, double margin) {
+  double A[3][3], B[3][3], d[3], dA[3], dB[3], C[3][3], aC[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int r = 0; r < 3; r++) { A[i][r] = m1[3 * r + i]; B[i][r] = m2[3 * r + i]; }
+  v3_sub(d, p2, p1);
+  for (int i = 0; i < 3; i++) { dA[i] = v3_dot(d, A[i]); dB[i] = v3_dot(d, B[i]); }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { C[i][j] = v3_dot(A[i], B[j]); aC[i][j] = fabs(C[i][j]); }
+  double best = -1e300;
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    double rb = s2[0] * aC[i][0] + s2[1] * aC[i][1] + s2[2] * aC[i][2];
+    double sep = fabs(dA[i]) - (s1[i] + rb);
+    if (sep > best) { best = sep; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double ra = s1[0] * aC[0][j] + s1[1] * aC[1][j] + s1[2] * aC[2][j];
+    double sep = fabs(dB[j]) - (ra + s2[j]);
+    if (sep > best) { best = sep; code = 3 + j; }
+  }
+  if (best > margin) return 0;
+  double ebest = -1e300, einv = 0;
+  int ecode = -1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double L[3];
+      v3_cross(L, A[i], B[j]);
+      double l2 = v3_dot(L, L);
+      if (l2 < 1e-10) continue;
+      double inv = 1.0 / sqrt(l2);
+      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      double ra = (s1[i1] * aC[i2][j] + s1[i2] * aC[i1][j]) * inv;
+      double rb = (s2[j1] * aC[i][j2] + s2[j2] * aC[i][j1]) * inv;
+      double sep = fabs(v3_dot(d, L) * inv) - (ra + rb);
+      if (sep > ebest) { ebest = sep; ecode = 3 * i + j; einv = inv; }
+    }
+  if (ecode >= 0 && ebest > margin) return 0;
+  int use_edge = ecode >= 0 && ebest > best + 0.05 * fabs(best) + 1e-9;
+  v3_zero(c->frame + 3);
+  if (use_edge) {
+    if (k != 12) return 0;
+    int i = ecode / 3, j = ecode % 3;
+    double L[3], e1[3], e2[3], w[3];
+    v3_cross(L, A[i], B[j]);
+    v3_scl(L, L, einv);
+    if (v3_dot(d, L) < 0) v3_scl(L, L, -1.0);
+    v3_copy(e1, p1);
+    v3_copy(e2, p2);
+    for (int q = 0; q < 3; q++) {
+      if (q != i) v3_addscl(e1, e1, A[q], (v3_dot(A[q], L) > 0 ? 1.0 : -1.0) * s1[q]);
+      if (q != j) v3_addscl(e2, e2, B[q], (v3_dot(B[q], L) > 0 ? -1.0 : 1.0) * s2[q]);
+    }
+    v3_sub(w, e1, e2);
+    double b = C[i][j], dd = v3_dot(A[i], w), ee = v3_dot(B[j], w), den = 1.0 - b * b;
+    double ta = (b * ee - dd) / den, tb = (ee - b * dd) / den;
+    if (ta > s1[i]) ta = s1[i]; if (ta < -s1[i]) ta = -s1[i];
+    if (tb > s2[j]) tb = s2[j]; if (tb < -s2[j]) tb = -s2[j];
+    double c1[3], c2[3], dif[3];
+    v3_addscl(c1, e1, A[i], ta);
+    v3_addscl(c2, e2, B[j], tb);
+    v3_sub(dif, c2, c1);
+    double dist = v3_dot(dif, L);
+    if (dist > margin) return 0;
+    c->dist = dist;
+    v3_copy(c->frame, L);
+    v3_add(c->pos, c1, c2);
+    v3_scl(c->pos, c->pos, 0.5);
+    return 1;
+  }
+  if (k >= 12) return 0;
+  /* reference / incident box */
+  const int ref1 = code < 3, ri = ref1 ? code : code - 3;
+  const double (*RA)[3] = ref1 ? A : B, (*IA)[3] = ref1 ? B : A;
+  const double *pR = ref1 ? p1 : p2, *pI = ref1 ? p2 : p1, *sR = ref1 ? s1 : s2, *sI = ref1 ? s2 : s1;
+  double sgn = ref1 ? (dA[ri] >= 0 ? 1.0 : -1.0) : (dB[ri] >= 0 ? -1.0 : 1.0);
+  double n[3];
+  v3_scl(n, RA[ri], sgn);
+  double cj[3] = {v3_dot(IA[0], n), v3_dot(IA[1], n), v3_dot(IA[2], n)};
+  int ii = 0;
+  if (fabs(cj[1]) > fabs(cj[ii])) ii = 1;
+  if (fabs(cj[2]) > fabs(cj[ii])) ii = 2;
+  double msgn = cj[ii] > 0 ? -1.0 : 1.0;
+  int iu = (ii + 1) % 3, iv = (ii + 2) % 3, ru = (ri + 1) % 3, rv = (ri + 2) % 3;
+  double cI[3], cR[3], eu[3], ev[3], V[4][3];
+  v3_addscl(cI, pI, IA[ii], msgn * sI[ii]);
+  v3_addscl(cR, pR, n, sR[ri]);
+  v3_scl(eu, IA[iu], sI[iu]);
+  v3_scl(ev, IA[iv], sI[iv]);
+  for (int q = 0; q < 4; q++) {
+    double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = q < 2 ? 1.0 : -1.0;
+    v3_addscl(V[q], cI, eu, su);
+    v3_addscl(V[q], V[q], ev, sv);
+  }
+  const double *tu = RA[ru], *tv = RA[rv];
+  double hu = sR[ru], hv = sR[rv];
+  double X[4], Y[4];
+  for (int q = 0; q < 4; q++) {
+    double rel[3];
+    v3_sub(rel, V[q], cR);
+    X[q] = v3_dot(rel, tu); Y[q] = v3_dot(rel, tv);
+  }
+  double nout = ref1 ? 1.0 : -1.0;
+  if (k < 8) {
+    int e = k >> 1, ex = k & 1, f = (e + 1) & 3;
+    double xa = X[e], ya = Y[e], dx = X[f] - X[e], dy = Y[f] - Y[e];
+    double t0 = 0.0, t1 = 1.0;
+    int ok = 1;
+    double pp[4] = {-dx, dx, -dy, dy}, qq[4] = {xa + hu, hu - xa, ya + hv, hv - ya};
+    for (int b = 0; b < 4; b++) {
+      if (pp[b] == 0.0) { if (qq[b] < 0.0) ok = 0; continue; }
+      double r = qq[b] / pp[b];
+      if (pp[b] < 0.0) { if (r > t0) t0 = r; } else { if (r < t1) t1 = r; }
+    }
+    if (!ok || t0 > t1) return 0;
+    if (ex && !(t1 < 1.0)) return 0;
+    double t = ex ? t1 : t0, P[3], dP[3], rel[3];
+    v3_sub(dP, V[f], V[e]);
+    v3_addscl(P, V[e], dP, t);
+    v3_sub(rel, P, cR);
+    double depth = v3_dot(rel, n);
+    if (depth > margin) return 0;
+    c->dist = depth;
+    v3_scl(c->frame, n, nout);
+    v3_addscl(c->pos, P, n, -0.5 * depth);
+    return 1;
+  }
+  /* items 8..11: corners of the reference face strictly inside the incident face's projection */
+  int q = k - 8;
+  double x = ((q == 0 || q == 3) ? 1.0 : -1.0) * hu, y = (q < 2 ? 1.0 : -1.0) * hv;
+  int pos = 0, neg = 0;
+  for (int e = 0; e < 4; e++) {
+    int f = (e + 1) & 3;
+    double w = (X[f] - X[e]) * (y - Y[e]) - (Y[f] - Y[e]) * (x - X[e]);
+    pos += w > 0.0; neg += w < 0.0;
+  }
+  if (pos != 4 && neg != 4) return 0;
+  double mI[3], Vr[3], rel[3];
+  v3_scl(mI, IA[ii], msgn);
+  double nm = v3_dot(n, mI);
+  if (nm > -1e-9) return 0;
+  v3_addscl(Vr, cR, tu, x);
+  v3_addscl(Vr, Vr, tv, y);
+  v3_sub(rel, cI, Vr);
+  double lam = v3_dot(rel, mI) / nm;
+  if (lam > margin) return 0;
+  c->dist = lam;
+  v3_scl(c->frame, n, nout);
+  v3_addscl(c->pos, Vr, n, 0.5 * lam);
+  return 1;
+}
+
+static inline int ora_box_box(ora_rawcon* c, const double* p1, const double* m1, const double* s1, const double* p2,
+                              const double* m2, const double* s2, double margin) {
+  int n = 0;
+  for (int k = 0; k < 13 && n < 8; k++) n += ora_box_box_item(c + n, k, p1, m1, s1, p2, m2, s2, margin);
   return n;
 }
 

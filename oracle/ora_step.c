@@ -425,7 +425,7 @@ static void ora_collision(const ora_model* m, ora_data* d) {
     else if (t1 == ORA_GEOM_SPHERE && t2 == ORA_GEOM_BOX) n = ora_sphere_box(rc, p1, s1[0], p2, m2, s2, margin);
     else if (t1 == ORA_GEOM_CAPSULE && t2 == ORA_GEOM_CAPSULE) n = ora_capsule_capsule(rc, p1, m1, s1, p2, m2, s2, margin);
     else if (t1 == ORA_GEOM_CAPSULE && t2 == ORA_GEOM_BOX) n = ora_capsule_box(rc, p1, m1, s1, p2, m2, s2, margin);
-    /* box-box: not generated (documented gap; no shipped 2-agent level can reach it) */
+    else if (t1 == ORA_GEOM_BOX && t2 == ORA_GEOM_BOX) n = ora_box_box(rc, p1, m1, s1, p2, m2, s2, margin);
     for (int k = 0; k < n; k++) add_contact(m, d, rc + k, g1, g2, margin, gap);
   }
 }

@@ -506,3 +506,50 @@ def test_batched_vector_env_follows_the_oracle_through_autoresets():
         else:
             assert not trunc.any() and np.allclose(obs, expect, atol=1e-9)
     vec.close()
+
+
+# --------------------------------------------------------------------------- box-box contacts
+def test_box_box_contacts_on_the_device():
+    """The free BOX agent of the reference's sensor configurations (Testing/sensor_test.py:20, Testing/sensor_levels/
+    Model1.xml) held at an arena wall, and pairs of free boxes in random poses: contact lists, solver sweeps and
+    trajectories against the oracle (the routine's known answers are in tests/test_box_box.py)."""
+    from tests.test_box_box import random_pose_xml
+    env = MuJoCoRL({"xmlPath": levels.level_path("sensor_touch.xml"), "agents": ["receiver"], "numEnvs": 4, "freeJoint": True})
+    env.reset()
+    qpos = env._handle.get_field("qpos")
+    qpos[:, 1] = 3.6
+    env._handle.set_field("qpos", qpos)
+    oras = [OracleEnv(env._blob) for _ in range(4)]
+    for o in oras:
+        o.qpos[1] = 3.6
+    drive = np.array([[0.0, 1.0, 0.0], [0.3, 1.0, 0.2], [-0.4, 0.9, -0.5], [0.0, 0.6, 1.0]])
+    for _ in range(450):
+        env.step({"receiver": drive})
+        for e, o in enumerate(oras):
+            o.qvel[[0, 1, 5]] = drive[e]
+            o.step()
+    names = env._compiled.names["geom"]
+    wall, box = names.index("border2_geom"), names.index("receiver_geom")
+    assert all(any((c["geom1"], c["geom2"]) == (wall, box) for c in o.contacts()) for o in oras[:3])
+    assert rel(env._handle.get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
+    stats = env._handle.get_field("solver_stats")
+    assert np.array_equal(stats[:, 0], [o.ncon for o in oras]) and np.array_equal(stats[:, 2], [o.niter for o in oras])
+    assert (env._handle.get_field("qpos")[:3, 1] + 0.5 < 4.738263 - 0.25 + 0.2).all()       # held at the wall
+    env.close()
+    rng = np.random.default_rng(17)
+    touched = 0
+    for trial in range(12):
+        model = mjcf.compile_mjcf_string(random_pose_xml(rng))
+        packed = blob.pack(model)
+        h = _capi.Handle(packed, 3)
+        h.reset()
+        ora = OracleEnv(packed)
+        for _ in range(6):
+            h.step_host(None, 1)
+            ora.step()
+            stats = h.get_field("solver_stats")
+            assert (stats[:, 0] == ora.ncon).all() and (stats[:, 2] == ora.niter).all(), trial
+            touched += ora.ncon > 0
+        assert rel(h.get_field("qpos"), np.tile(ora.qpos, (3, 1))) < 1e-10
+        h.close()
+    assert touched > 10
