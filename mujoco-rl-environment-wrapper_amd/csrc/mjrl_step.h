@@ -1221,7 +1221,17 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
     f_start = fi; s_start = sr;
     real ns = -sr, nss = ns;                 // negated residual: a row step is max, broadcast, multiply-add (see stage_pgs)
     const real nf = -fi;
-    const real improvement = wv::rows4_sum(wv::sum16(-c_prev));      // of the sweep before
+    if (pending) {                           // the stop test of the sweep before (see stage_pgs: one deciding row spares the sum)
+      const bool decided = wv::ballot(c_prev > 1e-10) == 0ull && wv::ballot((-c_prev - 1e-8) * scale >= m.tolerance) != 0ull;
+      if (!decided) {
+        const real improvement = wv::rows4_sum(wv::sum16(-c_prev));
+        if (wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
+          if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
+          pending = false;
+          break;
+        }
+      }
+    }
 #define MJ_FSTEP(KK)                                                                  \
       {                                                                               \
         real db = wide_bcast<KK>(fmax(ns, nf));                                       \
@@ -1229,12 +1239,6 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
         ns -= A[KK] * db;                                                             \
       }
     MJ_FSTEP(0) MJ_FSTEP(1)
-    if (pending && wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
-      if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
-      else { sr = s_start; }
-      pending = false;
-      break;
-    }
     MJ_FSTEP(2) MJ_FSTEP(3) MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7) MJ_FSTEP(8) MJ_FSTEP(9)
     MJ_FSTEP(10) MJ_FSTEP(11) MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
     MJ_FSTEP(16) MJ_FSTEP(17) MJ_FSTEP(18) MJ_FSTEP(19)
@@ -1644,7 +1648,23 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       // bit as the reference forms it, and with it the cost change of the row.)
       real ns = -sr, nss = ns;
       const real nf = -fi;
-      const real improvement = wv::rows_sum(wv::sum16(-c_prev), m.ntree);      // of the sweep before
+      // The stop test of the sweep before.  Its improvement is a 64-lane sum of the rows' cost decreases, as many
+      // instructions as three row steps -- but every term is >= -1e-10 (a step that would raise the cost by more is
+      // refused), so ONE row whose own decrease exceeds the threshold (by more than the other rows could take back)
+      // already decides "not converged", and that is what nearly every sweep of a long solve looks like: two compares
+      // and a scalar test, the sum only when no single row decides.  The sum, the branch and the sweep count are the
+      // reference's.
+      if (pending) {
+        const bool decided = wv::ballot(c_prev > 1e-10) == 0ull && wv::ballot((-c_prev - 1e-8) * scale >= m.tolerance) != 0ull;
+        if (!decided) {
+          const real improvement = wv::rows_sum(wv::sum16(-c_prev), m.ntree);
+          if (wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
+            if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
+            pending = false;                                                                        // (else: it had converged)
+            break;
+          }
+        }
+      }
 #define MJ_FSTEP(KK)                                                                  \
         {                                                                             \
           real db = wv::bcast16<KK>(fmax(ns, nf));                                    \
@@ -1652,13 +1672,6 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
           ns -= A[KK] * db;                                                           \
         }
       MJ_FSTEP(0) MJ_FSTEP(1)
-      // one branch for the two rare outcomes (a condition computed by the vector unit costs ~80 cycles to branch on)
-      if (pending && wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
-        if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
-        else { sr = s_start; }                                                                  // it had converged
-        pending = false;
-        break;
-      }
       do {
         if (2 >= tmax_s) break;
         MJ_FSTEP(2) MJ_FSTEP(3)
