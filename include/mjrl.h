@@ -147,6 +147,24 @@ int mjrl_query(mjrl_env* env, const char* name, double* h_out, size_t nbytes);
 int mjrl_render_device(mjrl_env* env, int width, int height, uint8_t* d_rgb);
 int mjrl_render_host(mjrl_env* env, int width, int height, uint8_t* h_rgb);
 
+/* Encoder of the reference's vision autoencoder (vision/autoencoder.py:12-18) on the matrix cores:
+ *   Conv2D(32, 3x3, relu, stride 2, same) -> Conv2D(64, 3x3, relu, stride 2, same) -> Flatten -> Dense(latent_dim[, relu])
+ * on 64x64x3 uint8 images scaled by 1/255 (vision/train.py:26).  Weights as Keras stores them, float32, channels last:
+ *   w1 [3][3][3][32]  b1 [32]  w2 [3][3][32][64]  b2 [64]  wd [16384][latent_dim]  bd [latent_dim]   (host pointers).
+ * Arithmetic: bf16 operands (weights and the activations between the layers are rounded to bf16), fp32 accumulation. */
+int mjrl_encoder_load(mjrl_env* env, int latent_dim, int relu_latent, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* wd, const float* bd);
+/* Encode n_img images [n_img][64][64][3] (uint8, e.g. the output of mjrl_render_device at 64 x 64) to
+ * float32 latents [n_img][latent_dim]. */
+int mjrl_encode_device(mjrl_env* env, const uint8_t* d_rgb, int n_img, float* d_latent);
+int mjrl_encode_host(mjrl_env* env, const uint8_t* h_rgb, int n_img, float* h_latent);
+/* Camera latents inside the observation: agent a's observation row grows by latent_dim values -- the encoding of the
+ * 64x64 image of camera agent_cam[a] (-1: the agent has no camera; its slots stay 0) -- placed after the physical part
+ * and the fused program's values.  Every mjrl_step_* call that returns observations then renders and encodes behind
+ * the step on the same stream (what a vision policy does with get_camera_data + the autoencoder, mujoco_parent.py:540-555,
+ * vision/autoencoder.py).  Needs mjrl_encoder_load and the gather tables; n_agent 0 turns it off.  obs_dim changes. */
+int mjrl_set_camera_obs(mjrl_env* env, int n_agent, const int32_t* agent_cam);
+
 /* Debug: step once like mjrl_step_device and also dump every copy's LDS image
  * ([n_env][lds_doubles] doubles; stage 0 = end of the forward pass, 1 = after the row build).
  * mjrl_lds_offset gives the offset of a named region inside one image. */

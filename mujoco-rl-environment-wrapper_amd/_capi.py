@@ -21,6 +21,7 @@ SYMBOLS = [
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
     "mjrl_reset_device", "mjrl_set_step_reset_mask", "mjrl_set_tag_tables", "mjrl_set_env_base", "mjrl_set_variants",
+    "mjrl_encoder_load", "mjrl_encode_device", "mjrl_encode_host", "mjrl_set_camera_obs",
 ]
 
 _lib = None
@@ -57,6 +58,10 @@ def load():
     L.mjrl_set_tag_tables.argtypes = [vp, ci, ip, ip]
     L.mjrl_set_env_base.argtypes = [vp, ci]
     L.mjrl_set_variants.argtypes = [vp, ci, vp, ctypes.c_ulonglong]
+    L.mjrl_encoder_load.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp]
+    L.mjrl_encode_device.argtypes = [vp, vp, ci, vp]
+    L.mjrl_encode_host.argtypes = [vp, vp, ci, vp]
+    L.mjrl_set_camera_obs.argtypes = [vp, ci, ip]
     L.mjrl_step_device.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.mjrl_step_host.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp]
     L.mjrl_get_field.argtypes = [vp, ctypes.c_char_p, vp, sz]
@@ -215,6 +220,37 @@ class Handle:
         if arr.ndim != 3 or arr.shape[1:] != (self.size("ngeom"), 4):
             raise Exception(f"variant colours have shape {arr.shape}, expected (n_variant, {self.size('ngeom')}, 4)")
         self._check(self._lib.mjrl_set_variants(self._h, arr.shape[0], _host_ptr(arr), int(seed)))
+
+    def encoder_load(self, weights: dict, relu: bool = True):
+        """``weights``: w1 [3,3,3,32], b1 [32], w2 [3,3,32,64], b2 [64], wd [16384, latent], bd [latent] (Keras layout)."""
+        shapes = {"w1": (3, 3, 3, 32), "b1": (32,), "w2": (3, 3, 32, 64), "b2": (64,)}
+        arrs = {k: np.ascontiguousarray(np.asarray(weights[k], dtype=np.float32)) for k in ("w1", "b1", "w2", "b2", "wd", "bd")}
+        for k, shape in shapes.items():
+            if arrs[k].shape != shape:
+                raise Exception(f"encoder weight {k} has shape {arrs[k].shape}, expected {shape}")
+        latent = arrs["bd"].shape[0]
+        if arrs["wd"].shape != (16384, latent):
+            raise Exception(f"encoder weight wd has shape {arrs['wd'].shape}, expected (16384, {latent})")
+        self._check(self._lib.mjrl_encoder_load(self._h, latent, int(bool(relu)), *[_host_ptr(arrs[k]) for k in ("w1", "b1", "w2", "b2", "wd", "bd")]))
+        self.latent_dim = latent
+
+    def encode(self, images=None, d_rgb: int | None = None, n_img: int | None = None, d_latent: int | None = None):
+        """Latents of uint8 images ``[n, 64, 64, 3]`` (host array -> host float32 array), or of a device buffer."""
+        if d_rgb:
+            self._check(self._lib.mjrl_encode_device(self._h, ctypes.c_void_p(d_rgb), int(n_img), ctypes.c_void_p(d_latent)))
+            return None
+        img = np.ascontiguousarray(np.asarray(images, dtype=np.uint8)).reshape(-1, 64, 64, 3)
+        out = np.zeros((img.shape[0], self.size("latent_dim")), np.float32)
+        self._check(self._lib.mjrl_encode_host(self._h, _host_ptr(img), img.shape[0], _host_ptr(out)))
+        return out
+
+    def set_camera_obs(self, agent_cam):
+        """``agent_cam``: camera id per agent (-1: none); None / empty turns the camera observation off."""
+        if not agent_cam:
+            self._check(self._lib.mjrl_set_camera_obs(self._h, 0, None))
+            return
+        arr, ptr = _i32(agent_cam)
+        self._check(self._lib.mjrl_set_camera_obs(self._h, len(agent_cam), ptr))
 
     def reset_device(self, d_mask: int | None, d_obs: int | None = None):
         """Reset the copies flagged in the device byte mask at address ``d_mask`` (None: all); asynchronous."""

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/mjrl.h"
+#include "mjrl_encoder.h"
 #include "mjrl_step.h"
 
 namespace {
@@ -194,6 +195,14 @@ struct mjrl_env {
   int *variant = nullptr, *episode = nullptr, n_variant = 0;
   unsigned long long variant_seed = 0;
   double* variant_rgba = nullptr;         // [n_variant][ngeom][4]
+  // camera encoder (mjrl_encoder_load): packed bf16 weight fragments, biases, scratch; camera latents in the observation
+  void *enc_w1 = nullptr, *enc_w2 = nullptr, *enc_wd = nullptr;
+  float *enc_b1 = nullptr, *enc_b2 = nullptr, *enc_bd = nullptr;
+  unsigned short* enc_a2 = nullptr;        // [enc_cap][16384] conv output (bf16)
+  unsigned char* enc_rgb = nullptr;        // [n_env][ncam][64][64][3] frames of the camera observation
+  int* enc_obs_row = nullptr;              // [n_env * ncam] first latent slot of the image in the flat observation tensor, -1: none
+  int enc_latent = 0, enc_tiles = 0, enc_relu = 1, enc_cap = 0, n_cam_obs = 0;
+  std::vector<int32_t> h_agent_cam;
   const unsigned char* step_reset_mask = nullptr;   // caller-owned device mask of the in-launch reset (mjrl_set_step_reset_mask)
   // tables
   int n_agent = 0, obs_dim = 0, scatter_mode = 0, max_steps = 1024;
@@ -259,7 +268,7 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  void* ptrs[] = {e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia, e->overflow};
@@ -282,6 +291,7 @@ static int launch_reset(mjrl_env* e, const unsigned char* d_mask, double* d_obs 
 static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int skip_frames, double* d_obs, double* d_reward,
                        uint8_t* d_term, uint8_t* d_trunc, double* d_dbg, int dbg_stage, int forward_only,
                        unsigned long long* d_stamps = nullptr, unsigned long long* d_timeline = nullptr);
+static int launch_encoder(mjrl_env* e, const uint8_t* d_rgb, int n_img, float* d_latent, double* d_obs, const int* d_obs_row);
 
 int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out) {
   if (!blob || !out || n_env <= 0) { g_create_error = "mjrl_create: bad arguments"; return 1; }
@@ -376,12 +386,15 @@ int mjrl_set_max_steps(mjrl_env* e, int max_steps) {
   e->max_steps = max_steps; return 0; }
 
 // device gather table = physical part [base_obs_dim] + n_extra slots per agent owned by the fused program (-2)
+static int upload_camera_rows(mjrl_env* e);
+
 static int upload_gather(mjrl_env* e) {
-  int dim = e->base_obs_dim + e->n_extra;
+  int dim = e->base_obs_dim + e->n_extra + e->n_cam_obs;
   std::vector<int32_t> table((size_t)e->n_agent * dim, -1);
   for (int a = 0; a < e->n_agent; a++) {
     for (int k = 0; k < e->base_obs_dim; k++) table[(size_t)a * dim + k] = e->h_gather[(size_t)a * e->base_obs_dim + k];
-    for (int k = 0; k < e->n_extra; k++) table[(size_t)a * dim + e->h_obs_len[a] + k] = -2;
+    // slots the step kernel's gather leaves alone: the fused program's, then the camera latents (written by the encoder)
+    for (int k = 0; k < e->n_extra + e->n_cam_obs; k++) table[(size_t)a * dim + e->h_obs_len[a] + k] = -2;
   }
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   if (e->d_gather) { hipFree(e->d_gather); e->d_gather = nullptr; }
@@ -393,6 +406,21 @@ static int upload_gather(mjrl_env* e) {
   e->obs_dim = dim;
   e->s_obs_n = 0;     // staging is re-sized on the next host-buffer step
   if (e->s_obs) { hipFree(e->s_obs); e->s_obs = nullptr; }
+  return e->n_cam_obs ? upload_camera_rows(e) : 0;
+}
+
+// image (env, cam) -> index of its first latent slot in the flat observation tensor [n_env][n_agent][obs_dim]
+static int upload_camera_rows(mjrl_env* e) {
+  const int ncam = e->hm.ncam;
+  std::vector<int> rows((size_t)e->n_env * ncam, -1);
+  for (int env = 0; env < e->n_env; env++)
+    for (int a = 0; a < e->n_agent && a < (int)e->h_agent_cam.size(); a++) {
+      const int cam = e->h_agent_cam[a];
+      if (cam >= 0) rows[(size_t)env * ncam + cam] = ((size_t)env * e->n_agent + a) * e->obs_dim + e->h_obs_len[a] + e->n_extra;
+    }
+  if (e->enc_obs_row) { hipFree(e->enc_obs_row); e->enc_obs_row = nullptr; }
+  MJRL_HIP(e, hipMalloc(&e->enc_obs_row, sizeof(int) * rows.size()));
+  MJRL_HIP(e, hipMemcpy(e->enc_obs_row, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -551,6 +579,128 @@ int mjrl_set_variants(mjrl_env* e, int n_variant, const double* rgba, unsigned l
   return 0;
 }
 
+static unsigned short host_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+int mjrl_encoder_load(mjrl_env* e, int latent_dim, int relu_latent, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* wd, const float* bd) {
+  MJRL_ENTER(e);
+  if (latent_dim < 1 || latent_dim > 1024) MJRL_FAIL(e, 1, "encoder_load: latent_dim must be in 1..1024");
+  if (!w1 || !b1 || !w2 || !b2 || !wd || !bd) MJRL_FAIL(e, 1, "encoder_load: null weights");
+  if (e->n_cam_obs && latent_dim != e->enc_latent) MJRL_FAIL(e, 1, "encoder_load: camera observations are laid out for latent_dim %d", e->enc_latent);
+  const int tiles = (latent_dim + 15) / 16;
+  auto lane_k = [](int lane, int j) { return 8 * (lane >> 4) + j; };
+  // conv1: B[k][n], k = (ky * 3 + kx) * 3 + c padded to 32, scaled by 1/255 (the pixels enter as integers 0..255)
+  std::vector<unsigned short> p1((size_t)2 * 64 * 8), p2((size_t)9 * 4 * 64 * 8), pd((size_t)(enc::FLAT / 32) * tiles * 64 * 8);
+  for (int nt = 0; nt < 2; nt++)
+    for (int lane = 0; lane < 64; lane++)
+      for (int j = 0; j < 8; j++) {
+        const int k = lane_k(lane, j), n = 16 * nt + (lane & 15);
+        p1[((size_t)nt * 64 + lane) * 8 + j] = host_bf16(k < 27 ? w1[k * 32 + n] / 255.0f : 0.0f);
+      }
+  for (int tap = 0; tap < 9; tap++)
+    for (int nt = 0; nt < 4; nt++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 8; j++) {
+          const int c = lane_k(lane, j), n = 16 * nt + (lane & 15);
+          p2[(((size_t)tap * 4 + nt) * 64 + lane) * 8 + j] = host_bf16(w2[((size_t)tap * 32 + c) * 64 + n]);
+        }
+  for (int kk = 0; kk < enc::FLAT / 32; kk++)
+    for (int nt = 0; nt < tiles; nt++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 8; j++) {
+          const int k = 32 * kk + lane_k(lane, j), n = 16 * nt + (lane & 15);
+          pd[(((size_t)kk * tiles + nt) * 64 + lane) * 8 + j] = n < latent_dim ? host_bf16(wd[(size_t)k * latent_dim + n]) : 0;
+        }
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  for (void** p : {&e->enc_w1, &e->enc_w2, &e->enc_wd, (void**)&e->enc_b1, (void**)&e->enc_b2, (void**)&e->enc_bd})
+    if (*p) { hipFree(*p); *p = nullptr; }
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+    MJRL_HIP(e, hipMalloc(dst, bytes));
+    MJRL_HIP(e, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (int rc = up(&e->enc_w1, p1.data(), p1.size() * 2)) return rc;
+  if (int rc = up(&e->enc_w2, p2.data(), p2.size() * 2)) return rc;
+  if (int rc = up(&e->enc_wd, pd.data(), pd.size() * 2)) return rc;
+  if (int rc = up((void**)&e->enc_b1, b1, sizeof(float) * 32)) return rc;
+  if (int rc = up((void**)&e->enc_b2, b2, sizeof(float) * 64)) return rc;
+  if (int rc = up((void**)&e->enc_bd, bd, sizeof(float) * latent_dim)) return rc;
+  e->enc_latent = latent_dim; e->enc_tiles = tiles; e->enc_relu = relu_latent ? 1 : 0;
+  const int conv_lds = enc::IMG * enc::IMG * 3 + enc::H1 * enc::H1 * enc::C1 * 2;
+  MJRL_HIP(e, hipFuncSetAttribute((const void*)enc::mjrl_encoder_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds));
+  return 0;
+}
+
+// conv + dense over n_img images already in HBM; obs / obs_row: scatter of the latents into the observation rows
+static int launch_encoder(mjrl_env* e, const uint8_t* d_rgb, int n_img, float* d_latent, double* d_obs, const int* d_obs_row) {
+  if (!e->enc_wd) MJRL_FAIL(e, 3, "encode: no encoder weights loaded (mjrl_encoder_load)");
+  if (n_img <= 0) return 0;
+  if (n_img > e->enc_cap) {
+    MJRL_HIP(e, hipStreamSynchronize(e->stream));
+    if (e->enc_a2) { hipFree(e->enc_a2); e->enc_a2 = nullptr; }
+    MJRL_HIP(e, hipMalloc(&e->enc_a2, sizeof(unsigned short) * (size_t)n_img * enc::FLAT));
+    e->enc_cap = n_img;
+  }
+  const int conv_lds = enc::IMG * enc::IMG * 3 + enc::H1 * enc::H1 * enc::C1 * 2;
+  hipLaunchKernelGGL(enc::mjrl_encoder_conv_kernel, dim3(n_img), dim3(256), conv_lds, e->stream, d_rgb, n_img,
+                     (const enc::frag_ab*)e->enc_w1, e->enc_b1, (const enc::frag_ab*)e->enc_w2, e->enc_b2, e->enc_a2);
+  MJRL_HIP(e, hipGetLastError());
+  hipLaunchKernelGGL(enc::mjrl_encoder_dense_kernel, dim3((n_img + 15) / 16, e->enc_tiles), dim3(64), 0, e->stream, e->enc_a2, n_img,
+                     (const enc::frag_ab*)e->enc_wd, e->enc_bd, e->enc_latent, e->enc_tiles, e->enc_relu, d_latent, d_obs,
+                     d_obs_row, e->obs_dim);
+  MJRL_HIP(e, hipGetLastError());
+  return 0;
+}
+
+int mjrl_encode_device(mjrl_env* e, const uint8_t* d_rgb, int n_img, float* d_latent) {
+  MJRL_ENTER(e);
+  if (!d_rgb || !d_latent) MJRL_FAIL(e, 3, "encode: null buffer");
+  return launch_encoder(e, d_rgb, n_img, d_latent, nullptr, nullptr);
+}
+
+int mjrl_encode_host(mjrl_env* e, const uint8_t* h_rgb, int n_img, float* h_latent) {
+  MJRL_ENTER(e);
+  if (!h_rgb || !h_latent || n_img <= 0) MJRL_FAIL(e, 3, "encode: bad arguments");
+  if (!e->enc_wd) MJRL_FAIL(e, 3, "encode: no encoder weights loaded (mjrl_encoder_load)");
+  uint8_t* d_rgb = nullptr;
+  float* d_lat = nullptr;
+  const size_t nb = (size_t)n_img * enc::IMG * enc::IMG * 3;
+  MJRL_HIP(e, hipMalloc(&d_rgb, nb));
+  hipError_t he = hipMalloc(&d_lat, sizeof(float) * (size_t)n_img * e->enc_latent);
+  int rc = 0;
+  if (he == hipSuccess) he = hipMemcpyAsync(d_rgb, h_rgb, nb, hipMemcpyHostToDevice, e->stream);
+  if (he == hipSuccess) rc = launch_encoder(e, d_rgb, n_img, d_lat, nullptr, nullptr);
+  if (he == hipSuccess && !rc) he = hipMemcpyAsync(h_latent, d_lat, sizeof(float) * (size_t)n_img * e->enc_latent, hipMemcpyDeviceToHost, e->stream);
+  if (he == hipSuccess && !rc) he = hipStreamSynchronize(e->stream);
+  hipFree(d_rgb);
+  if (d_lat) hipFree(d_lat);
+  if (he != hipSuccess) { e->err = hipGetErrorString(he); return 100 + (int)he; }
+  return rc;
+}
+
+int mjrl_set_camera_obs(mjrl_env* e, int n_agent, const int32_t* agent_cam) {
+  MJRL_ENTER(e);
+  if (n_agent == 0 || !agent_cam) {            // off
+    e->n_cam_obs = 0;
+    e->h_agent_cam.clear();
+    return e->n_agent ? upload_gather(e) : 0;
+  }
+  if (!e->enc_wd) MJRL_FAIL(e, 3, "set_camera_obs: load the encoder first (mjrl_encoder_load)");
+  if (!e->n_agent || e->h_obs_len.empty() || n_agent != e->n_agent) MJRL_FAIL(e, 3, "set_camera_obs: set the gather tables first (same agent count)");
+  if (e->hm.ncam == 0) MJRL_FAIL(e, 3, "set_camera_obs: the level has no cameras");
+  for (int a = 0; a < n_agent; a++)
+    if (agent_cam[a] < -1 || agent_cam[a] >= e->hm.ncam) MJRL_FAIL(e, 2, "set_camera_obs: camera id %d out of range", agent_cam[a]);
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (!e->enc_rgb) MJRL_HIP(e, hipMalloc(&e->enc_rgb, (size_t)e->n_env * e->hm.ncam * enc::IMG * enc::IMG * 3));
+  e->h_agent_cam.assign(agent_cam, agent_cam + n_agent);
+  e->n_cam_obs = e->enc_latent;
+  return upload_gather(e);
+}
+
 int mjrl_size(const mjrl_env* e, const char* name) {
 #define X(field) if (strcmp(name, #field) == 0) return e->hm.field;
   MJRL_SIZE_FIELDS(X)
@@ -566,6 +716,8 @@ int mjrl_size(const mjrl_env* e, const char* name) {
   }
   if (!strcmp(name, "n_slot")) return e->n_slot;
   if (!strcmp(name, "n_tag")) return e->n_tag;
+  if (!strcmp(name, "latent_dim")) return e->enc_latent;
+  if (!strcmp(name, "n_camera_obs")) return e->n_cam_obs;
   if (!strcmp(name, "n_variant")) return e->n_variant;
   if (!strcmp(name, "env_base")) return e->env_base;
   if (!strcmp(name, "n_extra_obs")) return e->n_extra;
@@ -671,6 +823,12 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
       hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
       MJRL_HIP(e, hipGetLastError());
     }
+  }
+  // Camera observations (mjrl_set_camera_obs): the agents' cameras are rendered at the new state and encoded, the
+  // latents land in the observation rows' last slots -- same stream, behind the step.
+  if (e->n_cam_obs && d_obs && !forward_only) {
+    if (int rc = mjrl_render_device(e, enc::IMG, enc::IMG, e->enc_rgb)) return rc;
+    if (int rc = launch_encoder(e, e->enc_rgb, e->n_env * e->hm.ncam, nullptr, d_obs, e->enc_obs_row)) return rc;
   }
   return 0;
 }

@@ -46,6 +46,9 @@ class MuJoCoRL(MuJoCoParent):
         self.environment_dynamics = config_dict.get("environmentDynamics", [])
         self.agent_cameras = config_dict.get("agentCameras", False)
         sensor_resolution = config_dict.get("sensorResolution", (64, 64))
+        # {"weights": {w1, b1, w2, b2, wd, bd}, "relu": True}: the encoder of vision/autoencoder.py:12-18; with
+        # agentCameras every agent's observation then ends with the latent of its first camera's 64x64 image
+        self.camera_encoder = config_dict.get("cameraEncoder")
 
         self.timestep = 0
         self.start_time = time.time()
@@ -73,6 +76,35 @@ class MuJoCoRL(MuJoCoParent):
         self._upload_tables(self.agents)
         self._fused_allowed = config_dict.get("fusedPlugins", True)
         self._setup_fused_program(self._fused_allowed)
+        self._setup_camera_encoder()
+
+    def _setup_camera_encoder(self):
+        """Camera latents as the tail of the observation (mjrl_set_camera_obs): what a vision policy of the reference
+        does by hand -- ``get_camera_data(agent)`` (mujoco_parent.py:540-555), scale by 1/255, encode
+        (vision/autoencoder.py:12-18) -- runs behind every step launch on the device."""
+        self._latent_dim = 0
+        if not self.camera_encoder:
+            return
+        if not self.agent_cameras:
+            raise Exception("cameraEncoder needs agentCameras: True")
+        self._handle.encoder_load(self.camera_encoder["weights"], relu=self.camera_encoder.get("relu", True))
+        names = self._compiled.names["camera"]
+        cams = [names.index(self.rgb_sensors[a][0]) if self.rgb_sensors.get(a) else -1 for a in self.agents]
+        self._handle.set_camera_obs(cams)
+        self._latent_dim = self._handle.latent_dim
+        low = 0.0 if self.camera_encoder.get("relu", True) else -np.inf
+        for agent, space in self._observation_space.items():
+            self._observation_space[agent] = Box(low=np.concatenate([space.low, np.full(self._latent_dim, low)]),
+                                                 high=np.concatenate([space.high, np.full(self._latent_dim, np.inf)]))
+        self._first_observation_space = self._observation_space[list(self._observation_space.keys())[0]]
+
+    def _camera_latents(self, agent):
+        """The latent slots of ``agent``'s row in the last step's observation buffer (host plugin path)."""
+        k = self._table_agents.index(agent)
+        start = self._obs_len[agent] + (self._program.n_extra if self._program is not None else 0)
+        if self._obs_cache is None:
+            return self._squeeze(np.zeros((self.n_env, self._latent_dim)))
+        return self._squeeze(self._obs_cache[:, k, start:start + self._latent_dim].copy())
 
     def _after_init_environment(self):
         """A multi-level ``reset()`` re-created the device state for another level: the new handle gets everything the
@@ -83,6 +115,11 @@ class MuJoCoRL(MuJoCoParent):
         self._handle.set_max_steps(self.max_steps)
         if hasattr(self, "_fused_allowed"):
             self._setup_fused_program(self._fused_allowed)
+            if self.camera_encoder:
+                self._handle.encoder_load(self.camera_encoder["weights"], relu=self.camera_encoder.get("relu", True))
+                names = self._compiled.names["camera"]
+                self._handle.set_camera_obs([names.index(self.rgb_sensors[a][0]) if self.rgb_sensors.get(a) else -1
+                                             for a in self.agents])
 
     def _setup_fused_program(self, allowed: bool):
         """When every configured plugin belongs to the device vocabulary (dynamics.py) the plugin loop runs inside
@@ -232,7 +269,7 @@ class MuJoCoRL(MuJoCoParent):
         self._handle.step_host(arr, self.skip_frames, obs, rew, term, trunc)
         self.frame += self.skip_frames
         self._obs_cache = None
-        extra = self._program.n_extra
+        extra = self._program.n_extra + self._latent_dim
         squeeze = (lambda x: x[0]) if self.n_env == 1 else (lambda x: x)
         observations = {a: squeeze(obs[:, k, :self._obs_len[a] + extra].copy()) for k, a in enumerate(self.agents)}
         rewards = {a: squeeze(rew[:, k].copy()) for k, a in enumerate(self.agents)}
@@ -263,6 +300,8 @@ class MuJoCoRL(MuJoCoParent):
         terminations = {agent: self._blank(False) for agent in self.agents}
         infos = {agent: {} for agent in self.agents}
         observations, rewards, terminations, infos = self._apply_dynamics(action, observations, rewards, terminations, infos)
+        if self._latent_dim:
+            observations = {agent: np.concatenate((observations[agent], self._camera_latents(agent)), axis=-1) for agent in self.agents}
 
         for reward_fn in self.reward_functions:
             rewards = {agent: rewards[agent] + reward_fn(self, agent) for agent in self.agents}
@@ -303,6 +342,8 @@ class MuJoCoRL(MuJoCoParent):
         copies = [copy.deepcopy(self.data_store) for _ in range(len(self.environment_dynamics))]
         original = copy.deepcopy(self.data_store)
         observations, rewards, terminations, infos = self._apply_dynamics(action, observations, rewards, terminations, infos)
+        if self._latent_dim:        # (the first images are encoded by the first step; the reset observation carries zeros)
+            observations = {agent: np.concatenate((observations[agent], self._camera_latents(agent)), axis=-1) for agent in self.agents}
         self.data_store = original
         for stored in copies:
             self.data_store = update_deep(self.data_store, stored)
