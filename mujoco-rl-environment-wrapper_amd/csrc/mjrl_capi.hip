@@ -183,6 +183,7 @@ struct mjrl_env {
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
   double* inertia = nullptr;       // [n_env][nM] scratch: the sparse inertia matrix between the CRB stage and the integrator
   unsigned long long* overflow = nullptr;   // [2] sticky cap-overflow counters (mjrl_cap_overflows)
+  double* rk = nullptr;            // [n_env][nq + 3 nv] Runge-Kutta scratch (models with <option integrator="RK4">)
   int* stats = nullptr;            // [n_env][4] ncon, nefc, solver sweeps, warning bits of each copy's last physics frame
   int* timestep = nullptr;
   unsigned char* d_mask = nullptr;
@@ -268,7 +269,7 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  void* ptrs[] = {e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia, e->overflow};
@@ -308,7 +309,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   if (m.njmax > 511 || m.njmax < 1) return fail(3, "mjrl_create: njmax must be in 1..511");
   if (m.pair_kmax != 1 && m.pair_kmax != 2 && m.pair_kmax != 4 && m.pair_kmax != 8 && m.pair_kmax != 16)
     return fail(3, "mjrl_create: bad pair_kmax");
-  if (m.integrator != 0) return fail(3, "mjrl_create: only the Euler integrator is implemented");
+  if (m.integrator != 0 && m.integrator != 1) return fail(3, "mjrl_create: unknown integrator (0 Euler, 1 RK4)");
   mj::make_layout(m, e->lay);
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
   if (lds_bytes > 160 * 1024) return fail(3, "mjrl_create: env working set exceeds the 160 KiB LDS of a CU");
@@ -332,6 +333,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
   CK(hipMalloc(&e->warm, sizeof(double) * n_env * m.nv));
   CK(hipMalloc(&e->inertia, sizeof(double) * (size_t)n_env * (m.nM > 0 ? m.nM : 1)));
+  if (m.integrator == 1) CK(hipMalloc(&e->rk, sizeof(double) * (size_t)n_env * (m.nq + 3 * m.nv)));
   CK(hipMalloc(&e->stats, sizeof(int) * 4 * (size_t)n_env));
   CK(hipMemset(e->stats, 0, sizeof(int) * 4 * (size_t)n_env));
   CK(hipMalloc(&e->overflow, sizeof(unsigned long long) * 2));
@@ -649,7 +651,7 @@ static int launch_encoder(mjrl_env* e, const uint8_t* d_rgb, int n_img, float* d
   hipLaunchKernelGGL(enc::mjrl_encoder_conv_kernel, dim3(n_img), dim3(256), conv_lds, e->stream, d_rgb, n_img,
                      (const enc::frag_ab*)e->enc_w1, e->enc_b1, (const enc::frag_ab*)e->enc_w2, e->enc_b2, e->enc_a2);
   MJRL_HIP(e, hipGetLastError());
-  hipLaunchKernelGGL(enc::mjrl_encoder_dense_kernel, dim3((n_img + 15) / 16, e->enc_tiles), dim3(64), 0, e->stream, e->enc_a2, n_img,
+  hipLaunchKernelGGL(enc::mjrl_encoder_dense_kernel, dim3((n_img + 15) / 16, e->enc_tiles), dim3(64 * enc::DENSE_WAVES), 0, e->stream, e->enc_a2, n_img,
                      (const enc::frag_ab*)e->enc_wd, e->enc_bd, e->enc_latent, e->enc_tiles, e->enc_relu, d_latent, d_obs,
                      d_obs_row, e->obs_dim);
   MJRL_HIP(e, hipGetLastError());
@@ -795,9 +797,13 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   // The kernel advances one physics frame; a step of skipFrames frames (mujoco_parent.py:333-336) is that many launches
   // on the stream.  The action scatter belongs to the first, everything after the physics (frame cache, debug dump,
   // counters, observations, plugin ops) to the last.
-  const int launches = skip_frames > 0 ? skip_frames : 1;
+  // (a Runge-Kutta frame is four launches, one forward pass each)
+  const int passes = (e->hm.integrator == 1 && !forward_only) ? 4 : 1;
+  const int launches = skip_frames > 0 ? skip_frames * passes : 1;
+  a.rk = e->rk;
   for (int f = 0; f < launches; f++) {
     const bool last = f == launches - 1;
+    a.rk_stage = f % passes;
     a.skip_frames = skip_frames > 0 ? 1 : 0;
     a.more_frames = last ? 0 : 1;
     if (f > 0) a.scatter = nullptr;

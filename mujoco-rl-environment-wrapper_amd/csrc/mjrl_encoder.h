@@ -118,20 +118,25 @@ __global__ __launch_bounds__(256) void mjrl_encoder_conv_kernel(const unsigned c
   }
 }
 
-// grid (ceil(n_img / 16), latent tiles); one wave: 16 images x 16 latent columns over K = 16384
-__global__ __launch_bounds__(64) void mjrl_encoder_dense_kernel(const unsigned short* __restrict__ a2, int n_img,
-                                                                const frag_ab* __restrict__ wdp, const float* __restrict__ bd,
-                                                                int latent, int n_tile, int relu, float* __restrict__ out,
-                                                                double* __restrict__ obs, const int* __restrict__ img_obs_row,
-                                                                int obs_dim) {
-  const int lane = threadIdx.x, row = lane & 15, grp = lane >> 4;
+// grid (ceil(n_img / 16), latent tiles), 8 waves per workgroup: a workgroup owns 16 images x 16 latent columns, its
+// waves split K = 16384 eight ways (64 k-steps each, the loads of 8 steps in flight) and the partial tiles are summed
+// through LDS in wave order -- a single wave walking all 512 k-steps left the chip at one or two waves per CU, bound by
+// the latency of its own loads.
+enum { DENSE_WAVES = 8 };
+__global__ __launch_bounds__(64 * DENSE_WAVES) void mjrl_encoder_dense_kernel(
+    const unsigned short* __restrict__ a2, int n_img, const frag_ab* __restrict__ wdp, const float* __restrict__ bd,
+    int latent, int n_tile, int relu, float* __restrict__ out, double* __restrict__ obs, const int* __restrict__ img_obs_row,
+    int obs_dim) {
+  __shared__ float part[DENSE_WAVES][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, grp = lane >> 4;
   const int img0 = blockIdx.x * 16, nt = blockIdx.y;
   const int my_img = img0 + row < n_img ? img0 + row : n_img - 1;           // (rows past the batch repeat the last image)
   const frag_ab* arow = (const frag_ab*)(a2 + (size_t)my_img * FLAT) + grp;  // k = 32 kk + 8 grp + j
   const frag_ab* bcol = wdp + (size_t)nt * 64 + lane;                        // fragment (kk, nt): wdp[(kk * n_tile + nt) * 64 + lane]
   frag_cd acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-  constexpr int STEPS = FLAT / 32;
-  for (int kk = 0; kk < STEPS; kk += 8) {
+  constexpr int STEPS = FLAT / 32 / DENSE_WAVES;
+  const int k0 = wave * STEPS;
+  for (int kk = k0; kk < k0 + STEPS; kk += 8) {
     frag_ab a[8], b[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) { a[u] = arow[(kk + u) * 4]; b[u] = bcol[(size_t)(kk + u) * n_tile * 64]; }
@@ -141,6 +146,10 @@ __global__ __launch_bounds__(64) void mjrl_encoder_dense_kernel(const unsigned s
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u + 1], b[u + 1], acc1, 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int r = 0; r < 4; r++) part[wave][lane][r] = acc0[r] + acc1[r];
+  __syncthreads();
+  if (wave != 0) return;
   const int n = 16 * nt + row;                                               // this lane's latent column
   if (n >= latent) return;
   const float bias = bd[n];
@@ -148,7 +157,10 @@ __global__ __launch_bounds__(64) void mjrl_encoder_dense_kernel(const unsigned s
   for (int r = 0; r < 4; r++) {
     const int image = img0 + 4 * grp + r;
     if (image >= n_img) continue;
-    float v = (acc0[r] + acc1[r]) + bias;
+    float v = part[0][lane][r];
+#pragma unroll
+    for (int w = 1; w < DENSE_WAVES; w++) v += part[w][lane][r];
+    v += bias;
     if (relu) v = fmaxf(v, 0.0f);
     if (out) out[(size_t)image * latent + n] = v;
     if (obs && img_obs_row) {

@@ -147,6 +147,11 @@ struct StepArgs {
   // reference's sampling loops (fps_benchmark.py:33-38, mujoco_rl.py:291-331) in one launch.
   const unsigned char* reset_mask;   // [n_env] device bytes, may be null
   int first_frame;                   // 1 in the first launch of a step (a flagged copy loads the reset image only there)
+  // Runge-Kutta (<option integrator="RK4">, benchmarking/levels/Ant.xml:3): a physics frame is four launches, one forward
+  // pass each; rk_stage 0..3 says which, rk [n_env][nq + 3 nv] keeps the frame's start state and the weighted sums of the
+  // passes' derivatives between them (x0 qpos | x0 qvel | sum b_i qvel_i | sum b_i qacc_i)
+  int rk_stage;
+  real* rk;
   // what the copy's last physics frame did: [n_env][4] = contacts, constraint rows, solver sweeps, cap-warning bits
   // (data.ncon, data.nefc, data.solver_iter, data.warning of MjData); may be null
   int* stats;
@@ -2041,6 +2046,45 @@ __device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK&
   wv::sync();
 }
 
+// One pass of the classical 4th-order Runge-Kutta step (the oracle's ora_step_rk4, operation for operation): the forward
+// pass of this launch has left qacc at the trial state in LDS; fold (qvel, qacc) into the weighted sums and set up the next
+// trial state X0 + h c F, or after the fourth pass the step's result X0 + h sum b_i F_i.  Positions move on the
+// configuration manifold like in the Euler update; joint damping stays explicit.
+__device__ inline void stage_rk4(const DevModel& m, const Lay& l, real* S, int L, int stage, real* R) {
+  const real h = m.timestep;
+  const real bw = (stage == 0 || stage == 3) ? 1.0 / 6.0 : 1.0 / 3.0, c = stage == 2 ? 1.0 : 0.5;
+  real* x0q = R;
+  real* x0v = R + m.nq;
+  real* accv = x0v + m.nv;
+  real* acca = accv + m.nv;
+  if (stage == 0) for (int i = L; i < m.nq; i += 64) x0q[i] = S[l.qpos + i];
+  if (L < m.nv) {
+    const real qv = S[l.qvel + L], qa = S[l.qacc + L];
+    const real v0 = stage == 0 ? qv : x0v[L];
+    real sv, sa;
+    if (stage == 0) { sv = bw * qv; sa = bw * qa; x0v[L] = qv; }
+    else { sv = accv[L] + bw * qv; sa = acca[L] + bw * qa; }
+    if (stage < 3) { accv[L] = sv; acca[L] = sa; }
+    S[l.x + L] = stage < 3 ? c * qv : sv;                       // the velocity the positions move with
+    S[l.qvel + L] = stage < 3 ? v0 + h * (c * qa) : v0 + h * sa;
+  }
+  if (stage > 0) for (int i = L; i < m.nq; i += 64) S[l.qpos + i] = x0q[i];
+  wv::sync();
+  if (L < m.njnt) {
+    int qa = m.jnt_qposadr[L], da = m.jnt_dofadr[L];
+    if (m.jnt_type[L] == JNT_FREE) {
+      for (int k = 0; k < 3; k++) S[l.qpos + qa + k] += h * S[l.x + da + k];
+      real len;
+      V3 w = normalized(ld3(S + l.x + da + 3), &len);
+      Quat q = qmul(qnormalized(ldq(S + l.qpos + qa + 3)), axis_angle(w, h * len));
+      stq(S + l.qpos + qa + 3, q);
+    } else {
+      S[l.qpos + qa] += h * S[l.x + da];
+    }
+  }
+  wv::sync();
+}
+
 // ------------------------------------------------------------------ one env copy, one step() call
 __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   const int L = wv::lane();
@@ -2168,7 +2212,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     stage_pgs(m, l, K, RK, S, L, stamps);
     MJ_STAMP(ST_PGS)
-    stage_sensors(m, l, K, S, L);
+    // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)
+    if (m.integrator == 0 || a.rk_stage == 0) stage_sensors(m, l, K, S, L);
     MJ_STAMP(ST_SENSORS)
     if (a.dbg && a.dbg_stage == 0)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
@@ -2190,7 +2235,10 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
         F[7 * m.nbody + 7 * m.ngeom + 2 + 2 * c] = c < ncon ? I[l.i_cong2 + c] : -1;
       }
     }
-    if (!a.forward_only) stage_euler(m, l, K, RK, S, L, a.inertia + (size_t)env * m.nM);
+    if (!a.forward_only) {
+      if (m.integrator == 0) stage_euler(m, l, K, RK, S, L, a.inertia + (size_t)env * m.nM);
+      else stage_rk4(m, l, S, L, a.rk_stage, a.rk + (size_t)env * (m.nq + 3 * m.nv));
+    }
     if (ops_staged) {
       int* TI = (int*)(S + l.bias);
       if (L < n_act_row) S[l.bias + L] = act_reg;
@@ -2209,7 +2257,12 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     MJ_FOR(i, m.nu) a.ctrl[(size_t)env * m.nu + i] = S[l.ctrl + i];
   }
   if (a.forward_only != 2) MJ_FOR(i, m.nv) a.warm[(size_t)env * m.nv + i] = S[l.warm + i];
-  MJ_FOR(i, m.nsensordata) a.sensordata[(size_t)env * m.nsensordata + i] = S[l.sens + i];
+  if (m.integrator == 0 || a.rk_stage == 0) {
+    MJ_FOR(i, m.nsensordata) a.sensordata[(size_t)env * m.nsensordata + i] = S[l.sens + i];
+  } else if (!a.more_frames) {        // the last pass of a Runge-Kutta frame: the observation gather reads the first pass's sensors
+    MJ_FOR(i, m.nsensordata) S[l.sens + i] = a.sensordata[(size_t)env * m.nsensordata + i];
+    wv::sync();
+  }
   // per-agent observation gather: sensordata | qpos | qvel (sensordata is the pre-integration forward pass,
   // qpos/qvel are post-integration, exactly as the reference reads them after mj_step)
   if (a.obs) {

@@ -141,6 +141,43 @@ def four_agent() -> str:
     return _to_text(root)
 
 
+def ant() -> str:
+    """The single free ant on an unbounded floor = benchmarking/levels/Ant.xml: the level with the Runge-Kutta integrator
+    (RK4, timestep 0.01), leg geoms that collide with the floor only (conaffinity 0 against the floor's 1), a tracking
+    camera on the torso."""
+    root = ET.Element("mujoco", model="ant")
+    ET.SubElement(root, "compiler", angle="degree", coordinate="local", inertiafromgeom="true")
+    ET.SubElement(root, "option", integrator="RK4", timestep="0.01")
+    default = ET.SubElement(root, "default")
+    ET.SubElement(default, "joint", armature="1", damping="1", limited="true")
+    ET.SubElement(default, "geom", conaffinity="0", condim="3", density="5.0", friction="1 0.5 0.5", margin="0.01",
+                  rgba="0.8 0.6 0.4 1")
+    world = ET.SubElement(root, "worldbody")
+    ET.SubElement(world, "light", cutoff="100", diffuse="1 1 1", dir="-0 0 -1.3", directional="true", exponent="1",
+                  pos="0 0 1.3", specular=".1 .1 .1")
+    ET.SubElement(world, "geom", conaffinity="1", condim="3", name="floor", pos="0 0 0", rgba="0.8 0.9 0.8 1",
+                  size="40 40 40", type="plane")
+    body = ET.SubElement(world, "body", name="torso", pos="0 0 0.75")
+    ET.SubElement(body, "camera", name="track", mode="trackcom", pos="0 -3 0.3", xyaxes="1 0 0 0 0 1")
+    ET.SubElement(body, "geom", name="torso_geom", pos="0 0 0", size="0.25", type="sphere")
+    ET.SubElement(body, "joint", armature="0", damping="0", limited="false", margin="0.01", name="root", pos="0 0 0",
+                  type="free")
+    for leg, aux_geom, hip_body, hip, leg_geom, ankle, ankle_geom, (sx, sy), axis, rng in _LEGS:
+        a, b = 0.2 * sx, 0.2 * sy
+        leg_body = ET.SubElement(body, "body", name=leg, pos="0 0 0")
+        ET.SubElement(leg_body, "geom", fromto=f"0.0 0.0 0.0 {_fmt(a)} {_fmt(b)} 0.0", name=aux_geom, size="0.08", type="capsule")
+        hb = ET.SubElement(leg_body, "body", name=hip_body, pos=f"{_fmt(a)} {_fmt(b)} 0")
+        ET.SubElement(hb, "joint", axis="0 0 1", name=hip, pos="0.0 0.0 0.0", range="-30 30", type="hinge")
+        ET.SubElement(hb, "geom", fromto=f"0.0 0.0 0.0 {_fmt(a)} {_fmt(b)} 0.0", name=leg_geom, size="0.08", type="capsule")
+        ab = ET.SubElement(hb, "body", pos=f"{_fmt(a)} {_fmt(b)} 0")
+        ET.SubElement(ab, "joint", axis=axis, name=ankle, pos="0.0 0.0 0.0", range=rng, type="hinge")
+        ET.SubElement(ab, "geom", fromto=f"0.0 0.0 0.0 {_fmt(2 * a)} {_fmt(2 * b)} 0.0", name=ankle_geom, size="0.08", type="capsule")
+    actuator = ET.SubElement(root, "actuator")
+    for joint in _MOTOR_ORDER:
+        ET.SubElement(actuator, "motor", ctrllimited="true", ctrlrange="-1.0 1.0", joint=joint, gear="150")
+    return _to_text(root)
+
+
 def sensor_level(kind: str) -> str:
     """Free box with one site sensor = Testing/sensor_levels/Model1-4.xml
     (touch / accelerometer / rangefinder / framexaxis)."""
@@ -172,6 +209,7 @@ LEVELS = {
     "two_agent_3sensors.xml": lambda: two_agent(("rangefinder", "touch", "accelerometer")),
     "single_agent.xml": single_agent,
     "four_agent.xml": four_agent,
+    "ant.xml": ant,
     "sensor_touch.xml": lambda: sensor_level("touch"),
     "sensor_accelerometer.xml": lambda: sensor_level("accelerometer"),
     "sensor_rangefinder.xml": lambda: sensor_level("rangefinder"),
@@ -184,6 +222,7 @@ REFERENCE_FILES = {
     "two_agent_2sensors.xml": "benchmarking/levels/MultiAgentModel2Sensors.xml",
     "two_agent_3sensors.xml": "benchmarking/levels/MultiAgentModel3Sensors.xml",
     "single_agent.xml": "benchmarking/levels/SingleAgentModel.xml",
+    "ant.xml": "benchmarking/levels/Ant.xml",
     "sensor_touch.xml": "Testing/sensor_levels/Model1.xml",
     "sensor_accelerometer.xml": "Testing/sensor_levels/Model2.xml",
     "sensor_rangefinder.xml": "Testing/sensor_levels/Model3.xml",

@@ -815,7 +815,43 @@ static void ora_integrate_pos(const ora_model* m, double* qpos, const double* qv
   }
 }
 
+/* 4th-order Runge-Kutta (<option integrator="RK4">, benchmarking/levels/Ant.xml:3), the classical tableau: the state
+ * (qpos, qvel) is advanced with the weighted derivatives of four forward passes, the three later ones at trial states
+ * X0 + h c F_prev (positions on the configuration manifold: quaternions by the exponential map).  Sensors belong to the
+ * first pass (the step's own mj_forward); joint damping is explicit here (no implicit-damping solve).  Every pass leaves
+ * its acceleration as the next pass's warm start, as ora_forward always does. */
+static void ora_step_rk4(const ora_model* m, ora_data* d) {
+  const int nv = m->nv, nq = m->nq;
+  const double h = m->timestep;
+  static const double Bw[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0}, Cn[3] = {0.5, 0.5, 1.0};
+  double* keep = (double*)malloc(sizeof(double) * (size_t)(nq + 4 * nv + m->nsensordata + 1));
+  double *x0q = keep, *x0v = x0q + nq, *accv = x0v + nv, *acca = accv + nv, *vtmp = acca + nv, *sens = vtmp + nv;
+  for (int stage = 0; stage < 4; stage++) {
+    ora_forward(m, d);
+    if (stage == 0) {
+      memcpy(x0q, d->qpos, sizeof(double) * (size_t)nq);
+      memcpy(x0v, d->qvel, sizeof(double) * (size_t)nv);
+      memcpy(sens, d->sensordata, sizeof(double) * (size_t)m->nsensordata);
+      for (int i = 0; i < nv; i++) { accv[i] = Bw[0] * d->qvel[i]; acca[i] = Bw[0] * d->qacc[i]; }
+    } else {
+      for (int i = 0; i < nv; i++) { accv[i] = accv[i] + Bw[stage] * d->qvel[i]; acca[i] = acca[i] + Bw[stage] * d->qacc[i]; }
+    }
+    if (stage < 3) {
+      const double c = Cn[stage];
+      for (int i = 0; i < nv; i++) { vtmp[i] = c * d->qvel[i]; d->qvel[i] = x0v[i] + h * (c * d->qacc[i]); }
+    } else {
+      for (int i = 0; i < nv; i++) { vtmp[i] = accv[i]; d->qvel[i] = x0v[i] + h * acca[i]; }
+    }
+    memcpy(d->qpos, x0q, sizeof(double) * (size_t)nq);
+    ora_integrate_pos(m, d->qpos, vtmp, h);
+  }
+  memcpy(d->sensordata, sens, sizeof(double) * (size_t)m->nsensordata);
+  d->time += h;
+  free(keep);
+}
+
 void ora_step(const ora_model* m, ora_data* d) {
+  if (m->integrator == 1) { ora_step_rk4(m, d); return; }
   int nv = m->nv;
   double h = m->timestep;
   ora_forward(m, d);

@@ -162,8 +162,10 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   mj::make_layout(m, l);
   std::vector<double> lds(l.total, 0.0);
   std::vector<double> inertia(m.nM > 0 ? m.nM : 1, 0.0);      // the per-copy HBM scratch of the real launch
+  std::vector<double> rk(m.nq + 3 * m.nv + 1, 0.0);           // and the Runge-Kutta scratch
   mj::StepArgs a{};
   a.inertia = inertia.data();
+  a.rk = rk.data();
   a.qpos = qpos; a.qvel = qvel; a.ctrl = ctrl; a.warm = warm; a.sensordata = sens; a.timestep = timestep;
   a.actions = actions; a.scatter = scatter; a.n_agent = n_agent; a.act_dim = act_dim; a.scatter_mode = scatter_mode;
   a.gather = gather; a.obs_dim = obs_dim; a.obs = obs;
@@ -176,9 +178,11 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   emu::cur_env = 0;
   // one frame per wave run, like the launches of launch_step in mjrl_capi.hip
   for (int s = 0; s < nsteps; s++) {
-    int launches = skip_frames > 0 ? skip_frames : 1;
+    const int passes = (m.integrator == 1 && !forward_only) ? 4 : 1;
+    int launches = skip_frames > 0 ? skip_frames * passes : 1;
     for (int f = 0; f < launches; f++) {
       mj::StepArgs b = a;
+      b.rk_stage = f % passes;
       b.skip_frames = skip_frames > 0 ? 1 : 0;
       b.more_frames = f < launches - 1;
       if (f > 0) b.scatter = nullptr;

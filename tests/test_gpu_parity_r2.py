@@ -553,3 +553,29 @@ def test_box_box_contacts_on_the_device():
         assert rel(h.get_field("qpos"), np.tile(ora.qpos, (3, 1))) < 1e-10
         h.close()
     assert touched > 10
+
+
+# --------------------------------------------------------------------------- Runge-Kutta integrator
+def test_rk4_level_through_the_c_abi():
+    """benchmarking/levels/Ant.xml (RK4, dt 0.01): four launches per physics frame, against the oracle's RK4 step; through
+    the env class with skipFrames 2."""
+    n_env = 5
+    env = MuJoCoRL({"xmlPath": levels.level_path("ant.xml"), "agents": ["torso"], "numEnvs": n_env, "skipFrames": 2})
+    assert env.agents_action_index == {"torso": [2, 3, 4, 5, 6, 7, 0, 1]} and env.observation_space("torso").shape == (29,)
+    env.reset()
+    oras = [OracleEnv(env._blob) for _ in range(n_env)]
+    rng = np.random.default_rng(4)
+    for step in range(80):
+        act = rng.uniform(-1, 1, (n_env, 8))
+        obs, rew, term, trunc, info = env.step({"torso": act})
+        for e, o in enumerate(oras):
+            o.ctrl[env.agents_action_index["torso"]] = act[e]
+            o.step(2)
+    assert max(o.ncon for o in oras) > 0
+    assert rel(env._handle.get_field("qpos"), np.stack([o.qpos for o in oras])) < 1e-9
+    assert rel(env._handle.get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
+    assert np.allclose(obs["torso"], np.stack([np.concatenate([o.qpos, o.qvel]) for o in oras]), atol=1e-8)
+    assert np.array_equal(env._handle.get_field("timestep"), np.full(n_env, 80, np.int32))
+    stats = env._handle.get_field("solver_stats")
+    assert np.array_equal(stats[:, 0], [o.ncon for o in oras]) and np.array_equal(stats[:, 2], [o.niter for o in oras])
+    env.close()
