@@ -59,20 +59,20 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
 }
 
 // Fixed body-mounted cameras as a ray caster (replaces mjv_updateScene + mjr_render + mjr_readPixels of
-// mujoco_parent.py:518-538 for the agent cameras).  One wave per env copy: body and geom frames from the current
-// qpos, then the lanes sweep the pixels of every camera; every lane tests the same geom at the same time, so the
-// geom-type switch is wave-uniform.  Camera convention of the reference's renderer: looks along -z, +x right, +y up,
-// vertical field of view fovy, rows stored bottom-up (glReadPixels order), uint8 RGB.
-__global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* qpos, int n_env, int width, int height,
-                                                         int tiles, unsigned char* rgb, const int* variant,
-                                                         const double* variant_rgba) {
-  // grid (n_env, ncam * tiles): a wave renders a group of 8x8 pixel blocks of one camera of one env copy -- with one
-  // wave per copy a batch of 512 copies (BASELINE config 5) left three quarters of the chip's wave slots empty.
-  // Every wave redoes the copy's kinematics.
+// mujoco_parent.py:518-538 for the agent cameras).  Camera convention of the reference's renderer: looks along -z, +x
+// right, +y up, vertical field of view fovy, rows stored bottom-up (glReadPixels order), uint8 RGB.
+//
+// Two kernels.  mjrl_camera_frames_kernel, one wave per env copy: body and geom frames from the current qpos (the step
+// kernel's kinematics), written as a scene row  [geom pos 3G | geom matrix 9G | camera pos 3C | camera matrix 9C]  to HBM.
+// mjrl_render_kernel, grid (n_env, ncam * tiles): a wave renders a group of 8x8 pixel blocks of one camera of one copy
+// from that row.  (Round 1 let every render wave redo the copy's kinematics behind the 20 KB step image: 16 tiles x 2
+// cameras repeated it 32 times per copy and the image held a CU to 7 waves.)
+inline __host__ __device__ int scene_doubles(const DevModel& m) { return 12 * m.ngeom + 12 * m.ncam; }
+
+__global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, const double* qpos, int n_env, double* scene) {
   extern __shared__ double lds[];
   using namespace mj;
   const int L = wv::lane(), env = blockIdx.x;
-  const int cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
   real* S = lds;
   Lay l;
   make_layout(m, l);
@@ -83,17 +83,39 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   wv::sync();
   stage_kinematics(m, l, K, S, L);
   stage_geoms(m, l, S, L);
-  // the geoms' rotation matrices, once per wave (behind the step image): the pixel loop reads them for every ray
-  real* GM = S + l.total;
+  double* out = scene + (size_t)env * scene_doubles(m);
   for (int g = L; g < m.ngeom; g += 64) {
+    st3(out + 3 * g, ld3(S + l.gpos + 3 * g));
     M3 gm = qmat(ldq(S + l.gquat + 4 * g));
-    for (int k = 0; k < 9; k++) GM[9 * g + k] = gm.m[k];
+    for (int k = 0; k < 9; k++) out[3 * m.ngeom + 9 * g + k] = gm.m[k];
   }
+  for (int cam = L; cam < m.ncam; cam += 64) {
+    const int body = m.cam_bodyid[cam];
+    const Quat bq = ldq(S + l.xquat + 4 * body);
+    st3(out + 12 * m.ngeom + 3 * cam, ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.cam_pos + 3 * cam)));
+    M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
+    for (int k = 0; k < 9; k++) out[12 * m.ngeom + 3 * m.ncam + 9 * cam + k] = cm.m[k];
+  }
+}
+
+__global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
+                                                         int tiles, unsigned char* rgb, const int* variant,
+                                                         const double* variant_rgba) {
+  extern __shared__ double lds[];
+  using namespace mj;
+  const int L = wv::lane(), env = blockIdx.x;
+  const int cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
+  // LDS: the copy's geom positions, matrices and sizes
+  real* GP = lds;
+  real* GM = lds + 3 * m.ngeom;
+  real* GS = lds + 12 * m.ngeom;
+  const double* row = scene + (size_t)env * scene_doubles(m);
+  for (int i = L; i < 12 * m.ngeom; i += 64) lds[i] = row[i];
+  for (int i = L; i < 3 * m.ngeom; i += 64) GS[i] = m.geom_size[i];
+  const V3 cp = ld3(row + 12 * m.ngeom + 3 * cam);
+  M3 cm;
+  for (int k = 0; k < 9; k++) cm.m[k] = row[12 * m.ngeom + 3 * m.ncam + 9 * cam + k];
   wv::sync();
-  const int body = m.cam_bodyid[cam];
-  const Quat bq = ldq(S + l.xquat + 4 * body);
-  const V3 cp = ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.cam_pos + 3 * cam));
-  const M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
   const real t = tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (real)width / (real)height;
   unsigned char* img = rgb + ((size_t)env * m.ncam + cam) * width * height * 3;
   // The wave's 64 rays cover an 8x8 block of pixels at a time.  Lane g first tests geom g's bounding sphere against the
@@ -110,7 +132,7 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   const bool my_geom = L < m.ngeom && rgba_of(L < m.ngeom ? L : 0, 3) != 0;
   const int my_type = my_geom ? m.geom_type[L] : -1;
   const real my_rb = my_geom ? m.geom_rbound[L] : 0.0;
-  const V3 my_rel = (my_geom ? ld3(S + l.gpos + 3 * L) : cp) - cp;
+  const V3 my_rel = (my_geom ? ld3(GP + 3 * L) : cp) - cp;
   for (int blk = blk0; blk < blk1; blk++) {
     const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 8;
     const V3 axis = pixel_ray(c0 + 4.0, r0 + 4.0);
@@ -144,17 +166,17 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
         if (d2 > rb * rb * (1.0 + 1e-9) + 1e-12 || along + rb < -1e-9) gt = -1;
       }
       if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
-      const V3 gp = ld3(S + l.gpos + 3 * g);
+      const V3 gp = ld3(GP + 3 * g);
       M3 gm;
       for (int k = 0; k < 9; k++) gm.m[k] = GM[9 * g + k];
-      real x = ray_geom(gt, gp, gm, ld3(S + l.gsize + 3 * g), cp, vec);
+      real x = ray_geom(gt, gp, gm, ld3(GS + 3 * g), cp, vec);
       if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
     }
     unsigned char out[3] = {0, 0, 0};
     if (hit >= 0) {
       M3 gm;
       for (int k = 0; k < 9; k++) gm.m[k] = GM[9 * hit + k];
-      V3 n = geom_normal(m.geom_type[hit], ld3(S + l.gpos + 3 * hit), gm, ld3(S + l.gsize + 3 * hit), cp + vec * best);
+      V3 n = geom_normal(m.geom_type[hit], ld3(GP + 3 * hit), gm, ld3(GS + 3 * hit), cp + vec * best);
       real shade = 0.4 + 0.6 * fmax(-dot(n, vec), 0.0);
       for (int k = 0; k < 3; k++)
         out[k] = (unsigned char)(255.0 * fmin(fmax(rgba_of(hit, k), 0.0), 1.0) * shade + 0.5);
@@ -163,8 +185,8 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   }
 }
 
-// the render kernel's LDS: the step image plus one rotation matrix per geom
-inline size_t render_lds_bytes(const mj::Lay& lay, const DevModel& m) { return ((size_t)lay.total + 9 * (size_t)m.ngeom) * sizeof(double); }
+// the ray kernel's LDS: geom positions, matrices and sizes
+inline size_t render_lds_bytes(const DevModel& m) { return 15 * (size_t)m.ngeom * sizeof(double); }
 
 std::string g_create_error;
 
@@ -183,6 +205,7 @@ struct mjrl_env {
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
   double* inertia = nullptr;       // [n_env][nM] scratch: the sparse inertia matrix between the CRB stage and the integrator
   unsigned long long* overflow = nullptr;   // [2] sticky cap-overflow counters (mjrl_cap_overflows)
+  double* scene = nullptr;         // [n_env][12 ngeom + 12 ncam] geom and camera frames of the camera kernels
   double* rk = nullptr;            // [n_env][nq + 3 nv] Runge-Kutta scratch (models with <option integrator="RK4">)
   int* stats = nullptr;            // [n_env][4] ncon, nefc, solver sweeps, warning bits of each copy's last physics frame
   int* timestep = nullptr;
@@ -269,7 +292,7 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia, e->overflow};
@@ -348,8 +371,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     CK(hipMalloc(&e->lpt_list[g], sizeof(int) * mj::LPT_BUCKETS * (size_t)n_env));
   }
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  CK(hipFuncSetAttribute((const void*)mjrl_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                         (int)render_lds_bytes(e->lay, m)));
+  CK(hipFuncSetAttribute((const void*)mjrl_camera_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 #undef CK
   // the reset image: reset every copy (zero warm start, as mj_resetData leaves it), run mj_forward once, keep copy 0's
   // warm start and sensor readings
@@ -983,15 +1005,17 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
   MJRL_ENTER(e);
   if (width <= 0 || height <= 0 || !d_rgb) MJRL_FAIL(e, 3, "render: bad arguments");
   if (e->hm.ncam == 0) MJRL_FAIL(e, 3, "render: the level has no cameras");
-  const size_t lds_bytes = render_lds_bytes(e->lay, e->hm);
-  // groups of 8x8 pixel blocks per camera: enough workgroups to fill the chip's wave slots a few times over, at
-  // least 4 blocks each (every workgroup repeats the copy's kinematics)
+  if (!e->scene) MJRL_HIP(e, hipMalloc(&e->scene, sizeof(double) * (size_t)e->n_env * scene_doubles(e->hm)));
+  hipLaunchKernelGGL(mjrl_camera_frames_kernel, dim3(e->n_env), dim3(64), (size_t)e->lay.total * sizeof(double), e->stream, e->dm,
+                     e->qpos, e->n_env, e->scene);
+  MJRL_HIP(e, hipGetLastError());
+  // groups of 8x8 pixel blocks per camera: enough workgroups to fill the chip's wave slots a few times over
   const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
-  const int target = 8 * 2048;       // (flat between 4 and 32 times the chip's 2048 wave slots, tools/render_rate.py)
+  const int target = 8 * 2048;
   int tiles = (int)((target + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
-  tiles = std::max(1, std::min(tiles, std::max(1, nblock / 4)));
-  hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), lds_bytes, e->stream, e->dm, e->qpos,
-                     e->n_env, width, height, tiles, d_rgb, e->variant, e->variant_rgba);
+  tiles = std::max(1, std::min(tiles, std::max(1, nblock / 2)));
+  hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), render_lds_bytes(e->hm), e->stream, e->dm,
+                     e->scene, e->n_env, width, height, tiles, d_rgb, e->variant, e->variant_rgba);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }

@@ -149,6 +149,10 @@ void emu_set_tags(const int32_t* adr, const int32_t* num, const int32_t* ref, in
   g_tag_adr = adr; g_tag_num = num; g_tag_ref = ref; g_env_base = env_base;
 }
 
+// longest-first dispatch tables of the following emu_step calls (launch_step's lpt_count_in / lpt_list_in); null: identity
+static const int *g_lpt_count = nullptr, *g_lpt_list = nullptr;
+void emu_set_lpt(const int* count_in, const int* list_in) { g_lpt_count = count_in; g_lpt_list = list_in; }
+
 // one env copy, `nsteps` step() calls with the same actions; state arrays are updated in place
 int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
              int* timestep, const double* actions, const int32_t* scatter, int n_agent, int act_dim, int scatter_mode,
@@ -172,6 +176,7 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.reward = reward; a.term = term; a.trunc = trunc;
   a.prog_i = prog_i; a.prog_f = prog_f; a.n_op = forward_only ? 0 : n_op; a.n_slot = n_slot;
   a.agent_body = agent_body; a.agent_obs_len = agent_obs_len; a.store = store;
+  a.lpt_count_in = g_lpt_count; a.lpt_list_in = g_lpt_list;
   a.tag_adr = g_tag_adr; a.tag_num = g_tag_num; a.tag_ref = g_tag_ref; a.env_base = g_env_base;
   a.max_steps = max_steps; a.n_env = 1;
   a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;

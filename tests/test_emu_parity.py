@@ -520,3 +520,26 @@ def test_target_and_pick_up_ops_follow_their_reference_dynamics():
             assert program["store"][a, 0] == store[a]["current_target"] and program["store"][a, 1] == store[a]["inventory"]
             assert np.isclose(program["store"][a, 2], store[a]["distance"], atol=1e-12)
     assert 4 <= toggles < 60
+
+
+def test_longest_first_lookup_and_a_short_bucket_list():
+    """The workgroup -> copy lookup of the longest-first dispatch: a workgroup finds its copy by walking the previous
+    launch's work buckets from the heaviest down; when the bucket counts do not cover the workgroup (they always sum to
+    n_env in launch_step -- this is the guard) the wave must leave without touching anything, not index with -1."""
+    from tests.emu.emu import lib, _p
+    model, ora, emu = pair("two_agent.xml")
+    counts = np.zeros(16, np.int32)
+    lists = np.full((16, 1), 0, np.int32)
+    counts[7] = 1                                     # the one copy sits in bucket 7
+    lib().emu_set_lpt(_p(counts), _p(lists))
+    try:
+        emu.step()
+        ora.step()
+        assert np.allclose(emu.qpos, ora.qpos, atol=1e-12) and emu.timestep[0] == 1
+        counts[:] = 0                                 # a list that does not cover workgroup 0
+        before = (emu.qpos.copy(), emu.qvel.copy(), emu.warm.copy(), emu.timestep.copy())
+        emu.step()
+        for was, now in zip(before, (emu.qpos, emu.qvel, emu.warm, emu.timestep)):
+            assert np.array_equal(was, now)
+    finally:
+        lib().emu_set_lpt(None, None)
