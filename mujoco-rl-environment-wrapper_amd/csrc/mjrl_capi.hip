@@ -9,6 +9,7 @@
 
 #include "../../include/mjrl.h"
 #include "mjrl_encoder.h"
+#include "mjrl_rayf.h"
 #include "mjrl_step.h"
 
 namespace {
@@ -98,95 +99,102 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
   }
 }
 
+// (Single precision: the kernel is bound by vector-instruction issue -- 93 M VALU instructions per 512 x 2 cameras,
+// profiles/r02_pmc_render.txt -- and fp32 issues at twice the fp64 rate.  The tests bound the pixels that may differ from
+// the oracle's fp64 ray caster.)
 __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
                                                          int tiles, unsigned char* rgb, const int* variant,
                                                          const double* variant_rgba) {
-  extern __shared__ double lds[];
+  extern __shared__ float ldsf[];
   using namespace mj;
   const int L = wv::lane(), env = blockIdx.x;
   const int cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
   // LDS: the copy's geom positions, matrices and sizes
-  real* GP = lds;
-  real* GM = lds + 3 * m.ngeom;
-  real* GS = lds + 12 * m.ngeom;
+  float* GP = ldsf;
+  float* GM = ldsf + 3 * m.ngeom;
+  float* GS = ldsf + 12 * m.ngeom;
   const double* row = scene + (size_t)env * scene_doubles(m);
-  for (int i = L; i < 12 * m.ngeom; i += 64) lds[i] = row[i];
-  for (int i = L; i < 3 * m.ngeom; i += 64) GS[i] = m.geom_size[i];
-  const V3 cp = ld3(row + 12 * m.ngeom + 3 * cam);
-  M3 cm;
-  for (int k = 0; k < 9; k++) cm.m[k] = row[12 * m.ngeom + 3 * m.ncam + 9 * cam + k];
+  for (int i = L; i < 12 * m.ngeom; i += 64) ldsf[i] = (float)row[i];
+  for (int i = L; i < 3 * m.ngeom; i += 64) GS[i] = (float)m.geom_size[i];
+  // the camera, and every geom's position relative to it (the subtraction in double: positions are metres from the
+  // arena's origin, differences are what the rays see)
+  const double cpx = row[12 * m.ngeom + 3 * cam], cpy = row[12 * m.ngeom + 3 * cam + 1], cpz = row[12 * m.ngeom + 3 * cam + 2];
+  float cm[9];
+  for (int k = 0; k < 9; k++) cm[k] = (float)row[12 * m.ngeom + 3 * m.ncam + 9 * cam + k];
   wv::sync();
-  const real t = tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (real)width / (real)height;
+  for (int g = L; g < m.ngeom; g += 64) {       // camera-relative positions
+    GP[3 * g] = (float)(row[3 * g] - cpx); GP[3 * g + 1] = (float)(row[3 * g + 1] - cpy); GP[3 * g + 2] = (float)(row[3 * g + 2] - cpz);
+  }
+  wv::sync();
+  const F3 origin = f3(0, 0, 0);
+  const float t = (float)tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (float)width / (float)height;
+  const float inv_w = 2.0f / (float)width, inv_h = 2.0f / (float)height;
   unsigned char* img = rgb + ((size_t)env * m.ncam + cam) * width * height * 3;
   // The wave's 64 rays cover an 8x8 block of pixels at a time.  Lane g first tests geom g's bounding sphere against the
   // block's bounding cone (all geoms at once); the rays then visit only the geoms that passed, each ray with its own
-  // bounding-sphere test (the same conservative one as the rangefinder's, stage_sensors) before the type-specific one.
+  // bounding-sphere test before the type-specific one.  Both tests are conservative (they may pass a geom the ray misses).
   const int bw = (width + 7) / 8, nblock = bw * ((height + 7) / 8);
   const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
-  auto pixel_ray = [&](real px, real py) {        // px, py in pixel units, pixel centres at +0.5
-    return normalized(mul(cm, v3((2.0 * px / width - 1.0) * t * aspect, (2.0 * py / height - 1.0) * t, -1.0)), 0);
+  auto pixel_ray = [&](float px, float py) {        // px, py in pixel units, pixel centres at +0.5
+    return normalizedf(mulf(cm, f3((px * inv_w - 1.0f) * t * aspect, (py * inv_h - 1.0f) * t, -1.0f)));
   };
   // the copy's colours: its level variant's (mjrl_set_variants), else the model's
   const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
-  auto rgba_of = [&](int g, int k) { return rgba_tab ? rgba_tab[4 * g + k] : (double)m.geom_rgba[4 * g + k]; };
+  auto rgba_of = [&](int g, int k) { return (float)(rgba_tab ? rgba_tab[4 * g + k] : (double)m.geom_rgba[4 * g + k]); };
   const bool my_geom = L < m.ngeom && rgba_of(L < m.ngeom ? L : 0, 3) != 0;
   const int my_type = my_geom ? m.geom_type[L] : -1;
-  const real my_rb = my_geom ? m.geom_rbound[L] : 0.0;
-  const V3 my_rel = (my_geom ? ld3(GP + 3 * L) : cp) - cp;
+  const float my_rb = my_geom ? (float)m.geom_rbound[L] * (1.0f + 1e-5f) + 1e-5f : 0.0f;     // (rounded up)
+  const F3 my_rel = my_geom ? ldf3(GP + 3 * L) : origin;
   for (int blk = blk0; blk < blk1; blk++) {
     const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 8;
-    const V3 axis = pixel_ray(c0 + 4.0, r0 + 4.0);
-    real cosmin = 1.0;
+    const F3 axis = pixel_ray(c0 + 4.0f, r0 + 4.0f);
+    float cosmin = 1.0f;
     for (int k = 0; k < 4; k++)
-      cosmin = fmin(cosmin, dot(axis, pixel_ray(c0 + ((k & 1) ? 7.5 : 0.5), r0 + ((k & 2) ? 7.5 : 0.5))));
-    const real cos_t = cosmin * (1.0 - 1e-9) - 1e-12, sin_t = sqrt(fmax(1.0 - cos_t * cos_t, 0.0));
+      cosmin = fminf(cosmin, dotf(axis, pixel_ray(c0 + ((k & 1) ? 7.5f : 0.5f), r0 + ((k & 2) ? 7.5f : 0.5f))));
+    const float cos_t = cosmin * (1.0f - 1e-5f) - 1e-6f, sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.0f));
     bool cand = my_geom;
     if (my_geom && my_type != GEOM_PLANE) {
-      const real along = dot(my_rel, axis), perp = sqrt(fmax(dot(my_rel, my_rel) - along * along, 0.0));
+      const float along = dotf(my_rel, axis), perp = sqrtf(fmaxf(dotf(my_rel, my_rel) - along * along, 0.0f));
       // (perp cos - along sin is a lower bound of the centre's distance to the cone, negative inside it)
-      cand = !(along + my_rb < -1e-9) && perp * cos_t - along * sin_t <= my_rb * (1.0 + 1e-9) + 1e-9;
+      cand = !(along + my_rb < 0.0f) && perp * cos_t - along * sin_t <= my_rb + 1e-5f * (1.0f + perp);
     }
     unsigned long long todo = wv::ballot(cand);
     const int r = r0 + (L >> 3), c = c0 + (L & 7);
     const bool inside = r < height && c < width;
     const int pix = r * width + c;
-    const V3 vec = pixel_ray(c + 0.5, r + 0.5);
-    real best = -1;
+    const F3 vec = pixel_ray(c + 0.5f, r + 0.5f);
+    float best = -1;
     int hit = -1;
     while (todo) {
       const int g = __builtin_ctzll(todo);
       todo &= todo - 1;
       // (geom g's type, bounding radius and position come from lane g's registers: no memory latency per candidate)
       int gt = wv::lane_int(my_type, g);
-      const V3 rel = v3(wv::lane_value(my_rel.x, g), wv::lane_value(my_rel.y, g), wv::lane_value(my_rel.z, g));
+      const F3 rel = f3(__int_as_float(wv::lane_int(__float_as_int(my_rel.x), g)), __int_as_float(wv::lane_int(__float_as_int(my_rel.y), g)),
+                        __int_as_float(wv::lane_int(__float_as_int(my_rel.z), g)));
       if (!inside) gt = -1;
       else if (gt != GEOM_PLANE) {
-        const real rb = wv::lane_value(my_rb, g);
-        real along = dot(rel, vec), d2 = dot(rel, rel) - along * along;
-        if (d2 > rb * rb * (1.0 + 1e-9) + 1e-12 || along + rb < -1e-9) gt = -1;
+        const float rb = __int_as_float(wv::lane_int(__float_as_int(my_rb), g));
+        const float along = dotf(rel, vec), d2 = dotf(rel, rel) - along * along;
+        if (d2 > rb * rb + 1e-5f * (1.0f + dotf(rel, rel)) || along + rb < 0.0f) gt = -1;
       }
       if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
-      const V3 gp = ld3(GP + 3 * g);
-      M3 gm;
-      for (int k = 0; k < 9; k++) gm.m[k] = GM[9 * g + k];
-      real x = ray_geom(gt, gp, gm, ld3(GS + 3 * g), cp, vec);
+      const float x = ray_geomf(gt, rel, GM + 9 * g, ldf3(GS + 3 * g), origin, vec);
       if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
     }
     unsigned char out[3] = {0, 0, 0};
     if (hit >= 0) {
-      M3 gm;
-      for (int k = 0; k < 9; k++) gm.m[k] = GM[9 * hit + k];
-      V3 n = geom_normal(m.geom_type[hit], ld3(GP + 3 * hit), gm, ld3(GS + 3 * hit), cp + vec * best);
-      real shade = 0.4 + 0.6 * fmax(-dot(n, vec), 0.0);
+      const F3 n = geom_normalf(m.geom_type[hit], ldf3(GP + 3 * hit), GM + 9 * hit, ldf3(GS + 3 * hit), vec * best);
+      const float shade = 0.4f + 0.6f * fmaxf(-dotf(n, vec), 0.0f);
       for (int k = 0; k < 3; k++)
-        out[k] = (unsigned char)(255.0 * fmin(fmax(rgba_of(hit, k), 0.0), 1.0) * shade + 0.5);
+        out[k] = (unsigned char)(255.0f * fminf(fmaxf(rgba_of(hit, k), 0.0f), 1.0f) * shade + 0.5f);
     }
     if (inside) { img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2]; }
   }
 }
 
 // the ray kernel's LDS: geom positions, matrices and sizes
-inline size_t render_lds_bytes(const DevModel& m) { return 15 * (size_t)m.ngeom * sizeof(double); }
+inline size_t render_lds_bytes(const DevModel& m) { return 15 * (size_t)m.ngeom * sizeof(float); }
 
 std::string g_create_error;
 
