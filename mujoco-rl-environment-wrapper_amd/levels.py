@@ -238,8 +238,11 @@ def level_path(name: str) -> str:
     path = os.path.join(_CACHE_DIR, name)
     text = LEVELS[name]()
     if not os.path.exists(path) or open(path).read() != text:
-        with open(path, "w") as fh:
+        # (atomic: several ranks of a multi-GPU run may get here at once, and a reader must never see half a file)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as fh:
             fh.write(text)
+        os.replace(tmp, path)
     return path
 
 

@@ -115,3 +115,25 @@ def test_counter_based_choices_are_reproducible_and_spread():
     picks = dynamics.pick_of(z, 3)
     assert set(picks) == {0, 1, 2} and abs(np.bincount(picks) - 4096 / 3).max() < 150
     assert not np.array_equal(picks, dynamics.pick_of(dynamics.mix64(7, np.arange(4096), 1, 33, 1), 3))
+
+
+def test_levels_that_differ_in_colours_only_are_one_model(tmp_path):
+    """Testing/levels/Model2-10.xml differ in the boxes' rgba only.  Such an xmlPath list is one model
+    plus colour variants (blob.same_physics); a transparent geom is not a colour change (rangefinders ignore it), and a
+    moved wall is another model."""
+    text = open(levels.level_path("two_agent.xml")).read()
+    base = blob.pack(mjcf.compile_mjcf_string(text))
+    recoloured = blob.pack(mjcf.compile_mjcf_string(text.replace('rgba="0 .9 0 1"', 'rgba="0.9 0 0.2 1"')))
+    transparent = blob.pack(mjcf.compile_mjcf_string(text.replace('rgba="0 .9 0 1" name="border1_geom"', 'rgba="0 .9 0 0" name="border1_geom"')))
+    moved = blob.pack(mjcf.compile_mjcf_string(text.replace('pos="7.02852 -2.071592 0.4710507"', 'pos="6.5 -2.071592 0.4710507"')))
+    assert base != recoloured and blob.same_physics(base, recoloured)
+    assert not blob.same_physics(base, transparent) and not blob.same_physics(base, moved)
+    assert not blob.same_physics(base, blob.pack(mjcf.compile_mjcf(levels.level_path("two_agent_2sensors.xml"))))
+    lo, hi = blob.section_range(base, "geom_rgba")
+    assert hi - lo == 8 * 4 * 35 and base[:lo] == recoloured[:lo] and base[hi:] == recoloured[hi:]
+    # the reference's own variants, when the tree is there
+    ref = "/root/reference/Testing/levels"
+    if os.path.isdir(ref):
+        packed = [blob.pack(mjcf.compile_mjcf(os.path.join(ref, f"Model{k}.xml"))) for k in (2, 3, 7, 10)]
+        assert all(blob.same_physics(packed[0], other) for other in packed[1:])
+        assert len({bytes(p) for p in packed}) > 1
