@@ -9,8 +9,9 @@
 //                              [32 ch] from the uint8 image staged in LDS, its output (32x32x32 bf16, 64 KB) kept in
 //                              LDS; conv2 as 9 taps x ([256 px] x [32] x [64 ch]) reading 16-byte channel runs of that
 //                              LDS image; output 16x16x64 bf16 in flatten order (h, w, c) to HBM.
-//   mjrl_encoder_dense_kernel  [n_img] x [16384] x [latent]: one wave per 16 images x 16 latent columns; bias, relu,
-//                              fp32 latents and, when asked, their scatter into the observation rows (float64).
+//   mjrl_encoder_dense_kernel  [n_img] x [16384] x [latent]: a workgroup of 8 waves per 16 images x 16 latent columns,
+//                              K split eight ways and summed through LDS; bias, relu, fp32 latents and, when asked,
+//                              their scatter into the observation rows (float64).
 // Weight fragments are packed on the host in the lane order of the MFMA operands (lane l holds B[k = 8 (l >> 4) + j]
 // [col = l & 15], j = 0..7), so a lane's fragment is one 16-byte load.
 #ifndef MJRL_ENCODER_H

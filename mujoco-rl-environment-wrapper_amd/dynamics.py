@@ -11,6 +11,11 @@ tests/test_gpu_parity.py.
 * ``TargetDistanceReward`` -- negative distance, or distance decrease since the last step, between the agent's body and a
   named body / geom (the target-seeking reward of the reference's tutorial notebook and Testing/EnvironmentDynamic.py).
 * ``TargetReached``       -- done when that distance falls below a threshold.
+* ``TargetDynamic``       -- target switching among the objects that carry a tag of the info JSON
+  (Testing/EnvironmentDynamic.py:17-32); ``PickUpDynamic`` -- the same with the inventory toggle and reward of
+  Testing/Pick_Up_Dynamic.py:15-41.  The two reward / done classes above also take ``current_target_of=<tag>``: the
+  agent's current target (Testing/SingleAgentTest.py:41-48).  Random choices come from ``mix64``, the counter-based
+  generator the device uses, so the host loop and the fused ops draw the same targets.
 """
 from __future__ import annotations
 
