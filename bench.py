@@ -44,6 +44,9 @@ WORKLOADS = {
     "four_agent": dict(level="four_agent.xml", agents=["sender", "receiver", "agent_3", "agent_4"],
                        what="4-agent contact-heavy arena (four_agent.xml: the 2-agent arena with the ant instantiated four "
                             "times, SURVEY 8d config 4; no such level ships with the reference)"),
+    # BASELINE config 5: every step also ray-casts both agent cameras (64x64x3 uint8 each) into HBM; 512 copies
+    "camera": dict(level="two_agent.xml", agents=["sender", "receiver"], cameras=True, envs=512,
+                   what="2-agent ant arena + both agent cameras (64x64x3 uint8 each, ray cast) per step, BASELINE config 5"),
 }
 
 
@@ -159,12 +162,15 @@ def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seco
 class DeviceBatch:
     """The product path: ``MuJoCoRL`` over libmjrl_hip.so, tensors resident in HBM."""
 
-    def __init__(self, torch, dev, level_file, agents, n_env, plugins, args, stream):
+    def __init__(self, torch, dev, level_file, agents, n_env, plugins, args, stream, cameras=False):
         from mjrl_amd.mujoco_rl import MuJoCoRL
         self.torch, self.dev = torch, dev
         self.env = MuJoCoRL({"xmlPath": level_file, "agents": agents, "numEnvs": n_env, "deviceId": dev.index,
                              "skipFrames": 1, "maxSteps": EPISODE, "environmentDynamics": plugins,
-                             "nconmax": args.nconmax, "njmax": args.njmax})
+                             "nconmax": args.nconmax, "njmax": args.njmax, "agentCameras": cameras})
+        self.rgb = None
+        if cameras:          # the images of every step land here (get_camera_data's content, kept in HBM)
+            self.rgb = torch.empty((n_env, self.env._handle.size("ncam"), 64, 64, 3), dtype=torch.uint8, device=dev)
         self.stream = stream
         self.env.set_stream(stream.cuda_stream)
         self.env.reset_batched()
@@ -190,6 +196,8 @@ class DeviceBatch:
     def step_batched(self, actions, obs, reward, term, trunc):
         with self.torch.cuda.stream(self.stream):
             self.env.step_batched(actions, obs, reward, term, trunc)
+            if self.rgb is not None:
+                self.env._handle.render(64, 64, d_rgb=self.rgb.data_ptr())
 
     def solver_stats(self):
         return self.env._handle.get_field("solver_stats")
@@ -251,7 +259,7 @@ def parse_args(argv=None):
     ap.add_argument("--level", choices=sorted(WORKLOADS), default="two_agent")
     ap.add_argument("--nconmax", type=int, default=None, help="contact cap per env copy (default: the compiler's)")
     ap.add_argument("--njmax", type=int, default=None, help="constraint-row cap per env copy (default: the compiler's)")
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="env copies per GPU (default 4096; 512 for --level camera)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--groups", type=int, default=1,
                     help="step the batch as this many independent groups on their own streams (1 = lockstep, the headline)")
@@ -310,9 +318,12 @@ def main():
 
     work = WORKLOADS[args.level]
     agents, level_file = work["agents"], levels.level_path(work["level"])
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = work.get("envs", ENVS_PER_GPU)
+    cameras = bool(work.get("cameras"))
     n_env, n_agent = args.envs_per_gpu, len(agents)
     # the Language channel is a 2-agent dynamic (README.md:109-136)
-    plugins = [Language] if (n_agent == 2 and not args.no_language) else []
+    plugins = [Language] if (n_agent == 2 and not args.no_language and not cameras) else []
 
     def barrier():
         if world > 1:
@@ -328,7 +339,7 @@ def main():
                 batch = RehearsalBatch(level_file, agents, per, bool(plugins))
             else:
                 stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
-                batch = DeviceBatch(torch, dev, level_file, agents, per, plugins, args, stream)
+                batch = DeviceBatch(torch, dev, level_file, agents, per, plugins, args, stream, cameras=cameras)
             n_phys = max(len(batch.agents_action_index[a]) for a in agents)
             act_dim = n_phys + len(plugins)
             first = rank * n_env + g * per
@@ -406,13 +417,15 @@ def main():
         m = batch.model
         bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * obs_dim, n_agent,
                                                    n_slot=len(plugins))
+        if cameras:                             # + the pixels written per env-step
+            bytes_per += m.ncam * 64 * 64 * 3
         if kernel_ms is None:                 # several groups / no GPU: the step time is the wall time's
             kernel_ms = wall / args.steps * 1e3
         achieved = bytes_per * n_env / (kernel_ms * 1e-3) / 1e9
         traffic = None
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
         pmc = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{args.level}.json")
-        if os.path.exists(pmc) and n_env == ENVS_PER_GPU and not on_cpu:
+        if os.path.exists(pmc) and n_env == work.get("envs", ENVS_PER_GPU) and not on_cpu:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
             "metric": "env-steps/sec", "value": n_env * world * args.steps / wall, "unit": "env-steps/s",
@@ -433,7 +446,8 @@ def main():
                        "cap_overflow_frames": list(overflows), "groups": args.groups},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": batch.kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
+                         "kernel": batch.kernel + (" + mjrl_camera_frames_kernel + mjrl_render_kernel" if cameras else ""),
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
         }
         if double_buffered:
             line["double_buffered"] = double_buffered

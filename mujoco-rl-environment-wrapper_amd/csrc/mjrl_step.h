@@ -656,11 +656,14 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
       int g1 = word & 255, g2 = (word >> 8) & 255, t1 = (word >> 16) & 15, t2 = (word >> 20) & 15;
       V3 dif = ld3(S + l.gpos + 3 * g2) - ld3(S + l.gpos + 3 * g1);
       bool pass;
+      // (bit 24 of the word: the frame this test needs is the identity rotation for good -- the arena's floor and walls --,
+      // so its matrix is neither built nor applied; with an exact identity the general form gives the same bits)
+      const bool fixed = (word >> 24) & 1;
       if (t1 == GEOM_PLANE) {
-        pass = !(dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2)) > bound);
+        pass = !((fixed ? dif.z : dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2))) > bound);
       } else if (t2 == GEOM_BOX && t1 != GEOM_BOX) {
         // geom1's bounding sphere against the box itself: a long wall's bounding sphere would cover the whole arena
-        V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
+        V3 loc = fixed ? dif * -1.0 : mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
         real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
         pass = !(ex * ex + ey * ey + ez * ez > bound * bound);
       } else if (m.pair_kmax >= 16 && t1 == GEOM_BOX && t2 == GEOM_BOX) {

@@ -796,7 +796,28 @@ def _kernel_schedules(m: Model, lane_map: bool = True):
     # (rounded up: the broad phase only has to be conservative)
     pg = A["pair_geom"]
     gt = A["geom_type"]
-    A["pair_word"] = np.array([int(a) | (int(b) << 8) | (int(gt[a]) << 16) | (int(gt[b]) << 20) for a, b in pg], np.int32)
+    # bit 24: the geom whose FRAME the broad-phase test needs (the plane of a plane pair, the box of a sphere|capsule-box
+    # pair) never rotates and has the identity orientation -- a static body chain and a geom with exactly identity
+    # quaternions (the arena's floor and walls).  Its rotation matrix is then exactly the identity and the test skips
+    # building and applying it; the results are the same bits.
+    ident = np.array([1.0, 0.0, 0.0, 0.0])
+    def fixed_identity(g):
+        b = int(A["geom_bodyid"][g])
+        if not np.array_equal(A["geom_quat"][g], ident):
+            return False
+        while b > 0:
+            if m.body_jntnum[b] > 0 or not np.array_equal(m.body_quat[b], ident):
+                return False
+            b = int(m.body_parentid[b])
+        return True
+    def frame_flag(a, b):
+        if gt[a] == GEOM_PLANE:
+            return fixed_identity(a)
+        if gt[b] == GEOM_BOX and gt[a] != GEOM_BOX:
+            return fixed_identity(b)
+        return False
+    A["pair_word"] = np.array([int(a) | (int(b) << 8) | (int(gt[a]) << 16) | (int(gt[b]) << 20) | (int(frame_flag(a, b)) << 24)
+                               for a, b in pg], np.int32)
     A["pair_reach"] = (np.nextafter(A["pair_bound"].astype(np.float32), np.float32(np.inf))).view(np.int32) \
         if len(pg) else np.zeros(0, np.int32)
 

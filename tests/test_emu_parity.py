@@ -543,3 +543,28 @@ def test_longest_first_lookup_and_a_short_bucket_list():
             assert np.array_equal(was, now)
     finally:
         lib().emu_set_lpt(None, None)
+
+
+def test_fixed_identity_frames_in_the_broad_phase_give_the_same_bits():
+    """Pairs whose broad-phase test needs the frame of a geom that never rotates and has the identity orientation (the
+    arena's floor and walls; bit 24 of the pair word) skip building and applying that rotation matrix.  With an exact
+    identity the general form computes the same bits: a model with the flags cleared steps to the identical state."""
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    flagged = int(((model.pair_word >> 24) & 1).sum())
+    assert flagged > 200                                        # every ant geom against the floor and the eight boxes
+    plain = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    plain.arrays["pair_word"] = (plain.pair_word & 0x00FFFFFF).astype(np.int32)
+    a, b = EmuEnv(model, blob.pack(model)), EmuEnv(plain, blob.pack(plain))
+    rng = np.random.default_rng(12)
+    for env in (a, b):
+        env.step(forward_only=True)
+    most = 0
+    for _ in range(260):
+        ctrl = rng.uniform(-1, 1, model.nu)
+        a.ctrl[:model.nu] = ctrl
+        b.ctrl[:model.nu] = ctrl
+        most = max(most, a.step().ncon)
+        b.step()
+    assert most > 0
+    for name in ("qpos", "qvel", "warm", "sens"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
