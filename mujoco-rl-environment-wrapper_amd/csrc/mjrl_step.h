@@ -1229,17 +1229,10 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
     f_start = fi; s_start = sr;
     real ns = -sr, nss = ns;                 // negated residual: a row step is max, broadcast, multiply-add (see stage_pgs)
     const real nf = -fi;
-    if (pending) {                           // the stop test of the sweep before (see stage_pgs: one deciding row spares the sum)
-      const bool decided = wv::ballot(c_prev > 1e-10) == 0ull && wv::ballot((-c_prev - 1e-8) * scale >= m.tolerance) != 0ull;
-      if (!decided) {
-        const real improvement = wv::rows4_sum(wv::sum16(-c_prev));
-        if (wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
-          if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
-          pending = false;
-          break;
-        }
-      }
-    }
+    // the stop test of the sweep before (see stage_pgs): the two lane masks are formed here, the branch on them comes
+    // after the first two row steps, whose work covers the vector-to-scalar latency
+    unsigned long long refused = 0ull, deciding = 1ull;
+    if (pending) { refused = wv::ballot(c_prev > 1e-10); deciding = wv::ballot((-c_prev - 1e-8) * scale >= m.tolerance); }
 #define MJ_FSTEP(KK)                                                                  \
       {                                                                               \
         real db = wide_bcast<KK>(fmax(ns, nf));                                       \
@@ -1247,6 +1240,15 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
         ns -= A[KK] * db;                                                             \
       }
     MJ_FSTEP(0) MJ_FSTEP(1)
+    if (pending && (refused != 0ull || deciding == 0ull)) {
+      const real improvement = wv::rows4_sum(wv::sum16(-c_prev));
+      if (refused != 0ull || wv::ballot(improvement * scale < m.tolerance)) {
+        if (refused != 0ull) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
+        else { sr = s_start; }
+        pending = false;
+        break;
+      }
+    }
     MJ_FSTEP(2) MJ_FSTEP(3) MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7) MJ_FSTEP(8) MJ_FSTEP(9)
     MJ_FSTEP(10) MJ_FSTEP(11) MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
     MJ_FSTEP(16) MJ_FSTEP(17) MJ_FSTEP(18) MJ_FSTEP(19)
@@ -1662,17 +1664,10 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       // already decides "not converged", and that is what nearly every sweep of a long solve looks like: two compares
       // and a scalar test, the sum only when no single row decides.  The sum, the branch and the sweep count are the
       // reference's.
-      if (pending) {
-        const bool decided = wv::ballot(c_prev > 1e-10) == 0ull && wv::ballot((-c_prev - 1e-8) * scale >= m.tolerance) != 0ull;
-        if (!decided) {
-          const real improvement = wv::rows_sum(wv::sum16(-c_prev), m.ntree);
-          if (wv::ballot(c_prev > 1e-10 || improvement * scale < m.tolerance)) {
-            if (wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
-            pending = false;                                                                        // (else: it had converged)
-            break;
-          }
-        }
-      }
+      // (the two lane masks are formed here; the branch on them comes after the first two row steps, whose work covers
+      // the vector-to-scalar latency -- when the sweep before turns out to have converged those two steps are dropped)
+      unsigned long long refused = 0ull, deciding = 1ull;
+      if (pending) { refused = wv::ballot(c_prev > 1e-10); deciding = wv::ballot((-c_prev - 1e-8) * scale >= m.tolerance); }
 #define MJ_FSTEP(KK)                                                                  \
         {                                                                             \
           real db = wv::bcast16<KK>(fmax(ns, nf));                                    \
@@ -1680,6 +1675,15 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
           ns -= A[KK] * db;                                                           \
         }
       MJ_FSTEP(0) MJ_FSTEP(1)
+      if (pending && (refused != 0ull || deciding == 0ull)) {
+        const real improvement = wv::rows_sum(wv::sum16(-c_prev), m.ntree);
+        if (refused != 0ull || wv::ballot(improvement * scale < m.tolerance)) {
+          if (refused != 0ull) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
+          else { sr = s_start; }                                                       // it had converged
+          pending = false;
+          break;
+        }
+      }
       do {
         if (2 >= tmax_s) break;
         MJ_FSTEP(2) MJ_FSTEP(3)
