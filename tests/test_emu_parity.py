@@ -568,3 +568,42 @@ def test_fixed_identity_frames_in_the_broad_phase_give_the_same_bits():
     assert most > 0
     for name in ("qpos", "qvel", "warm", "sens"):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_in_launch_reset_with_several_frames_per_step():
+    """skipFrames > 1: only the first launch of the step loads the reset image; the later frames continue from it, and
+    the step counter, the data store and the fused program see a fresh episode."""
+    model, ora, emu = pair("two_agent.xml")
+    reset_warm = emu.warm.copy()
+    rng = np.random.default_rng(9)
+    scatter = np.array([[2, 3, 4, 5, 6, 7, 0, 1, -1], [10, 11, 12, 13, 14, 15, 8, 9, -1]], np.int32)
+    gather = np.full((2, 60), -1, np.int32)
+    for a in range(2):
+        gather[a, 0] = a
+        gather[a, 1:31] = (1 << 24) | np.arange(30)
+        gather[a, 31:59] = (2 << 24) | np.arange(28)
+        gather[a, 59] = -2
+    bodies = np.array([model.names["body"].index("sender"), model.names["body"].index("receiver")], np.int32)
+
+    def program(store):
+        return dict(prog_i=np.array([[1, 8, 0, 0, 0, 0, 0, 0]], np.int32), prog_f=np.zeros((1, 4)), n_slot=1, agent_body=bodies,
+                    agent_obs_len=np.array([59, 59], np.int32), store=store, reward=np.zeros(2), term=np.zeros(2, np.uint8),
+                    trunc=np.zeros(2, np.uint8))
+    store = np.full((2, 1), np.nan)
+    obs = np.zeros((2, 60))
+    for _ in range(25):
+        emu.step(actions=np.concatenate([rng.uniform(-1, 1, (2, 8)), rng.uniform(0, 3, (2, 1))], axis=1), scatter=scatter,
+                 n_agent=2, gather=gather, obs=obs, program=program(store), skip_frames=3)
+    assert emu.timestep[0] == 25 and not np.isnan(store).any()
+    actions = np.concatenate([rng.uniform(-1, 1, (2, 8)), [[2.4], [1.7]]], axis=1)
+    store[:] = np.nan                                  # (the emulation's reset flag covers the state; the store row is the caller's)
+    emu.step(actions=actions, scatter=scatter, n_agent=2, gather=gather, obs=obs, program=program(store), skip_frames=3,
+             reset_warm=reset_warm)
+    _, _, fresh = pair("two_agent.xml")
+    store2, obs2 = np.full((2, 1), np.nan), np.zeros((2, 60))
+    fresh.step(actions=actions, scatter=scatter, n_agent=2, gather=gather, obs=obs2, program=program(store2), skip_frames=3)
+    assert emu.timestep[0] == 1
+    for name in ("qpos", "qvel", "ctrl", "warm", "sens"):
+        assert np.array_equal(getattr(emu, name), getattr(fresh, name)), name
+    assert np.array_equal(obs, obs2) and np.array_equal(store, store2)
+    assert obs[0, 59] == 0 and obs[1, 59] == 2         # a fresh episode: the sender has heard nothing yet

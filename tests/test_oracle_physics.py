@@ -207,3 +207,74 @@ def test_accelerometer_reads_zero_in_free_fall_and_g_at_rest():
     env.qvel[:] = 0
     env.step(1500)
     assert np.allclose(env.sensordata[:3], [0, 0, 9.81], atol=1e-3)  # at rest the floor pushes up with g
+
+
+def _incline(theta_deg, mu):
+    """A box on a plane with gravity tilted by theta about y (the same thing as a slope of angle theta)."""
+    th = np.deg2rad(theta_deg)
+    return f"""
+<mujoco><option timestep="0.002" gravity="{9.81 * np.sin(th)} 0 {-9.81 * np.cos(th)}"/><worldbody>
+  <geom type="plane" size="50 50 0.1" friction="{mu} 0.005 0.0001"/>
+  <body name="block" pos="0 0 0.1"><joint type="free" name="root"/>
+    <geom type="box" size="0.2 0.2 0.1" density="1000" friction="{mu} 0.005 0.0001"/></body>
+</worldbody></mujoco>"""
+
+
+def test_coulomb_friction_holds_below_the_friction_angle_and_slides_above_it():
+    """Known answer of dry friction (pyramidal cone, slope along a pyramid axis): below tan(theta) = mu the block stays
+    (a soft-constraint solver lets it creep, orders of magnitude slower than free sliding); above it the block
+    accelerates with g (sin(theta) - mu cos(theta))."""
+    mu = 0.5
+    model, env = make(_incline(20.0, mu))                 # tan 20 deg = 0.364 < 0.5
+    env.step(1500)
+    assert env.ncon == 4
+    v_hold = env.qvel[0]
+    free_fall_speed = 9.81 * np.sin(np.deg2rad(20.0)) * 3.0
+    assert abs(v_hold) < 2e-3 * free_fall_speed
+    theta = 35.0                                          # tan 35 deg = 0.700 > 0.5
+    model, env = make(_incline(theta, mu))
+    env.step(500)                                         # settle onto the plane while sliding
+    v0 = env.qvel[0]
+    normal = []
+    for _ in range(500):
+        env.step()
+        normal.append(sum(c["normal_force"] for c in env.contacts()))
+    accel = (env.qvel[0] - v0) / (500 * 0.002)
+    expect = 9.81 * (np.sin(np.deg2rad(theta)) - mu * np.cos(np.deg2rad(theta)))
+    assert accel == pytest.approx(expect, rel=2e-2)
+    # (the sliding block chatters on its leading edge; on average the plane carries the normal component of its weight)
+    assert np.mean(normal) == pytest.approx(model.body_mass[1] * 9.81 * np.cos(np.deg2rad(theta)), rel=5e-2)
+
+
+def test_soft_contact_rests_at_the_depth_its_reference_acceleration_dictates():
+    """MuJoCo's soft-constraint model in closed form for one frictionless normal row at rest: the reference acceleration
+    aref = -k d (pos - margin) - b v with k = 1 / (dmax^2 tc^2 dr^2), and force f = (aref - a0) / (A + R) with a0 = -g the
+    unconstrained acceleration along the normal, A = 1 / m, R = (1 - d) / d * diagApprox.  At rest f = m g, so the
+    penetration follows from the numbers in the model (solref 0.02 1, solimp 0.9 0.95 0.001 0.5 2)."""
+    xml = """
+<mujoco><option timestep="0.002"/><worldbody>
+  <geom type="plane" size="5 5 0.1" condim="1"/>
+  <body name="ball" pos="0 0 0.1"><joint type="free" name="root"/><geom type="sphere" size="0.1" density="1000" condim="1"/></body>
+</worldbody></mujoco>"""
+    model, env = make(xml)
+    env.step(3000)
+    assert env.ncon == 1 and env.nefc == 1 and abs(env.qvel[2]) < 1e-7
+    pen = -env.contacts()[0]["dist"]
+    m, g = model.body_mass[1], 9.81
+    dmin, dmax, width, mid, power = 0.9, 0.95, 0.001, 0.5, 2.0
+    tc, dr = 0.02, 1.0
+    k = 1.0 / (dmax * dmax * tc * tc * dr * dr)
+
+    def imp(r):
+        x = min(abs(r) / width, 1.0)
+        y = (x / mid) ** power * mid if x <= mid else 1 - ((1 - x) / (1 - mid)) ** power * (1 - mid)
+        return dmin + y * (dmax - dmin)
+    # rest: qacc = 0 = a0 + f / m  and  (A + R) f = aref - a0  with  R = (1 - d) / d * A  (diagApprox = 1 / m for the free body)
+    # => f = m g  and  aref = a0 + (A + R) m g = -g + g / d  =>  k d pen = g (1 / d - 1)
+    lo, hi = 0.0, 0.01
+    for _ in range(200):
+        r = 0.5 * (lo + hi)
+        d = imp(r)
+        if k * d * r < g * (1.0 / d - 1.0): lo = r
+        else: hi = r
+    assert pen == pytest.approx(0.5 * (lo + hi), rel=1e-3)
