@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void mjrl_encoder_conv_kernel(const unsigned c
       for (int nt = 0; nt < 4; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[rt][nt], 0, 0, 0);
     }
   }
-  unsigned short* out = a2 + (size_t)image * FLAT;
+  // Epilogue through LDS: the accumulator layout (a lane holds 4 pixels of one channel) would make 64 two-byte stores per
+  // lane; a1 is dead once every wave has left the tap loop, so the tile is laid out there in flatten order (h, w, c) and
+  // goes to HBM as 16-byte stores.
+  __syncthreads();
+  unsigned short* tile = a1;
 #pragma unroll
   for (int nt = 0; nt < 4; nt++) {
     const float bias = b2[16 * nt + row];
@@ -114,9 +118,13 @@ __global__ __launch_bounds__(256) void mjrl_encoder_conv_kernel(const unsigned c
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int oy = 4 * wave + rt, ox = 4 * grp + r;
-        out[(oy * H2 + ox) * C2 + 16 * nt + row] = bf16_bits(fmaxf(acc[rt][nt][r] + bias, 0.0f));
+        tile[(oy * H2 + ox) * C2 + 16 * nt + row] = bf16_bits(fmaxf(acc[rt][nt][r] + bias, 0.0f));
       }
   }
+  __syncthreads();
+  uint4* out = (uint4*)(a2 + (size_t)image * FLAT);
+  const uint4* src = (const uint4*)tile;
+  for (int i = tid; i < FLAT * 2 / 16; i += 256) out[i] = src[i];
 }
 
 // grid (ceil(n_img / 16), latent tiles), 8 waves per workgroup: a workgroup owns 16 images x 16 latent columns, its
