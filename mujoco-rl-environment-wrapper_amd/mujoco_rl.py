@@ -27,9 +27,16 @@ from .helper import update_deep
 from .mujoco_parent import MuJoCoParent
 from .spaces import Box
 
+try:  # pragma: no cover - depends on the environment
+    # the reference's class is a pettingzoo ParallelEnv (mujoco_rl.py:7, 18); so is this one where pettingzoo exists
+    from pettingzoo import ParallelEnv as _ParallelBase
+except Exception:
+    class _ParallelBase:
+        pass
 
-class MuJoCoRL(MuJoCoParent):
-    metadata = {"name": "mjrl_amd_v0"}
+
+class MuJoCoRL(_ParallelBase, MuJoCoParent):
+    metadata = {"name": "mjrl_amd_v0", "render_modes": ["none"]}
 
     def __init__(self, config_dict: dict):
         self.agents = config_dict.get("agents", [])

@@ -579,3 +579,33 @@ def test_rk4_level_through_the_c_abi():
     stats = env._handle.get_field("solver_stats")
     assert np.array_equal(stats[:, 0], [o.ncon for o in oras]) and np.array_equal(stats[:, 2], [o.niter for o in oras])
     env.close()
+
+
+# --------------------------------------------------------------------------- random scenes on the hardware
+def test_random_scenes_on_the_device():
+    """The scenes of tests/test_fuzz_scenes.py (mixed geoms, one to four trees, hinge / slide / free joints) through the
+    C-ABI with the generic kernel (one code object for every shape), against the oracle: contact, row and sweep counts
+    every 20 steps, trajectories at the end."""
+    from tests.test_fuzz_scenes import random_scene
+    for seed in list(range(0, 8)) + list(range(3000, 3008)):
+        rng = np.random.default_rng(seed)
+        model = mjcf.compile_mjcf_string(random_scene(rng), nconmax=24, njmax=120)
+        packed = blob.pack(model)
+        h = _capi.Handle(packed, 3, specialize=False)
+        h.reset()
+        ora = OracleEnv(packed)
+        qvel = h.get_field("qvel")
+        for j in range(model.njnt):
+            if model.jnt_type[j] == mjcf.JNT_FREE:
+                qa, da = int(model.jnt_qposadr[j]), int(model.jnt_dofadr[j])
+                ora.qvel[da:da + 2] = -2.0 * ora.qpos[qa:qa + 2]
+                qvel[:, da:da + 2] = -2.0 * model.qpos0[qa:qa + 2]
+        h.set_field("qvel", qvel)
+        for step in range(240):
+            h.step_host(None, 1)
+            ora.step()
+            if step % 20 == 19:
+                stats = h.get_field("solver_stats")
+                assert (stats[:, 0] == ora.ncon).all() and (stats[:, 1] == ora.nefc).all() and (stats[:, 2] == ora.niter).all(), (seed, step)
+        assert rel(h.get_field("qpos"), np.tile(ora.qpos, (3, 1))) < 1e-8, seed
+        h.close()
