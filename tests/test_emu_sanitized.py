@@ -37,6 +37,27 @@ for level, kw, steps in (("two_agent.xml", {}, 240), ("four_agent.xml", {}, 160)
         env.ctrl[:model.nu] = rng.uniform(-1, 1, model.nu)
         most = max(most, env.step().ncon)
     assert np.isfinite(env.qpos).all() and most > 0, (level, most)
+# random scenes (tests/test_fuzz_scenes.py): box-box items, rows that couple two to four trees, hinge / slide joints
+from tests.test_fuzz_scenes import random_scene
+for seed in (3, 1002, 3001, 5004):
+    model = mjcf.compile_mjcf_string(random_scene(np.random.default_rng(seed)), nconmax=24, njmax=120)
+    env = EmuEnv(model, blob.pack(model))
+    for j in range(model.njnt):
+        if model.jnt_type[j] == mjcf.JNT_FREE:
+            qa, da = int(model.jnt_qposadr[j]), int(model.jnt_dofadr[j])
+            env.qvel[da:da + 2] = -2.0 * env.qpos[qa:qa + 2]
+    env.step(forward_only=True)
+    for t in range(200):
+        env.step()
+    assert np.isfinite(env.qpos).all(), seed
+# the Runge-Kutta level
+model = mjcf.compile_mjcf(levels.level_path("ant.xml"))
+env = EmuEnv(model, blob.pack(model))
+env.step(forward_only=True)
+for t in range(60):
+    env.ctrl[:model.nu] = rng.uniform(-1, 1, model.nu)
+    env.step()
+assert np.isfinite(env.qpos).all()
 # the fused program, the gather / scatter tables and the in-launch reset
 batch = EmuBatch(levels.level_path("two_agent.xml"), ["sender", "receiver"], 2, language=True)
 obs, rew = np.zeros((2, 2, batch.obs_dim)), np.zeros((2, 2))
