@@ -322,19 +322,23 @@ def test_level_switch_on_reset_keeps_the_device_configuration(tmp_path):
     from mjrl_amd.dynamics import Language, TargetDistanceReward
     text = open(levels.level_path("two_agent.xml")).read()
     paths = []
-    for k, colour in enumerate(("0 .9 0 1", "0.9 0 0 1")):          # Testing/levels/Model2-10.xml differ in box colours only
-        p = tmp_path / f"variant{k}.xml"
-        p.write_text(text.replace('rgba="0 .9 0 1" name="border1_geom"', f'rgba="{colour}" name="border1_geom"'))
+    # two levels that differ in STRUCTURE (a platform stands elsewhere): not colour variants of one model, so reset()
+    # switches the whole batch like the reference does and re-creates the device state
+    for k, where in enumerate(("7.02852 -2.071592 0.4710507", "6.2 -1.5 0.4710507")):
+        p = tmp_path / f"level{k}.xml"
+        p.write_text(text.replace('pos="7.02852 -2.071592 0.4710507"', f'pos="{where}"'))
         paths.append(str(p))
     random.seed(0)
     env = MuJoCoRL({"xmlPath": paths, "agents": AGENTS, "numEnvs": 4, "maxSteps": 3, "environmentDynamics": [Language],
                     "rewardFunctions": [TargetDistanceReward("reference", mode="negative")]})
-    assert env._program is not None
-    seen = set()
+    assert env._program is not None and env._variants is None
+    seen, handles = set(), []
     for episode in range(12):
         env.reset()
         seen.add(env.xml_path)
         handle = env._handle
+        if not any(handle is h for h in handles):
+            handles.append(handle)          # (kept referenced, so that a new handle is a new object)
         assert handle.size("n_slot") == len(env._program.slots) and handle.size("obs_dim") == 60
         for call in range(5):
             act = {a: np.concatenate([np.zeros((4, 8)), np.full((4, 1), 2.0 if a == "sender" else 1.0)], axis=1) for a in AGENTS}
@@ -344,7 +348,7 @@ def test_level_switch_on_reset_keeps_the_device_configuration(tmp_path):
             assert trunc["sender"].all() == (call >= 3)
         if len(seen) == 2 and episode >= 3:
             break
-    assert len(seen) == 2, "the level never switched"
+    assert len(seen) == 2 and len(handles) >= 2, "the level never switched"
     env.close()
 
 
