@@ -1237,7 +1237,7 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
       {                                                                               \
         real db = wide_bcast<KK>(fmax(ns, nf));                                       \
         if (kme_s == KK) nss = ns;                                                    \
-        ns -= A[KK] * db;                                                             \
+        ns = __builtin_fma(-A[KK], db, ns);     /* one fused op on the chain (see stage_pgs) */ \
       }
     MJ_FSTEP(0) MJ_FSTEP(1)
     if (pending && (refused != 0ull || deciding == 0ull)) {
@@ -1652,7 +1652,10 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
       f_start = fi; s_start = sr;
       // A row step changes its force by d = max(f - s, 0) - f = max(-s, -f): one max on the negated residual, then
-      // the broadcast and the multiply-add -- the whole dependent chain of a step.  (The reference forms d as the
+      // the broadcast and ONE fused multiply-add (an explicit fma: the build keeps contraction off everywhere else, but
+      // this update sits on the dependent chain of every row step -- max, broadcast, fma instead of max, broadcast,
+      // multiply, subtract -- and its residuals are the solver's own running sums, not a quantity the oracle forms) --
+      // the whole dependent chain of a step.  (The reference forms d as the
       // rounded difference of the rounded new force; max(-s, -f) is that quantity without the two roundings.  The new
       // force itself, max(f - s, 0), is formed after the sweep from the residual captured in the row's step, bit for
       // bit as the reference forms it, and with it the cost change of the row.)
@@ -1672,7 +1675,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
         {                                                                             \
           real db = wv::bcast16<KK>(fmax(ns, nf));                                    \
           if (kme_s == KK) nss = ns;                                                  \
-          ns -= A[KK] * db;                                                           \
+          ns = __builtin_fma(-A[KK], db, ns);                                         \
         }
       MJ_FSTEP(0) MJ_FSTEP(1)
       if (pending && (refused != 0ull || deciding == 0ull)) {
