@@ -18,7 +18,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 12
+VERSION = 13
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
@@ -43,7 +43,7 @@ F64_FIELDS = [
     ("cam_pos", "ncam*3"), ("cam_quat", "ncam*4"), ("cam_fovy", "ncam"),
     ("act_gear", "nu"), ("act_ctrlrange", "nu*2"),
     ("sensor_cutoff", "nsensor"),
-    ("pair_margin", "npair"), ("pair_bound", "npair"),
+    ("pair_margin", "npair"), ("pair_bound", "npair"), ("pair_gap", "npair"), ("pair_mu", "npair"),
 ]
 I32_FIELDS = [
     ("body_parentid", "nbody"), ("body_rootid", "nbody"), ("body_weldid", "nbody"), ("body_jntnum", "nbody"),

@@ -79,11 +79,17 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
   make_layout(m, l);
   LaneK K;
   load_lane_constants(m, L, K);
+  TabRegs TR;
+  tab_issue(m, L, TR);
+  KinK KK;
+  load_kin_constants(m, L, K, KK);
+  GeomK GK;
+  load_geom_constants(m, L, GK);
   for (int i = L; i < m.nq; i += 64) S[l.qpos + i] = qpos[(size_t)env * m.nq + i];
-  stage_constants(m, l, S, L);
+  stage_constants(m, l, S, L, TR);
   wv::sync();
-  stage_kinematics(m, l, K, S, L);
-  stage_geoms(m, l, S, L);
+  stage_kinematics(m, l, K, KK, S, L);
+  stage_geoms(m, l, GK, S, L);
   double* out = scene + (size_t)env * scene_doubles(m);
   for (int g = L; g < m.ngeom; g += 64) {
     st3(out + 3 * g, ld3(S + l.gpos + 3 * g));

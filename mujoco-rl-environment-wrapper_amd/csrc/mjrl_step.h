@@ -294,15 +294,42 @@ __device__ inline Tab make_tab(const DevModel& m, const Lay& l, const real* S) {
   return T;
 }
 
-// copy the launch-invariant tables into LDS (one coalesced sweep per launch)
-__device__ inline void stage_constants(const DevModel& m, const Lay& l, real* S, int L) {
-  if (tab_in_bytes(m)) {
-    unsigned char* t = (unsigned char*)(S + l.tab);
-    for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned char)m.lds_tab[i];
-  } else {
-    unsigned short* t = (unsigned short*)(S + l.tab);
-    for (int i = L; i < m.ntab; i += 64) t[i] = (unsigned short)m.lds_tab[i];
+// copy the launch-invariant tables into LDS (one coalesced sweep per launch).  The first TAB_EARLY x 64 entries are
+// fetched into registers by tab_issue() -- at the top of the kernel, so that their round trip runs under the lookup of
+// the copy's id -- and written by stage_constants(); a longer table takes a loop of batched loads for the rest.
+enum { TAB_EARLY = 8 };
+struct TabRegs { int v[TAB_EARLY]; };
+__device__ __forceinline__ void tab_issue(const DevModel& m, int L, TabRegs& r) {
+#pragma unroll
+  for (int u = 0; u < TAB_EARLY; u++) {
+    const int i = 64 * u + L;
+    r.v[u] = 64 * u < m.ntab ? m.lds_tab[i < m.ntab ? i : 0] : 0;
   }
+}
+template <typename T>
+__device__ __forceinline__ void tab_commit(const DevModel& m, T* t, int L, const TabRegs& r) {
+#pragma unroll
+  for (int u = 0; u < TAB_EARLY; u++) {
+    const int i = 64 * u + L;
+    if (i < m.ntab) t[i] = (T)r.v[u];
+  }
+  for (int base = 64 * TAB_EARLY; base < m.ntab; base += 64 * TAB_EARLY) {
+    int v[TAB_EARLY];
+#pragma unroll
+    for (int u = 0; u < TAB_EARLY; u++) {
+      const int i = base + 64 * u + L;
+      v[u] = m.lds_tab[i < m.ntab ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < TAB_EARLY; u++) {
+      const int i = base + 64 * u + L;
+      if (i < m.ntab) t[i] = (T)v[u];
+    }
+  }
+}
+__device__ inline void stage_constants(const DevModel& m, const Lay& l, real* S, int L, const TabRegs& r) {
+  if (tab_in_bytes(m)) tab_commit(m, (unsigned char*)(S + l.tab), L, r);
+  else tab_commit(m, (unsigned short*)(S + l.tab), L, r);
   if (L == 0) S[l.zero] = 0.0;
 }
 
@@ -345,7 +372,28 @@ __device__ inline void load_row_constants(const DevModel& m, const Lay& l, int L
 }
 
 // ------------------------------------------------------------------ position stage
-__device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+// The model constants of the first two stages (the lane's body: offset from its kinematic parent, first joint, inertial
+// frame).  They are used once, right at the start of the step, so they are fetched with the prologue's other loads
+// instead of costing each stage a round trip to L2 of its own.
+struct KinK {
+  V3 bpos; Quat bquat;         // offset from the kinematic parent
+  V3 jaxis0, jpos0;            // the body's first joint
+  V3 ipos; Quat iquat;         // inertial frame, principal inertias (centre-of-mass stage)
+  real inertia[3];
+};
+__device__ __forceinline__ void load_kin_constants(const DevModel& m, int L, const LaneK& K, KinK& k) {
+  const int b = L < m.nbody ? L : 0;
+  k.bpos = ld3(m.body_kpos + 3 * b);
+  k.bquat = ldq(m.body_kquat + 4 * b);
+  const int j0 = K.b_jntnum > 0 ? K.b_jntadr : 0;       // (lanes without a joint read joint 0 and ignore it)
+  k.jaxis0 = ld3(m.jnt_axis + 3 * j0);
+  k.jpos0 = ld3(m.jnt_pos + 3 * j0);
+  k.ipos = ld3(m.body_ipos + 3 * b);
+  k.iquat = ldq(m.body_iquat + 4 * b);
+  for (int i = 0; i < 3; i++) k.inertia[i] = m.body_inertia[3 * b + i];
+}
+
+__device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const LaneK& K, const KinK& KK, real* S, int L) {
   if (L == 0) {
     st3(S + l.xpos, v3(0, 0, 0));
     Quat q; q.w = 1; q.x = q.y = q.z = 0;
@@ -355,13 +403,12 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
   // body's offset, and for its first joint (the only one of most bodies) the constants and the joint's own motion --
   // the rotation quaternion of a hinge (one sincos for the whole wave instead of one per tree level), the normalised
   // quaternion of a free joint.
-  const bool isb = L < m.nbody;
-  V3 bpos = ld3(m.body_kpos + 3 * (isb ? L : 0));          // offset from the kinematic parent
-  Quat bquat = ldq(m.body_kquat + 4 * (isb ? L : 0));
+  const V3 bpos = KK.bpos;
+  const Quat bquat = KK.bquat;
   const int j0 = K.b_jntadr;
   const bool hasj = K.b_jntnum > 0;
   const int jt0 = K.b_jnttype, qa0 = K.b_qposadr;
-  V3 jaxis0 = hasj ? ld3(m.jnt_axis + 3 * j0) : v3(0, 0, 1), jpos0 = hasj ? ld3(m.jnt_pos + 3 * j0) : v3(0, 0, 0);
+  V3 jaxis0 = hasj ? KK.jaxis0 : v3(0, 0, 1), jpos0 = hasj ? KK.jpos0 : v3(0, 0, 0);
   real q0 = 0;
   V3 fpos = v3(0, 0, 0);
   Quat jq; jq.w = 1; jq.x = jq.y = jq.z = 0;
@@ -428,22 +475,36 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
   }
 }
 
-__device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+// (lane as one coordinate of a tree's centre of mass, lane as joint: fetched while the kinematics run)
+struct ComK { int root, n; real mass; int j_body, j_dofadr, j_type; };
+__device__ __forceinline__ void load_com_constants(const DevModel& m, int L, ComK& c) {
+  const int t = L < 3 * m.ntree ? L / 3 : 0;
+  c.root = m.tree_rootbody[t];
+  c.n = m.body_subtreenum[c.root];
+  c.mass = m.body_subtreemass[c.root];
+  const int j = L < m.njnt ? L : 0;
+  c.j_body = m.njnt > 0 ? m.jnt_bodyid[j] : 0;
+  c.j_dofadr = m.njnt > 0 ? m.jnt_dofadr[j] : 0;
+  c.j_type = m.njnt > 0 ? m.jnt_type[j] : -1;
+}
+
+__device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const LaneK& K, const KinK& KK, const ComK& CK,
+                                         real* S, int L) {
   const Tab T = make_tab(m, l, S);
   // mass-weighted centres of mass; a tree's bodies are the id range of its root (depth-first numbering)
   V3 xi = v3(0, 0, 0);
   Quat q; q.w = 1; q.x = q.y = q.z = 0;
   if (L > 0 && L < m.nbody) {
     q = ldq(S + l.xquat + 4 * L);
-    xi = ld3(S + l.xpos + 3 * L) + rot(q, ld3(m.body_ipos + 3 * L));
+    xi = ld3(S + l.xpos + 3 * L) + rot(q, KK.ipos);
     st3(S + l.cinert + 10 * L, xi * K.b_mass);     // (scratch until the sums are taken; cinert is written after)
   }
   wv::sync();
   if (L < 3 * m.ntree) {
-    int t = L / 3, k = L % 3, root = m.tree_rootbody[t], n = m.body_subtreenum[root];
+    int t = L / 3, k = L % 3, root = CK.root, n = CK.n;
     real acc = 0;
     for (int c = root; c < root + n; c++) acc += S[l.cinert + 10 * c + k];
-    real mass = m.body_subtreemass[root];
+    real mass = CK.mass;
     S[l.com + 3 * t + k] = mass < MJ_MINVAL ? S[l.xpos + 3 * root + k] : acc / mass;
   }
   if (L < 3) S[l.com + 3 * m.ntree + L] = 0;
@@ -454,16 +515,16 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const 
     if (L == 0 || K.b_tree < 0) {
       for (int k = 0; k < 10; k++) ci[k] = 0;
     } else {
-      M3 ximat = qmat(qmul(q, ldq(m.body_iquat + 4 * L)));
-      inert_com(ci, m.body_inertia + 3 * L, ximat, xi - ld3(S + l.com + 3 * K.b_tree), K.b_mass);
+      M3 ximat = qmat(qmul(q, KK.iquat));
+      inert_com(ci, KK.inertia, ximat, xi - ld3(S + l.com + 3 * K.b_tree), K.b_mass);
     }
     for (int k = 0; k < 10; k++) S[l.cinert + 10 * L + k] = ci[k];
   }
   // joint motion axes in the same frame
   if (L < m.njnt) {
-    int j = L, b = m.jnt_bodyid[j], da = m.jnt_dofadr[j];
+    int j = L, b = CK.j_body, da = CK.j_dofadr;
     V3 off = ld3(S + l.com + 3 * T.body_tree(b)) - ld3(S + l.xanchor + 3 * j);     // (tree id from the LDS table)
-    if (m.jnt_type[j] == JNT_FREE) {
+    if (CK.j_type == JNT_FREE) {
       M3 xm = qmat(ldq(S + l.xquat + 4 * b));
       for (int k = 0; k < 3; k++) {
         real* c = S + l.cdof + 6 * (da + k);
@@ -478,7 +539,7 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const 
     } else {
       real* c = S + l.cdof + 6 * da;
       V3 axis = ld3(S + l.xaxis + 3 * j);
-      if (m.jnt_type[j] == JNT_HINGE) { st3(c, axis); st3(c + 3, cross(axis, off)); }
+      if (CK.j_type == JNT_HINGE) { st3(c, axis); st3(c + 3, cross(axis, off)); }
       else { st3(c, v3(0, 0, 0)); st3(c + 3, axis); }
     }
   }
@@ -517,19 +578,41 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
 // In-place sparse L'DL of the matrix at S[ld..] (dof_Madr layout), Featherstone order inside every kinematic tree.
 // Trees are independent, so up to two of them are eliminated side by side (32 lanes each); inside a tree the
 // lanes cover the (ancestor a, offset t) pairs of the pivot row.  dinv gets 1/D.
-__device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, int L) {
+// The schedule words of the first FACTOR_AHEAD elimination steps of a factorisation, fetched ahead of it (before the
+// stage in front) so that the factorisation starts without a round trip to L2 of its own.
+enum { FACTOR_AHEAD = 4 };
+struct FactorRing { unsigned q[FACTOR_AHEAD]; };
+__device__ __forceinline__ void factor_prefetch(const DevModel& m, int L, FactorRing& r) {
+  const int32_t* sched = m.factor_sched + L;
+#pragma unroll
+  for (int u = 0; u < FACTOR_AHEAD; u++) {
+    const int kk = m.maxtreedof - 1 - u;
+    r.q[u] = kk >= 0 ? (unsigned)sched[kk * 64] : 0u;
+  }
+}
+
+__device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, int L, FactorRing ring) {
   const int groups = m.ntree > 1 ? 2 : 1, width = 64 / groups;
   const int g = L / width, p = L % width;
   for (int ps = 0; ps < m.npass; ps++) {
     int tree = ps * groups + g;
     bool has_tree = tree < m.ntree;
     int adr0 = has_tree ? m.tree_dofadr[tree] : 0, num = has_tree ? m.tree_dofnum[tree] : 0;
-    // the lane's (ancestor, offset) pair of every elimination step comes from the host-built schedule
+    // the lane's (ancestor, offset) pair of every elimination step comes from the host-built schedule, fetched
+    // FACTOR_AHEAD steps before its use (a step is two short LDS phases, far less than a round trip to L2)
     const int32_t* sched = m.factor_sched + (size_t)ps * m.maxtreedof * 64 + L;
-    unsigned next = (unsigned)sched[(m.maxtreedof - 1) * 64];
+    if (ps > 0) {
+#pragma unroll
+      for (int u = 0; u < FACTOR_AHEAD; u++) {
+        const int kk = m.maxtreedof - 1 - u;
+        ring.q[u] = kk >= 0 ? (unsigned)sched[kk * 64] : 0u;
+      }
+    }
     for (int kk = m.maxtreedof - 1; kk >= 0; kk--) {
-      unsigned w = next;
-      if (kk > 0) next = (unsigned)sched[(kk - 1) * 64];
+      unsigned w = ring.q[0];
+#pragma unroll
+      for (int u = 0; u + 1 < FACTOR_AHEAD; u++) ring.q[u] = ring.q[u + 1];
+      ring.q[FACTOR_AHEAD - 1] = kk >= FACTOR_AHEAD ? (unsigned)sched[(kk - FACTOR_AHEAD) * 64] : 0u;
       bool live = kk < num, valid = (w >> 26) & 1u;
       int kkadr = w & 1023, ijt = (w >> 10) & 1023, a = (w >> 20) & 7, t = (w >> 23) & 7;
       int ki = kkadr + 1 + a;
@@ -625,33 +708,70 @@ __device__ __forceinline__ void geom_frame(const DevModel& m, const Lay& l, cons
   quat = qmul(bq, ldq(m.geom_quat + 4 * g));
 }
 
-__device__ inline void stage_geoms(const DevModel& m, const Lay& l, real* S, int L) {
+// The lane's geom record and the candidate pairs of the first broad-phase chunks, fetched two stages ahead (before the
+// inertia matrix is built and factorised): the geom and collision stages then start on registers.
+enum { PAIR_AHEAD = 3 };
+struct GeomK {
+  int body; V3 pos; Quat quat;
+  real size[3];                           // geom_size[L], [L + 64], [L + 128] (a longer table takes a loop)
+  int word[PAIR_AHEAD], reach[PAIR_AHEAD];
+};
+__device__ __forceinline__ void load_geom_constants(const DevModel& m, int L, GeomK& g) {
+  const int i = L < m.ngeom ? L : 0;
+  g.body = m.geom_bodyid[i];
+  g.pos = ld3(m.geom_pos + 3 * i);
+  g.quat = ldq(m.geom_quat + 4 * i);
+#pragma unroll
+  for (int u = 0; u < 3; u++) g.size[u] = 64 * u < 3 * m.ngeom ? m.geom_size[64 * u + L < 3 * m.ngeom ? 64 * u + L : 0] : 0.0;
+#pragma unroll
+  for (int u = 0; u < PAIR_AHEAD; u++) {
+    const int p = 64 * u + L, q = p < m.npair ? p : 0;
+    g.word[u] = 64 * u < m.npair ? m.pair_word[q] : 0;
+    g.reach[u] = 64 * u < m.npair ? m.pair_reach[q] : 0;
+  }
+}
+
+__device__ inline void stage_geoms(const DevModel& m, const Lay& l, const GeomK& G, real* S, int L) {
   if (L < m.ngeom) {
-    V3 pos; Quat quat;
-    geom_frame(m, l, S, L, pos, quat);
+    // (the arithmetic of geom_frame() on the prefetched record)
+    Quat bq = ldq(S + l.xquat + 4 * G.body);
+    V3 pos = ld3(S + l.xpos + 3 * G.body) + rot(bq, G.pos);
+    Quat quat = qmul(bq, G.quat);
     st3(S + l.gpos + 3 * L, pos);
     stq(S + l.gquat + 4 * L, quat);
   }
   // the geom sizes go next to the work items of the collision stage (scratch area of `u`, free since the composite
-  // inertias were consumed); the loads were issued above the frame arithmetic
-  for (int i = L; i < 3 * m.ngeom; i += 64) S[l.gsize + i] = m.geom_size[i];
+  // inertias were consumed)
+#pragma unroll
+  for (int u = 0; u < 3; u++)
+    if (64 * u + L < 3 * m.ngeom) S[l.gsize + 64 * u + L] = G.size[u];
+  for (int i = 192 + L; i < 3 * m.ngeom; i += 64) S[l.gsize + i] = m.geom_size[i];
   wv::sync();
 }
 
 // ------------------------------------------------------------------ collision
-__device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S, int L) {
+__device__ inline void stage_collision(const DevModel& m, const Lay& l, const GeomK& G, real* S, int L) {
   int* I = (int*)(S + l.ints);
   int nitem = 0, warn = 0;
   // broad phase: bounding spheres (planes: signed distance of the other geom's bounding sphere).  Every surviving
   // pair expands into its narrow-phase work items, in pair order.
-  // one packed word + one float per candidate pair; the next chunk's are in flight while this chunk is tested
-  int word_next = 0, reach_next = 0;
-  if (L < m.npair) { word_next = m.pair_word[L]; reach_next = m.pair_reach[L]; }
+  // one packed word + one float per candidate pair; those of the next PAIR_AHEAD chunks are in flight while this chunk
+  // is tested (a chunk without a survivor is a few dozen instructions, much less than a round trip to L2)
+  int wring[PAIR_AHEAD], rring[PAIR_AHEAD];
+#pragma unroll
+  for (int u = 0; u < PAIR_AHEAD; u++) { wring[u] = G.word[u]; rring[u] = G.reach[u]; }
   for (int base = 0; base < m.npair; base += 64) {
     int p = base + L, items = 0;
-    int word = word_next;
-    real bound = (real)int_as_float(reach_next);
-    if (p + 64 < m.npair) { word_next = m.pair_word[p + 64]; reach_next = m.pair_reach[p + 64]; }
+    int word = wring[0];
+    real bound = (real)int_as_float(rring[0]);
+#pragma unroll
+    for (int u = 0; u + 1 < PAIR_AHEAD; u++) { wring[u] = wring[u + 1]; rring[u] = rring[u + 1]; }
+    {
+      const int pn = p + 64 * PAIR_AHEAD, q = pn < m.npair ? pn : 0;
+      const bool more = base + 64 * PAIR_AHEAD < m.npair;
+      wring[PAIR_AHEAD - 1] = more ? m.pair_word[q] : 0;
+      rring[PAIR_AHEAD - 1] = more ? m.pair_reach[q] : 0;
+    }
     if (p < m.npair) {
       int g1 = word & 255, g2 = (word >> 8) & 255, t1 = (word >> 16) & 15, t2 = (word >> 20) & 15;
       V3 dif = ld3(S + l.gpos + 3 * g2) - ld3(S + l.gpos + 3 * g1);
@@ -713,13 +833,17 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
     bool hit = false;
     RawCon rc;
     int g1 = 0, g2 = 0;
-    real margin = 0, gap = 0;
+    real margin = 0, gap = 0, mu = 0;
     if (it < nitem) {
       int code = I[l.i_item + it], p = code >> 4, k = code & 15;
+      // (one round trip for everything a contact takes from the model: the pair's record holds the larger gap and the
+      // larger sliding friction of its two geoms, fmax(geom_gap[g1], geom_gap[g2]) and fmax(geom_friction[3 g1],
+      // geom_friction[3 g2]) evaluated once by the model compiler)
       int word = m.pair_word[p];
-      g1 = word & 255; g2 = (word >> 8) & 255;
       margin = m.pair_margin[p];
-      gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
+      gap = m.pair_gap[p];
+      mu = m.pair_mu[p];
+      g1 = word & 255; g2 = (word >> 8) & 255;
       hit = collide_item((word >> 16) & 15, (word >> 20) & 15, ld3(S + l.gpos + 3 * g1), qmat(ldq(S + l.gquat + 4 * g1)),
                          ld3(S + l.gsize + 3 * g1), ld3(S + l.gpos + 3 * g2), qmat(ldq(S + l.gquat + 4 * g2)),
                          ld3(S + l.gsize + 3 * g2), margin, k, rc, m.pair_kmax >= 16);
@@ -733,7 +857,7 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, real* S,
         st3(C + CON_POS, rc.pos);
         make_frame(rc.n, rc.t, C + CON_FRAME);
         C[CON_INCL] = margin - gap;
-        C[CON_MU] = fmax(m.geom_friction[3 * g1], m.geom_friction[3 * g2]);
+        C[CON_MU] = mu;
         I[l.i_cong1 + slot] = g1;
         I[l.i_cong2 + slot] = g2;
       }
@@ -832,15 +956,36 @@ __device__ inline void stage_velocity(const DevModel& m, const Lay& l, const Lan
   wv::sync();
 }
 
+// What the two stages after the velocity stage read from the model for the lane (as dof: its actuator; as joint-limit
+// item: the joint's range), fetched before the velocity stage
+struct ActK {
+  int limited; real lo, hi, gear;                       // the lane's dof's actuator (K.d_act >= 0)
+  int j_limited, j_type, j_qposadr; real j_range, j_margin;   // limit item L: joint L >> 1, lower side first
+};
+__device__ __forceinline__ void load_act_constants(const DevModel& m, int L, const LaneK& K, ActK& A) {
+  const int u = K.d_act >= 0 ? K.d_act : 0;
+  A.limited = m.nu > 0 ? m.act_ctrllimited[u] : 0;
+  A.lo = m.nu > 0 ? m.act_ctrlrange[2 * u] : 0.0;
+  A.hi = m.nu > 0 ? m.act_ctrlrange[2 * u + 1] : 0.0;
+  A.gear = m.nu > 0 ? m.act_gear[u] : 0.0;
+  const int it = L < 2 * m.njnt ? L : 0, j = it >> 1, side = (it & 1) ? 1 : -1;
+  A.j_limited = m.njnt > 0 ? m.jnt_limited[j] : 0;
+  A.j_type = m.njnt > 0 ? m.jnt_type[j] : -1;
+  A.j_qposadr = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
+  A.j_range = m.njnt > 0 ? m.jnt_range[2 * j + (side + 1) / 2] : 0.0;
+  A.j_margin = m.njnt > 0 ? m.jnt_margin[j] : 0.0;
+}
+
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
-__device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK& K, const RowK& R, real* S, int L) {
+__device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK& K, const RowK& R, const ActK& A, real* S,
+                                    int L) {
   if (L < m.nv) {
     real act = 0;
     if (K.d_act >= 0) {
       int u = K.d_act;
       real c = S[l.ctrl + u];
-      if (m.act_ctrllimited[u]) c = fmin(fmax(c, m.act_ctrlrange[2 * u]), m.act_ctrlrange[2 * u + 1]);
-      act = m.act_gear[u] * c;
+      if (A.limited) c = fmin(fmax(c, A.lo), A.hi);
+      act = A.gear * c;
     } else if (K.d_act == -2) {
       for (int u = 0; u < m.nu; u++) {
         if (m.act_dofid[u] != L) continue;
@@ -870,7 +1015,7 @@ __device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK
 // dump of the raw rows was requested) immediately projects it:  J <- J L^-1  by back substitution restricted to the
 // row's own dof chains, and AR_ii = sum_d B_id^2 / D_d + R_i.  A row only touches the dof chains of its (at most
 // two) bodies; the chains are read from the LDS structure tables.
-__device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int L, bool project,
+__device__ inline void stage_rows(const DevModel& m, const Lay& l, const ActK& A, real* S, int L, bool project,
                                   Stamps* stamps) {
 #define MJ_SUBSTAMP(k)                                                     \
   if (stamps) {                                                            \
@@ -887,10 +1032,13 @@ __device__ inline void stage_rows(const DevModel& m, const Lay& l, real* S, int 
     int it = base + L, j = it >> 1, side = (it & 1) ? 1 : -1;
     bool active = false;
     real dist = 0;
-    if (it < 2 * m.njnt && m.jnt_limited[j] && (m.jnt_type[j] == JNT_HINGE || m.jnt_type[j] == JNT_SLIDE)) {
-      real value = S[l.qpos + m.jnt_qposadr[j]];
-      dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - value);
-      active = dist < m.jnt_margin[j];
+    // (the first 64 items test the prefetched record of their lane)
+    const int limited = base == 0 ? A.j_limited : (it < 2 * m.njnt ? m.jnt_limited[j] : 0);
+    const int jtype = base == 0 ? A.j_type : (it < 2 * m.njnt ? m.jnt_type[j] : -1);
+    if (it < 2 * m.njnt && limited && (jtype == JNT_HINGE || jtype == JNT_SLIDE)) {
+      real value = S[l.qpos + (base == 0 ? A.j_qposadr : m.jnt_qposadr[j])];
+      dist = side * ((base == 0 ? A.j_range : m.jnt_range[2 * j + (side + 1) / 2]) - value);
+      active = dist < (base == 0 ? A.j_margin : m.jnt_margin[j]);
     }
     unsigned long long mask = wv::ballot(active);
     if (active) {
@@ -1927,106 +2075,156 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
 // ------------------------------------------------------------------ sensors (mj_forward's sensor stage)
 __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
   int* I = (int*)(S + l.ints);
-  bool need_acc = false;
-  for (int s = 0; s < m.nsensor; s++) need_acc |= (m.sensor_type[s] == SENS_ACCELEROMETER);
-  if (need_acc) stage_velocity(m, l, K, S, L, true);
-  // the lane's geom as a ray target, fetched once for all rangefinders
-  bool any_ray = false;
-  for (int s = 0; s < m.nsensor; s++) any_ray |= (m.sensor_type[s] == SENS_RANGEFINDER);
-  int rg_body = -1, rg_type = -1;
-  real rg_rb = 0;
-  V3 rg_pos = v3(0, 0, 0), rg_size = v3(0, 0, 0);
-  M3 rg_mat = qmat(ldq(S + l.xquat));
-  if (any_ray && L < m.ngeom && m.geom_rgba[4 * L + 3] != 0) {
-    rg_body = m.geom_bodyid[L]; rg_type = m.geom_type[L]; rg_rb = m.geom_rbound[L];
-    rg_size = ld3(m.geom_size + 3 * L);
-    Quat gq;
-    geom_frame(m, l, S, L, rg_pos, gq);
-    rg_mat = qmat(gq);
-  }
-  for (int s = 0; s < m.nsensor; s++) {
-    int site = m.sensor_objid[s], adr = m.sensor_adr[s], body = m.site_bodyid[site], type = m.sensor_type[s];
-    real cutoff = m.sensor_cutoff[s];
-    Quat bq = ldq(S + l.xquat + 4 * body);
-    V3 sp = ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.site_pos + 3 * site));
-    M3 sm = qmat(qmul(bq, ldq(m.site_quat + 4 * site)));
-    if (type == SENS_RANGEFINDER) {
-      V3 vec = col(sm, 2);
-      real best = 1e300;
-      if (rg_type >= 0 && rg_body != body) {
-        // a geom whose bounding sphere the ray misses (or that lies wholly behind the ray's origin) cannot be hit: it
-        // takes no type-specific test, and a type with no candidate left in the wave costs nothing
-        int gt = rg_type;
-        if (gt != GEOM_PLANE) {
-          V3 rel = rg_pos - sp;
-          real t = dot(rel, vec), d2 = dot(rel, rel) - t * t;
-          if (d2 > rg_rb * rg_rb * (1.0 + 1e-9) + 1e-12 || t + rg_rb < -1e-9) gt = -1;
+  const Tab T = make_tab(m, l, S);
+  if (m.has_accel) stage_velocity(m, l, K, S, L, true);
+  // Sensor s's record lives in lane s (64 sensors per pass): the chain sensor -> site -> body is followed by all
+  // sensors at once, two round trips to L2 for the stage instead of two per sensor, and the loop over the sensors reads
+  // lane s with v_readlane.
+  for (int s0 = 0; s0 < m.nsensor; s0 += 64) {
+    const int sl = s0 + L < m.nsensor ? s0 + L : 0;
+    const int k_site = m.sensor_objid[sl], k_adr = m.sensor_adr[sl], k_type = m.sensor_type[sl];
+    const real k_cut = m.sensor_cutoff[sl];
+    // the lane's geom as a ray target, fetched once for all rangefinders (with the sensor records: one round trip)
+    const int gl = L < m.ngeom ? L : 0;
+    const real rg_alpha = m.geom_rgba[4 * gl + 3];
+    const int rg_body0 = m.geom_bodyid[gl], rg_type0 = m.geom_type[gl];
+    const real rg_rb0 = m.geom_rbound[gl];
+    const V3 rg_size0 = ld3(m.geom_size + 3 * gl), rg_gpos = ld3(m.geom_pos + 3 * gl);
+    const Quat rg_gquat = ldq(m.geom_quat + 4 * gl);
+    const int k_body = m.site_bodyid[k_site];
+    const V3 k_pos = ld3(m.site_pos + 3 * k_site);
+    const Quat k_quat = ldq(m.site_quat + 4 * k_site);
+    const real k_size = m.site_size[3 * k_site];
+    const bool any_ray = wv::ballot(s0 + L < m.nsensor && k_type == SENS_RANGEFINDER) != 0ull;
+    int rg_body = -1, rg_type = -1;
+    real rg_rb = 0;
+    V3 rg_pos = v3(0, 0, 0), rg_size = v3(0, 0, 0);
+    M3 rg_mat = qmat(ldq(S + l.xquat));
+    if (any_ray && L < m.ngeom && rg_alpha != 0) {
+      rg_body = rg_body0; rg_type = rg_type0; rg_rb = rg_rb0;
+      rg_size = rg_size0;
+      // (the arithmetic of geom_frame())
+      Quat bq = ldq(S + l.xquat + 4 * rg_body0);
+      rg_pos = ld3(S + l.xpos + 3 * rg_body0) + rot(bq, rg_gpos);
+      rg_mat = qmat(qmul(bq, rg_gquat));
+    }
+    const int ns = m.nsensor - s0 < 64 ? m.nsensor - s0 : 64;
+    for (int j = 0; j < ns; j++) {
+      const int adr = wv::lane_int(k_adr, j), body = wv::lane_int(k_body, j), type = wv::lane_int(k_type, j);
+      const real cutoff = wv::lane_value(k_cut, j);
+      const V3 site_pos = v3(wv::lane_value(k_pos.x, j), wv::lane_value(k_pos.y, j), wv::lane_value(k_pos.z, j));
+      Quat site_quat;
+      site_quat.w = wv::lane_value(k_quat.w, j); site_quat.x = wv::lane_value(k_quat.x, j);
+      site_quat.y = wv::lane_value(k_quat.y, j); site_quat.z = wv::lane_value(k_quat.z, j);
+      Quat bq = ldq(S + l.xquat + 4 * body);
+      V3 sp = ld3(S + l.xpos + 3 * body) + rot(bq, site_pos);
+      M3 sm = qmat(qmul(bq, site_quat));
+      if (type == SENS_RANGEFINDER) {
+        V3 vec = col(sm, 2);
+        real best = 1e300;
+        if (rg_type >= 0 && rg_body != body) {
+          // a geom whose bounding sphere the ray misses (or that lies wholly behind the ray's origin) cannot be hit: it
+          // takes no type-specific test, and a type with no candidate left in the wave costs nothing
+          int gt = rg_type;
+          if (gt != GEOM_PLANE) {
+            V3 rel = rg_pos - sp;
+            real t = dot(rel, vec), d2 = dot(rel, rel) - t * t;
+            if (d2 > rg_rb * rg_rb * (1.0 + 1e-9) + 1e-12 || t + rg_rb < -1e-9) gt = -1;
+          }
+          real x = ray_geom(gt, rg_pos, rg_mat, rg_size, sp, vec);
+          if (x >= 0) best = x;
         }
-        real x = ray_geom(gt, rg_pos, rg_mat, rg_size, sp, vec);
-        if (x >= 0) best = x;
-      }
-      best = wv::min_pos(best);
-      real out = best > 1e299 ? -1.0 : best;
-      if (cutoff > 0 && out > cutoff) out = cutoff;
-      if (L == 0) S[l.sens + adr] = out;
-    } else if (type == SENS_TOUCH) {
-      real part = 0;
-      int ncon = I[I_NCON];
-      if (L < ncon) {
-        int c = L, a = I[l.i_conadr + c];
-        int g1 = I[l.i_cong1 + c], g2 = I[l.i_cong2 + c];
-        int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-        if (a >= 0 && (b1 == body || b2 == body)) {
-          int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
-          int rows = dim == 1 ? 1 : 2 * ((dim < 3 ? dim : 3) - 1);
-          real fn = 0;
-          for (int r = 0; r < rows; r++) fn += S[l.row + ROW_STRIDE * (a + r) + ROW_F];
-          const real* C = S + l.con + CON_STRIDE * c;
-          V3 ray = ld3(C + CON_FRAME) * (b2 == body ? -1.0 : 1.0);
-          if (fn > 0 && ray_sphere_at(sp, m.site_size[3 * site], ld3(C + CON_POS), ray) >= 0) part = fn;
+        best = wv::min_pos(best);
+        real out = best > 1e299 ? -1.0 : best;
+        if (cutoff > 0 && out > cutoff) out = cutoff;
+        if (L == 0) S[l.sens + adr] = out;
+      } else if (type == SENS_TOUCH) {
+        const real site_size = wv::lane_value(k_size, j);
+        real part = 0;
+        int ncon = I[I_NCON];
+        if (L < ncon) {
+          int c = L, a = I[l.i_conadr + c];
+          int g1 = I[l.i_cong1 + c], g2 = I[l.i_cong2 + c];
+          int b1 = T.geom_body(g1), b2 = T.geom_body(g2);          // (LDS structure tables)
+          if (a >= 0 && (b1 == body || b2 == body)) {
+            int dim = T.geom_condim(g1) > T.geom_condim(g2) ? T.geom_condim(g1) : T.geom_condim(g2);
+            int rows = dim == 1 ? 1 : 2 * ((dim < 3 ? dim : 3) - 1);
+            real fn = 0;
+            for (int r = 0; r < rows; r++) fn += S[l.row + ROW_STRIDE * (a + r) + ROW_F];
+            const real* C = S + l.con + CON_STRIDE * c;
+            V3 ray = ld3(C + CON_FRAME) * (b2 == body ? -1.0 : 1.0);
+            if (fn > 0 && ray_sphere_at(sp, site_size, ld3(C + CON_POS), ray) >= 0) part = fn;
+          }
         }
-      }
-      real out = wv::sum(part);
-      if (cutoff > 0 && out > cutoff) out = cutoff;
-      if (L == 0) S[l.sens + adr] = out;
-    } else if (type == SENS_ACCELEROMETER) {
-      if (L == 0) {
-        int t = m.body_treeid[body];
-        V3 off = sp - ld3(S + l.com + 3 * (t < 0 ? m.ntree : t));
-        V3 wa = ld3(S + l.cacc + 6 * body), la = ld3(S + l.cacc + 6 * body + 3);
-        V3 wv_ = ld3(S + l.cvel + 6 * body), lv = ld3(S + l.cvel + 6 * body + 3);
-        V3 acc = la + cross(wa, off), vel = lv + cross(wv_, off);
-        V3 wl = mulT(sm, wv_), vl = mulT(sm, vel), al = mulT(sm, acc);
-        V3 o = al + cross(wl, vl);
-        real out[3] = {o.x, o.y, o.z};
-        for (int k = 0; k < 3; k++) {
-          if (cutoff > 0) out[k] = fmin(fmax(out[k], -cutoff), cutoff);
-          S[l.sens + adr + k] = out[k];
+        real out = wv::sum(part);
+        if (cutoff > 0 && out > cutoff) out = cutoff;
+        if (L == 0) S[l.sens + adr] = out;
+      } else if (type == SENS_ACCELEROMETER) {
+        if (L == 0) {
+          int t = T.body_tree(body);
+          V3 off = sp - ld3(S + l.com + 3 * (t < 0 ? m.ntree : t));
+          V3 wa = ld3(S + l.cacc + 6 * body), la = ld3(S + l.cacc + 6 * body + 3);
+          V3 wv_ = ld3(S + l.cvel + 6 * body), lv = ld3(S + l.cvel + 6 * body + 3);
+          V3 acc = la + cross(wa, off), vel = lv + cross(wv_, off);
+          V3 wl = mulT(sm, wv_), vl = mulT(sm, vel), al = mulT(sm, acc);
+          V3 o = al + cross(wl, vl);
+          real out[3] = {o.x, o.y, o.z};
+          for (int k = 0; k < 3; k++) {
+            if (cutoff > 0) out[k] = fmin(fmax(out[k], -cutoff), cutoff);
+            S[l.sens + adr + k] = out[k];
+          }
         }
+      } else {
+        int c = type - SENS_FRAMEXAXIS;
+        // (a select, not col(sm, c): a run-time column index would put the matrix in scratch memory)
+        V3 axis = c == 0 ? col(sm, 0) : (c == 1 ? col(sm, 1) : col(sm, 2));
+        if (L == 0) st3(S + l.sens + adr, axis);
       }
-    } else {
-      int c = type - SENS_FRAMEXAXIS;
-      // (a select, not col(sm, c): a run-time column index would put the matrix in scratch memory)
-      V3 axis = c == 0 ? col(sm, 0) : (c == 1 ? col(sm, 1) : col(sm, 2));
-      if (L == 0) st3(S + l.sens + adr, axis);
     }
   }
   wv::sync();
 }
 
 // ------------------------------------------------------------------ integrator
-__device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L,
-                                   const real* Mg) {
+// What the integrator and the observation gather read from HBM / the model, fetched before the sensor stage: the
+// lane's row of the inertia matrix (written by the CRB stage a whole step of work ago), the first schedule words of the
+// second factorisation, the lane's joint record, and the first two gather codes of the lane.
+struct EulerK {
+  real mg[MAX_DOF_DEPTH];
+  FactorRing ring;
+  int qa, da, jtype;
+  int gcode[2];
+};
+__device__ __forceinline__ void load_euler_constants(const DevModel& m, const StepArgs& a, const LaneK& K, int L, const real* Mg,
+                                                     bool integrate, EulerK& E) {
+#pragma unroll
+  for (int t = 0; t < MAX_DOF_DEPTH; t++)     // (entries past the lane's row repeat its diagonal and are not used)
+    E.mg[t] = integrate ? Mg[K.d_Madr + (t <= K.d_depth ? t : 0)] : 0.0;
+  if (integrate) factor_prefetch(m, L, E.ring);
+  else { for (int u = 0; u < FACTOR_AHEAD; u++) E.ring.q[u] = 0u; }
+  const int j = L < m.njnt ? L : 0;
+  E.qa = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
+  E.da = m.njnt > 0 ? m.jnt_dofadr[j] : 0;
+  E.jtype = m.njnt > 0 ? m.jnt_type[j] : -1;
+  const int nobs = a.n_agent * a.obs_dim;
+#pragma unroll
+  for (int u = 0; u < 2; u++) E.gcode[u] = (a.obs && 64 * u < nobs) ? a.gather[64 * u + L < nobs ? 64 * u + L : 0] : -1;
+}
+
+__device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, const EulerK& E, real* S,
+                                   int L) {
   real h = m.timestep;
   bool damped = wv::ballot(L < m.nv && K.d_damping > 0) != 0ull;
   if (damped) {
     // (M + h*diag(damping)) qacc = qfrc_smooth + qfrc_constraint
     if (L < m.nv) {
-      for (int t = 0; t <= K.d_depth; t++) S[l.LD + K.d_Madr + t] = Mg[K.d_Madr + t] + (t == 0 ? h * K.d_damping : 0.0);
+#pragma unroll
+      for (int t = 0; t < MAX_DOF_DEPTH; t++)
+        if (t <= K.d_depth) S[l.LD + K.d_Madr + t] = E.mg[t] + (t == 0 ? h * K.d_damping : 0.0);
       S[l.x + L] = S[l.smooth + L] + S[l.qfc + L];
     }
     wv::sync();
-    factor_ld(m, S, l.LD, l.Dinv, L);
+    factor_ld(m, S, l.LD, l.Dinv, L, E.ring);
     if (m.rowmap) {
       real x = solve_rows(m, RK, S, l.LD, l.Dinv, RK.dof >= 0 ? S[l.x + RK.dof] : 0.0, true, true, true);
       wv::sync();
@@ -2042,8 +2240,8 @@ __device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK&
   if (L < m.nv) S[l.qvel + L] += h * S[l.x + L];
   wv::sync();
   if (L < m.njnt) {
-    int qa = m.jnt_qposadr[L], da = m.jnt_dofadr[L];
-    if (m.jnt_type[L] == JNT_FREE) {
+    int qa = E.qa, da = E.da;
+    if (E.jtype == JNT_FREE) {
       for (int k = 0; k < 3; k++) S[l.qpos + qa + k] += h * S[l.qvel + da + k];
       real len;
       V3 w = normalized(ld3(S + l.qvel + da + 3), &len);
@@ -2100,11 +2298,28 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   const int L = wv::lane();
   int env = wv::env_index();
   const unsigned long long t_begin = a.timeline ? wv::realtime() : 0ull;
+  // The prologue is a chain of dependent round trips to L2 / HBM (bucket counts -> the copy's id -> the copy's rows),
+  // and nothing else of the wave can start before it ends.  So every load that does not need the copy's id is issued
+  // before the id is known, and every load that needs it is issued before the first of them is waited for: three round
+  // trips in all (they were eleven when each block of state was fetched and stored in turn).
+  int my_count = 0;
+  if (a.lpt_count_in) my_count = a.lpt_count_in[L & (LPT_BUCKETS - 1)];
+  Lay l;
+  make_layout(m, l);
+  LaneK K;
+  load_lane_constants(m, L, K);
+  RowK RK;
+  load_row_constants(m, l, L, RK);
+  TabRegs TR;
+  tab_issue(m, L, TR);
+  KinK KK;
+  load_kin_constants(m, L, K, KK);
+  ComK CK;
+  load_com_constants(m, L, CK);
   if (a.lpt_count_in) {
     // workgroup id -> copy: walk the buckets from the heaviest down
     // (the bucket counts come in with one load, lane b holding bucket b's; walking them is register work -- a loop of
     // dependent loads here cost every wave several L2 round trips before it could even fetch its state)
-    const int my_count = L < LPT_BUCKETS ? a.lpt_count_in[L] : 0;
     int rest = env, bucket = -1;
     for (int b = LPT_BUCKETS - 1; b >= 0; b--) {
       int c = wv::lane_int(my_count, b);
@@ -2119,12 +2334,6 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     // chain: its wave gets issue priority over the waves that share its SIMD (they fill the gaps it leaves).
     wv::set_priority(bucket >= 10 ? 3 : (bucket == 9 ? 2 : (bucket == 8 ? 1 : 0)));
   }
-  Lay l;
-  make_layout(m, l);
-  LaneK K;
-  load_lane_constants(m, L, K);
-  RowK RK;
-  load_row_constants(m, l, L, RK);
   // diagnostic stage clock: lane k accumulates the cycles of stage k in a register and adds them to the batch totals
   // when the wave is done -- nothing of the measurement touches memory while a stage is being timed
   Stamps clock_state;
@@ -2138,22 +2347,20 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     stamps->prev = t_now;                                                  \
   }
 #define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
-  // state in: the copy's rows, or the reset image when the copy is flagged for an in-launch reset
-  const bool resetting = a.reset_mask != nullptr && !a.forward_only && wv::first_int((int)a.reset_mask[env]) != 0;
-  if (resetting && a.first_frame) {
-    MJ_FOR(i, m.nq) S[l.qpos + i] = m.qpos0[i];
-    MJ_FOR(i, m.nv) { S[l.qvel + i] = 0; S[l.warm + i] = a.reset_warm[i]; }
-    MJ_FOR(i, m.nu) S[l.ctrl + i] = 0;
-  } else {
-    MJ_FOR(i, m.nq) S[l.qpos + i] = a.qpos[(size_t)env * m.nq + i];
-    MJ_FOR(i, m.nv) { S[l.qvel + i] = a.qvel[(size_t)env * m.nv + i]; S[l.warm + i] = a.warm[(size_t)env * m.nv + i]; }
-    MJ_FOR(i, m.nu) S[l.ctrl + i] = a.ctrl[(size_t)env * m.nu + i];
-  }
-  // what the end of the step reads from HBM is fetched now, one element per lane, so that no load latency is left
-  // exposed after the integrator: the step counter and, for the fused plugin ops, the copy's action row and its
-  // data-store row (staged in the dead bias-force vector once the integrator is done; a program too large for that
-  // reads HBM directly)
-  const int ts = (a.forward_only || resetting) ? 0 : a.timestep[env];
+  // state in: the copy's rows (one element per lane and array, a second one of qpos when nq > 64), fetched whether or
+  // not the copy is flagged for an in-launch reset -- the flag arrives with them
+  const bool may_reset = a.reset_mask != nullptr && !a.forward_only;
+  const int r_mask = may_reset ? (int)a.reset_mask[env] : 0;
+  const int r_ts = a.forward_only ? 0 : a.timestep[env];
+  const real r_qpos0 = a.qpos[(size_t)env * m.nq + (L < m.nq ? L : 0)];
+  const real r_qpos1 = m.nq > 64 ? a.qpos[(size_t)env * m.nq + (L + 64 < m.nq ? L + 64 : 0)] : 0.0;
+  const real r_qvel = a.qvel[(size_t)env * m.nv + (L < m.nv ? L : 0)];
+  const real r_warm = a.warm[(size_t)env * m.nv + (L < m.nv ? L : 0)];
+  const real r_ctrl = m.nu > 0 ? a.ctrl[(size_t)env * m.nu + (L < m.nu ? L : 0)] : 0.0;
+  // what the end of the step reads from HBM is fetched now as well, one element per lane, so that no load latency is
+  // left exposed after the integrator: the step counter (above) and, for the fused plugin ops, the copy's action row
+  // and its data-store row (staged in the dead bias-force vector once the integrator is done; a program too large for
+  // that reads HBM directly)
   // staging area at the end of the step: the four nv-vectors from the bias forces on, all dead after the integrator
   //   [action row | data-store row | prog_f (4 per op) | prog_i (8 ints per op) | obs_len, agent_body (ints)]
   const int n_act_row = a.n_agent * a.act_dim, n_store_row = a.n_agent * a.n_slot;
@@ -2165,23 +2372,37 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // otherwise wait for two dependent loads of its own)
   const bool act_in_lanes = a.actions != nullptr && n_act_row <= 64;
   int sc_reg = -1;
-  if (act_in_lanes && L < n_act_row) {
-    act_reg = a.actions[(size_t)env * n_act_row + L];
-    if (a.scatter) sc_reg = a.scatter[L];
+  if (act_in_lanes && n_act_row > 0) {
+    const int i = L < n_act_row ? L : 0;
+    act_reg = a.actions[(size_t)env * n_act_row + i];
+    if (a.scatter) sc_reg = a.scatter[i];         // (lanes past the row hold entry 0: masked where it is used)
   }
   if (ops_staged) {
-    if (a.store && L < n_store_row)
-      store_reg = resetting ? __builtin_nan("") : a.store[(size_t)env * n_store_row + L];     // (reset: an empty store)
-    if (L < 4 * a.n_op) pf_reg = a.prog_f[L];
-    if (L < 8 * a.n_op) pi_reg = a.prog_i[L];
-    if (L < a.n_agent) { len_reg = a.agent_obs_len[L]; body_reg = a.agent_body[L]; }
+    if (a.store && n_store_row > 0) store_reg = a.store[(size_t)env * n_store_row + (L < n_store_row ? L : 0)];
+    pf_reg = a.prog_f[L < 4 * a.n_op ? L : 0];
+    pi_reg = a.prog_i[L < 8 * a.n_op ? L : 0];
+    if (a.n_agent > 0) { len_reg = a.agent_obs_len[L < a.n_agent ? L : 0]; body_reg = a.agent_body[L < a.n_agent ? L : 0]; }
   }
-  stage_constants(m, l, S, L);
+  // -- every load of the prologue is in flight; from here on their values are used --
+  const bool resetting = may_reset && wv::first_int(r_mask) != 0;
+  const int ts = (a.forward_only || resetting) ? 0 : wv::first_int(r_ts);
+  if (resetting) store_reg = __builtin_nan("");          // (reset: an empty store)
+  if (resetting && a.first_frame) {
+    MJ_FOR(i, m.nq) S[l.qpos + i] = m.qpos0[i];
+    MJ_FOR(i, m.nv) { S[l.qvel + i] = 0; S[l.warm + i] = a.reset_warm[i]; }
+    MJ_FOR(i, m.nu) S[l.ctrl + i] = 0;
+  } else {
+    if (L < m.nq) S[l.qpos + L] = r_qpos0;
+    if (m.nq > 64 && L + 64 < m.nq) S[l.qpos + L + 64] = r_qpos1;
+    if (L < m.nv) { S[l.qvel + L] = r_qvel; S[l.warm + L] = r_warm; }
+    if (L < m.nu) S[l.ctrl + L] = r_ctrl;
+  }
+  stage_constants(m, l, S, L, TR);
   wv::sync();
   // scatter the physical part of every agent's action (mujoco_parent.py:323-332)
   if (a.actions && a.scatter) {
     if (act_in_lanes) {
-      if (sc_reg >= 0) { if (a.scatter_mode == 0) S[l.ctrl + sc_reg] = act_reg; else S[l.qvel + sc_reg] = act_reg; }
+      if (L < n_act_row && sc_reg >= 0) { if (a.scatter_mode == 0) S[l.ctrl + sc_reg] = act_reg; else S[l.qvel + sc_reg] = act_reg; }
     } else {
       MJ_FOR(it, a.n_agent * a.act_dim) {
         int idx = a.scatter[it];
@@ -2198,30 +2419,54 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // in here would make everything a frame computes from the lane id, the lane constants and the model loop-invariant:
   // hoisted, those hundreds of masks and addresses stay live for the whole kernel and spill (340 VGPRs with AGPR
   // spill space against 218 without the loop).  Between launches the state round-trips through HBM, 2.5 KB per copy.
+  EulerK EK;
+  EK.gcode[0] = EK.gcode[1] = -3;          // (-3: not fetched -- a launch without a physics frame reads the table below)
+  int lpt_pos = -1, lpt_bucket = 0;
   if (a.skip_frames) {
-    stage_kinematics(m, l, K, S, L);
+    stage_kinematics(m, l, K, KK, S, L);
     MJ_STAMP(ST_KIN)
-    stage_com_inertia(m, l, K, S, L);
+    stage_com_inertia(m, l, K, KK, CK, S, L);
     MJ_STAMP(ST_COM)
+    // (model constants of a stage are fetched a stage or two ahead of it: with two waves on a SIMD nothing else hides a
+    // round trip to L2 at the head of a stage)
+    GeomK GK;
+    load_geom_constants(m, L, GK);
+    FactorRing ring;
+    factor_prefetch(m, L, ring);
     stage_crb(m, l, K, S, L, a.inertia + (size_t)env * m.nM);
     MJ_STAMP(ST_CRB)
-    factor_ld(m, S, l.LD, l.Dinv, L);
+    factor_ld(m, S, l.LD, l.Dinv, L, ring);
     MJ_STAMP(ST_FACTOR)
-    stage_geoms(m, l, S, L);
+    stage_geoms(m, l, GK, S, L);
     MJ_STAMP(ST_GEOM)
-    stage_collision(m, l, S, L);
+    ActK AK;
+    load_act_constants(m, L, K, AK);
+    stage_collision(m, l, GK, S, L);
     MJ_STAMP(ST_COLLIDE)
     stage_velocity(m, l, K, S, L, false);
     MJ_STAMP(ST_VEL)
-    stage_smooth(m, l, K, RK, S, L);
+    stage_smooth(m, l, K, RK, AK, S, L);
     MJ_STAMP(ST_SMOOTH)
     // (a raw-row debug dump keeps J unprojected; such a launch is for inspection only)
-    stage_rows(m, l, S, L, !(a.dbg && a.dbg_stage == 1), stamps);
+    stage_rows(m, l, AK, S, L, !(a.dbg && a.dbg_stage == 1), stamps);
     MJ_STAMP(ST_ROWS)
     if (a.dbg && a.dbg_stage == 1)
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     stage_pgs(m, l, K, RK, S, L, stamps);
     MJ_STAMP(ST_PGS)
+    // the copy's work bucket for the next launch is known now: the slot in the bucket's list is claimed here, a whole
+    // sensor stage and integrator ahead of the store that needs it
+    if (a.lpt_count_out && L == 0) {
+      const int* I = (const int*)(S + l.ints);
+      unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
+      int b = 0;
+      while (work) { b++; work >>= 1; }
+      if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
+      lpt_bucket = b;
+      lpt_pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
+    }
+    const bool integrate = !a.forward_only && m.integrator == 0;
+    load_euler_constants(m, a, K, L, a.inertia + (size_t)env * m.nM, integrate, EK);
     // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)
     if (m.integrator == 0 || a.rk_stage == 0) stage_sensors(m, l, K, S, L);
     MJ_STAMP(ST_SENSORS)
@@ -2246,7 +2491,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       }
     }
     if (!a.forward_only) {
-      if (m.integrator == 0) stage_euler(m, l, K, RK, S, L, a.inertia + (size_t)env * m.nM);
+      if (m.integrator == 0) stage_euler(m, l, K, RK, EK, S, L);
       else stage_rk4(m, l, S, L, a.rk_stage, a.rk + (size_t)env * (m.nq + 3 * m.nv));
     }
     if (ops_staged) {
@@ -2277,7 +2522,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // qpos/qvel are post-integration, exactly as the reference reads them after mj_step)
   if (a.obs) {
     MJ_FOR(it, a.n_agent * a.obs_dim) {
-      int code = a.gather[it];
+      int code = it < 64 ? EK.gcode[0] : (it < 128 ? EK.gcode[1] : -3);
+      if (code == -3) code = a.gather[it];
       if (code == -2) continue;        // slot owned by a fused dynamics op (written below by lane 0)
       real v = 0;
       if (code >= 0) {
@@ -2290,13 +2536,16 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   MJ_STAMP(ST_STORE)
   if (a.lpt_count_clear && wv::env_index() == 0 && L < LPT_BUCKETS) a.lpt_count_clear[L] = 0;
   if (a.lpt_count_out && L == 0) {
-    const int* I = (const int*)(S + l.ints);
-    unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
-    int b = 0;
-    while (work) { b++; work >>= 1; }
-    if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
-    int pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
-    a.lpt_list_out[(size_t)b * a.n_env + pos] = env;
+    if (lpt_pos < 0) {                 // (a launch without a physics frame: any bucket will do)
+      const int* I = (const int*)(S + l.ints);
+      unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
+      int b = 0;
+      while (work) { b++; work >>= 1; }
+      if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
+      lpt_bucket = b;
+      lpt_pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
+    }
+    a.lpt_list_out[(size_t)lpt_bucket * a.n_env + lpt_pos] = env;
   }
   if (a.stats && a.skip_frames && L < 4) {
     const int* I = (const int*)(S + l.ints);

@@ -685,6 +685,11 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     # broad-phase constants per pair: contact margin and the bounding-sphere reach (plane pairs: the other geom's)
     rb, mg = A["geom_rbound"], A["geom_margin"]
     A["pair_margin"] = np.array([max(mg[a], mg[b]) for a, b in pairs], np.float64)
+    # what a contact of the pair takes from its two geoms, so that the narrow phase reads one record per pair instead of
+    # following the geom ids: gap and sliding friction, both the larger of the two (MuJoCo's mixing rule for geom pairs)
+    gp, fr = A["geom_gap"], np.asarray(A["geom_friction"], np.float64).reshape(-1, 3)
+    A["pair_gap"] = np.array([max(gp[a], gp[b]) for a, b in pairs], np.float64)
+    A["pair_mu"] = np.array([max(fr[a, 0], fr[b, 0]) for a, b in pairs], np.float64)
     # reach of the broad-phase test: plane pairs and (sphere|capsule)-box pairs test ONE bounding sphere against the
     # plane / the box itself, every other pair tests the two bounding spheres against each other
     def reach(a, b):
