@@ -180,6 +180,13 @@ int mjrl_lds_offset(const mjrl_env* env, const char* region);
 int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames,
                       unsigned long long* h_cycles, int n);
 
+/* Diagnostic: one launch of the step kernel in which every wave ends right after stage number `stop_after` (1-based, in
+ * the stage order of mjrl_step_profile; 1..15 are the stages of the step proper) and nothing is written back: the copies'
+ * state is untouched.  Hardware counters (rocprofv3 --pmc) of launches cut at successive stages give each stage's
+ * instruction mix by difference (tools/stage_mix.py).  The cuts exist only in a specialised kernel built with
+ * -DMJRL_STAGE_CUT (MJRL_SPEC_FLAGS); any other kernel leaves such a launch at once. */
+int mjrl_step_truncated(mjrl_env* env, int stop_after);
+
 /* Diagnostic: one step whose waves record when they ran.  h_out[3*w + 0..2] = start and end of workgroup w's wave on
  * the device's constant 100 MHz clock and the env copy it stepped (w is the dispatch order, which the longest-first
  * scheduling decouples from the copy index).  n must be 3 * n_env; skip_frames must be 1. */

@@ -20,6 +20,7 @@ SYMBOLS = [
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
+    "mjrl_step_truncated",
     "mjrl_reset_device", "mjrl_set_step_reset_mask", "mjrl_set_tag_tables", "mjrl_set_env_base", "mjrl_set_variants",
     "mjrl_encoder_load", "mjrl_encode_device", "mjrl_encode_host", "mjrl_set_camera_obs",
 ]
@@ -77,6 +78,7 @@ def load():
     L.mjrl_load_kernel.argtypes = [vp, ctypes.c_char_p]
     L.mjrl_cap_overflows.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     L.mjrl_step_timeline.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t]
+    L.mjrl_step_truncated.argtypes = [vp, ctypes.c_int]
     _lib = L
     return L
 
@@ -98,7 +100,9 @@ class Handle:
     def __init__(self, blob: bytes, n_env: int, device_id: int = 0, specialize: bool | None = None):
         self._lib = load()
         self._h = ctypes.c_void_p()
-        rc = self._lib.mjrl_create(blob, len(blob), int(n_env), int(device_id), 0, ctypes.byref(self._h))
+        # (MJRL_CREATE_FLAGS: experiments only -- bit 0 switches the longest-first dispatch off)
+        flags = int(os.environ.get("MJRL_CREATE_FLAGS", "0"))
+        rc = self._lib.mjrl_create(blob, len(blob), int(n_env), int(device_id), flags, ctypes.byref(self._h))
         if rc:
             raise Exception(f"mjrl_create failed ({rc}): {self._lib.mjrl_last_error(None).decode()}")
         self.n_env = int(n_env)
@@ -306,6 +310,10 @@ class Handle:
         out = np.zeros(len(self.STAGES), np.uint64)
         self._check(self._lib.mjrl_step_profile(self._h, None, 0, int(skip_frames), _host_ptr(out), out.size))
         return dict(zip(self.STAGES, out.tolist()))
+
+    def step_truncated(self, stage: str):
+        """Diagnostic launch that ends every wave right after ``stage`` (a name of STAGES[:15]); writes nothing back."""
+        self._check(self._lib.mjrl_step_truncated(self._h, self.STAGES.index(stage) + 1))
 
     def step_timeline(self, d_actions=None, act_dim=0):
         """One step; ``[n_env, 3]`` uint64 per workgroup in dispatch order: wave start, wave end (100 MHz ticks), copy."""

@@ -256,9 +256,12 @@ struct mjrl_env {
   // longest-first dispatch: two generations of work buckets (read the previous launch's, fill the next one's)
   // three generations of work buckets: a launch reads one, files into the next and clears the third for the launch
   // after it (a hipMemsetAsync per step was a 5 us kernel of its own, 2 % of the step)
-  int *lpt_count[3] = {nullptr, nullptr, nullptr}, *lpt_list[3] = {nullptr, nullptr, nullptr};
+  int* lpt_count[3] = {nullptr, nullptr, nullptr};
+  unsigned* lpt_mask[3] = {nullptr, nullptr, nullptr};     // [LPT_BUCKETS][lpt_words] bit sets
+  int lpt_words = 0;
   int lpt_cur = 0;
   bool lpt_valid = false, lpt_enabled = true;
+  int stop_after = 0;              // diagnostic (mjrl_step_truncated)
   // forward-pass frames kept for host-side plugin queries
   double* frames = nullptr;
   bool frames_valid = false;
@@ -299,7 +302,7 @@ struct DeviceGuard {
 
 extern "C" {
 
-const char* mjrl_version(void) { return "mjrl-hip 0.5 (blob layout 12, gfx950)"; }
+const char* mjrl_version(void) { return "mjrl-hip 0.6 (blob layout 13, gfx950)"; }
 
 const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 
@@ -309,7 +312,7 @@ void mjrl_destroy(mjrl_env* e) {
   void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
-                  e->lpt_list[0], e->lpt_list[1], e->lpt_list[2], e->inertia, e->overflow};
+                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->inertia, e->overflow};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->spec_module) hipModuleUnload(e->spec_module);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
@@ -373,16 +376,18 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   if (m.integrator == 1) CK(hipMalloc(&e->rk, sizeof(double) * (size_t)n_env * (m.nq + 3 * m.nv)));
   CK(hipMalloc(&e->stats, sizeof(int) * 4 * (size_t)n_env));
   CK(hipMemset(e->stats, 0, sizeof(int) * 4 * (size_t)n_env));
-  CK(hipMalloc(&e->overflow, sizeof(unsigned long long) * 2));
-  CK(hipMemset(e->overflow, 0, sizeof(unsigned long long) * 2));
+  CK(hipMalloc(&e->overflow, sizeof(unsigned long long) * 3));
+  CK(hipMemset(e->overflow, 0, sizeof(unsigned long long) * 3));
   CK(hipMalloc(&e->sens, sizeof(double) * n_env * (m.nsensordata > 0 ? m.nsensordata : 1)));
   CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
   CK(hipMalloc(&e->d_mask, n_env));
   e->lpt_enabled = !(flags & 1u);
+  e->lpt_words = (n_env + 31) / 32;
   for (int g = 0; g < 3; g++) {
     CK(hipMalloc(&e->lpt_count[g], sizeof(int) * mj::LPT_BUCKETS));
     CK(hipMemset(e->lpt_count[g], 0, sizeof(int) * mj::LPT_BUCKETS));
-    CK(hipMalloc(&e->lpt_list[g], sizeof(int) * mj::LPT_BUCKETS * (size_t)n_env));
+    CK(hipMalloc(&e->lpt_mask[g], sizeof(unsigned) * mj::LPT_BUCKETS * (size_t)e->lpt_words));
+    CK(hipMemset(e->lpt_mask[g], 0, sizeof(unsigned) * mj::LPT_BUCKETS * (size_t)e->lpt_words));
   }
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_camera_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -846,14 +851,17 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     a.first_frame = f == 0;
     a.dbg = last ? d_dbg : nullptr;
     a.frames = last ? e->frames : nullptr;
-    a.lpt_count_in = nullptr; a.lpt_list_in = nullptr; a.lpt_count_out = nullptr; a.lpt_list_out = nullptr;
-    a.lpt_count_clear = nullptr;
-    if (e->lpt_enabled && !forward_only && !d_dbg) {
-      int in = e->lpt_cur, out = (e->lpt_cur + 1) % 3;
-      a.lpt_count_clear = e->lpt_count[(e->lpt_cur + 2) % 3];
-      if (e->lpt_valid) { a.lpt_count_in = e->lpt_count[in]; a.lpt_list_in = e->lpt_list[in]; }
+    a.lpt_count_in = nullptr; a.lpt_mask_in = nullptr; a.lpt_count_out = nullptr; a.lpt_mask_out = nullptr;
+    a.lpt_count_clear = nullptr; a.lpt_mask_clear = nullptr;
+    a.lpt_words = e->lpt_words;
+    a.stop_after = e->stop_after;
+    if (e->lpt_enabled && !forward_only && !d_dbg && !e->stop_after) {
+      int in = e->lpt_cur, out = (e->lpt_cur + 1) % 3, next = (e->lpt_cur + 2) % 3;
+      a.lpt_count_clear = e->lpt_count[next];
+      a.lpt_mask_clear = e->lpt_mask[next];
+      if (e->lpt_valid) { a.lpt_count_in = e->lpt_count[in]; a.lpt_mask_in = e->lpt_mask[in]; }
       a.lpt_count_out = e->lpt_count[out];
-      a.lpt_list_out = e->lpt_list[out];
+      a.lpt_mask_out = e->lpt_mask[out];
       e->lpt_cur = out;
       e->lpt_valid = true;
     }
@@ -879,8 +887,12 @@ int mjrl_cap_overflows(mjrl_env* e, unsigned long long* h_counts, int clear) {
   MJRL_ENTER(e);
   if (!h_counts) MJRL_FAIL(e, 4, "cap_overflows: null output");
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
-  MJRL_HIP(e, hipMemcpy(h_counts, e->overflow, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost));
+  unsigned long long all[3] = {0, 0, 0};
+  MJRL_HIP(e, hipMemcpy(all, e->overflow, sizeof(all), hipMemcpyDeviceToHost));
+  h_counts[0] = all[0]; h_counts[1] = all[1];
   if (clear) MJRL_HIP(e, hipMemset(e->overflow, 0, sizeof(unsigned long long) * 2));
+  // (never seen: a workgroup whose share of the dispatch tables held no copy left its copy unstepped)
+  if (all[2]) MJRL_FAIL(e, 7, "dispatch tables were inconsistent in %llu workgroup launches: copies were not stepped", all[2]);
   return 0;
 }
 
@@ -1101,6 +1113,15 @@ int mjrl_step_profile(mjrl_env* e, const double* d_actions, int act_dim, int ski
     if (he != hipSuccess) { e->err = hipGetErrorString(he); rc = 100 + (int)he; }
   }
   hipFree(d);
+  return rc;
+}
+
+int mjrl_step_truncated(mjrl_env* e, int stop_after) {
+  MJRL_ENTER(e);
+  if (stop_after < 1 || stop_after > mj::N_STAMPS) MJRL_FAIL(e, 4, "step_truncated: stage index %d outside 1..%d", stop_after, (int)mj::N_STAMPS);
+  e->stop_after = stop_after;
+  int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0);
+  e->stop_after = 0;
   return rc;
 }
 

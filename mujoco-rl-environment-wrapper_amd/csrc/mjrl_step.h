@@ -184,21 +184,28 @@ struct StepArgs {
   real* frames;
   // Longest-first dispatch: a copy's solver work (rows x sweeps) in the previous step predicts this step's, and
   // workgroups are dispatched in index order, so handing the heavy copies to the lowest workgroup ids keeps a straggler
-  // from starting last.  Each wave files its copy under a work bucket for the next launch (lpt_*_out) and picks its copy
-  // from the previous launch's buckets, heaviest bucket first (lpt_*_in; null = identity order).  Which workgroup steps a
-  // copy has no effect on the copy's result.
-  const int* lpt_count_in;     // [LPT_BUCKETS]
-  const int* lpt_list_in;      // [LPT_BUCKETS][n_env]
+  // from starting last.  Each wave files its copy under a work bucket for the next launch -- one count and one bit set
+  // per bucket, lpt_*_out, updated by atomics that return nothing -- and picks its copy from the previous launch's
+  // buckets, heaviest bucket first (lpt_*_in; null = identity order): workgroup w steps the copy of the w-th set bit.
+  // Which workgroup steps a copy has no effect on the copy's result.
+  const int* lpt_count_in;          // [LPT_BUCKETS]
+  const unsigned* lpt_mask_in;      // [LPT_BUCKETS][lpt_words]: bit e of a bucket's row = copy e is in the bucket
   int* lpt_count_out;
-  int* lpt_list_out;
-  int* lpt_count_clear;        // [LPT_BUCKETS] the counts the NEXT launch files into: zeroed by workgroup 0 of this one
+  unsigned* lpt_mask_out;
+  int* lpt_count_clear;             // the tables the NEXT launch files into: zeroed by this one (counts by workgroup 0,
+  unsigned* lpt_mask_clear;         // word i of every bucket's row by workgroup i)
+  int lpt_words;                    // (n_env + 31) / 32
   // Sticky count of physics frames that ran into a cap (what MuJoCo reports as mjWARN_CONTACTFULL / mjWARN_CNSTRFULL):
   // [0] frames whose contact list was cut at nconmax, [1] frames whose row list was cut at njmax.  Not touched by
-  // forward-only launches.
+  // forward-only launches.  [2] workgroups that found no copy in the dispatch tables although the counts covered them
+  // (cannot happen with consistent tables; mjrl_cap_overflows turns a non-zero count into an error).
   unsigned long long* overflow;
   // diagnostic: [n_env][3] per workgroup, in dispatch order: start and end of the wave on the constant 100 MHz clock
   // and the copy it stepped; null outside tools/timeline_probe.py
   unsigned long long* timeline;
+  // diagnostic: k > 0 ends every wave right after stage k - 1 (ST_* order) without writing anything back, so that
+  // hardware counters of launches cut at successive stages give the instruction mix of each stage (tools/stage_mix.py)
+  int stop_after;
 };
 enum { LPT_BUCKETS = 16 };
 
@@ -2293,6 +2300,53 @@ __device__ inline void stage_rk4(const DevModel& m, const Lay& l, real* S, int L
   wv::sync();
 }
 
+// Longest-first dispatch, workgroup id -> copy (see StepArgs::lpt_*): walk the bucket counts from the heaviest bucket
+// down (they come in with one load, lane b holding bucket b's: my_count), then take the set bit of that rank in the
+// bucket's row.  Lane L counts the bits of words 2L and 2L + 1 of a block of 128 words; the prefix over the lanes comes
+// from seven ballots (a lane's count is below 128), the lane that holds the bit and the bit's place in its word are
+// found in scalar registers.  Returns the copy, -1 when the counts do not cover the workgroup (they sum to n_env by
+// construction: such a workgroup has no copy to step), -2 when the rows disagree with the counts.
+__device__ inline int lpt_copy_of(const StepArgs& a, int L, int wg, int my_count, int& bucket_out) {
+  int rest = wg, bucket = -1;
+  for (int b = LPT_BUCKETS - 1; b >= 0; b--) {
+    int c = wv::lane_int(my_count, b);
+    if (bucket < 0) {
+      if (rest < c) bucket = b; else rest -= c;
+    }
+  }
+  if (bucket < 0) return -1;
+  bucket_out = bucket;
+  const unsigned* row = a.lpt_mask_in + (size_t)bucket * a.lpt_words;
+  const unsigned long long upto = (2ull << L) - 1ull;              // lanes 0..L
+  int found = -1, before = 0;
+  for (int w0 = 0; w0 < a.lpt_words && found < 0; w0 += 128) {
+    const int i0 = w0 + 2 * L, i1 = i0 + 1;
+    const unsigned m0 = row[i0 < a.lpt_words ? i0 : 0], m1 = row[i1 < a.lpt_words ? i1 : 0];
+    const unsigned u0 = i0 < a.lpt_words ? m0 : 0u, u1 = i1 < a.lpt_words ? m1 : 0u;
+    const int c = wv::popc32(u0) + wv::popc32(u1);
+    int incl = 0;
+    for (int bit = 0; bit < 7; bit++) incl += wv::popc(wv::ballot(((c >> bit) & 1) != 0) & upto) << bit;
+    const int total = wv::lane_int(incl, 63), local = rest - before;
+    if (local < total) {
+      const int sel = wv::first_set(wv::ballot(incl > local));
+      int r = local - (wv::lane_int(incl, sel) - wv::lane_int(c, sel));
+      const unsigned s0 = (unsigned)wv::lane_int((int)u0, sel), s1 = (unsigned)wv::lane_int((int)u1, sel);
+      unsigned word = s0;
+      int wi = w0 + 2 * sel;
+      if (r >= wv::popc32(s0)) { r -= wv::popc32(s0); word = s1; wi++; }
+      int pos = 0;
+      for (int sh = 16; sh >= 1; sh >>= 1) {
+        const unsigned lo = word & ((1u << sh) - 1u);
+        const int cc = wv::popc32(lo);
+        if (r >= cc) { r -= cc; word >>= sh; pos += sh; } else word = lo;
+      }
+      found = 32 * wi + pos;
+    }
+    before += total;
+  }
+  return (found < 0 || found >= a.n_env) ? -2 : found;
+}
+
 // ------------------------------------------------------------------ one env copy, one step() call
 __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   const int L = wv::lane();
@@ -2302,6 +2356,9 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // and nothing else of the wave can start before it ends.  So every load that does not need the copy's id is issued
   // before the id is known, and every load that needs it is issued before the first of them is waited for: three round
   // trips in all (they were eleven when each block of state was fetched and stored in turn).
+#ifndef MJRL_STAGE_CUT
+  if (a.stop_after) return;          // (a truncated launch on a kernel without the cuts must not run a whole step)
+#endif
   int my_count = 0;
   if (a.lpt_count_in) my_count = a.lpt_count_in[L & (LPT_BUCKETS - 1)];
   Lay l;
@@ -2317,19 +2374,10 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   ComK CK;
   load_com_constants(m, L, CK);
   if (a.lpt_count_in) {
-    // workgroup id -> copy: walk the buckets from the heaviest down
-    // (the bucket counts come in with one load, lane b holding bucket b's; walking them is register work -- a loop of
-    // dependent loads here cost every wave several L2 round trips before it could even fetch its state)
-    int rest = env, bucket = -1;
-    for (int b = LPT_BUCKETS - 1; b >= 0; b--) {
-      int c = wv::lane_int(my_count, b);
-      if (bucket < 0) {
-        if (rest < c) bucket = b; else rest -= c;
-      }
-    }
-    // (the bucket counts sum to n_env by construction; a workgroup past them has no copy to step)
-    if (bucket < 0) return;
-    env = a.lpt_list_in[(size_t)bucket * a.n_env + rest];
+    int bucket = 0;
+    env = lpt_copy_of(a, L, env, my_count, bucket);
+    if (env == -2 && a.overflow && L == 0) wv::atomic_add(a.overflow + 2, 1ull);
+    if (env < 0) return;
     // The launch ends with its slowest copy, and a copy with hundreds of solver row steps is one long dependent
     // chain: its wave gets issue priority over the waves that share its SIMD (they fill the gaps it leaves).
     wv::set_priority(bucket >= 10 ? 3 : (bucket == 9 ? 2 : (bucket == 8 ? 1 : 0)));
@@ -2340,12 +2388,20 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   clock_state.prev = a.stamps ? wv::clock() : 0ull;
   clock_state.mine = 0;
   Stamps* const stamps = a.stamps ? &clock_state : nullptr;
+  // (the stage cuts of mjrl_step_truncated exist in diagnostic builds only, -DMJRL_STAGE_CUT through MJRL_SPEC_FLAGS:
+  // an exit after every stage costs the 4-agent kernel 1.4 KB of scratch per lane)
+#ifdef MJRL_STAGE_CUT
+#define MJ_CUT(k) if (a.stop_after == (k) + 1) return;
+#else
+#define MJ_CUT(k)
+#endif
 #define MJ_STAMP(k)                                                        \
   if (stamps) {                                                            \
     unsigned long long t_now = wv::clock();                                \
     if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
     stamps->prev = t_now;                                                  \
-  }
+  }                                                                        \
+  MJ_CUT(k)
 #define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
   // state in: the copy's rows (one element per lane and array, a second one of qpos when nq > 64), fetched whether or
   // not the copy is flagged for an in-launch reset -- the flag arrives with them
@@ -2421,7 +2477,6 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // spill space against 218 without the loop).  Between launches the state round-trips through HBM, 2.5 KB per copy.
   EulerK EK;
   EK.gcode[0] = EK.gcode[1] = -3;          // (-3: not fetched -- a launch without a physics frame reads the table below)
-  int lpt_pos = -1, lpt_bucket = 0;
   if (a.skip_frames) {
     stage_kinematics(m, l, K, KK, S, L);
     MJ_STAMP(ST_KIN)
@@ -2454,17 +2509,6 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     stage_pgs(m, l, K, RK, S, L, stamps);
     MJ_STAMP(ST_PGS)
-    // the copy's work bucket for the next launch is known now: the slot in the bucket's list is claimed here, a whole
-    // sensor stage and integrator ahead of the store that needs it
-    if (a.lpt_count_out && L == 0) {
-      const int* I = (const int*)(S + l.ints);
-      unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
-      int b = 0;
-      while (work) { b++; work >>= 1; }
-      if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
-      lpt_bucket = b;
-      lpt_pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
-    }
     const bool integrate = !a.forward_only && m.integrator == 0;
     load_euler_constants(m, a, K, L, a.inertia + (size_t)env * m.nM, integrate, EK);
     // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)
@@ -2535,18 +2579,8 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   }
   MJ_STAMP(ST_STORE)
   if (a.lpt_count_clear && wv::env_index() == 0 && L < LPT_BUCKETS) a.lpt_count_clear[L] = 0;
-  if (a.lpt_count_out && L == 0) {
-    if (lpt_pos < 0) {                 // (a launch without a physics frame: any bucket will do)
-      const int* I = (const int*)(S + l.ints);
-      unsigned work = (unsigned)(I[I_NEFC] * I[I_NITER]);
-      int b = 0;
-      while (work) { b++; work >>= 1; }
-      if (b > LPT_BUCKETS - 1) b = LPT_BUCKETS - 1;
-      lpt_bucket = b;
-      lpt_pos = wv::atomic_add_int(a.lpt_count_out + b, 1);
-    }
-    a.lpt_list_out[(size_t)lpt_bucket * a.n_env + lpt_pos] = env;
-  }
+  if (a.lpt_mask_clear && wv::env_index() < a.lpt_words && L < LPT_BUCKETS)
+    a.lpt_mask_clear[(size_t)L * a.lpt_words + wv::env_index()] = 0u;
   if (a.stats && a.skip_frames && L < 4) {
     const int* I = (const int*)(S + l.ints);
     a.stats[4 * (size_t)env + L] = I[L == 0 ? I_NCON : (L == 1 ? I_NEFC : (L == 2 ? I_NITER : I_WARN))];
@@ -2556,6 +2590,18 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     if (warn & 1) wv::atomic_add(a.overflow + 0, 1ull);
     if (warn & 2) wv::atomic_add(a.overflow + 1, 1ull);
   }
+  // The copy's work bucket for the next launch: one count, one bit.  The last thing a wave issues -- the atomics
+  // return nothing, and nothing is left that could have to wait behind them.
+#define MJ_FILE_WORK                                                                                         \
+  if (a.lpt_count_out && L == 0) {                                                                           \
+    const int* Iw = (const int*)(S + l.ints);                                                                \
+    unsigned work = (unsigned)(Iw[I_NEFC] * Iw[I_NITER]);                                                    \
+    int wb = 0;                                                                                              \
+    while (work) { wb++; work >>= 1; }                                                                       \
+    if (wb > LPT_BUCKETS - 1) wb = LPT_BUCKETS - 1;                                                          \
+    wv::atomic_add_noret(a.lpt_count_out + wb, 1);                                                           \
+    wv::atomic_or_noret(a.lpt_mask_out + (size_t)wb * a.lpt_words + (env >> 5), 1u << (env & 31));          \
+  }
 #define MJ_TIMELINE                                                                        \
   if (a.timeline && L == 0) {                                                              \
     unsigned long long* tl = a.timeline + 3 * (size_t)wv::env_index();                     \
@@ -2564,6 +2610,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   if (a.forward_only || a.more_frames) {
     MJ_STAMP(ST_TAIL)
     if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+    MJ_FILE_WORK
     MJ_TIMELINE
     return;
   }
@@ -2677,9 +2724,12 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   }
   MJ_STAMP(ST_TAIL)
   if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+  MJ_FILE_WORK
   MJ_TIMELINE
 #undef MJ_TIMELINE
+#undef MJ_FILE_WORK
 #undef MJ_STAMP
+#undef MJ_CUT
 #undef MJ_FOR
 }
 

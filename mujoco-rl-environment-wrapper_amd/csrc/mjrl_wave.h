@@ -34,6 +34,18 @@ __device__ __forceinline__ void atomic_add(unsigned long long* p, unsigned long 
 // device-scope counter add returning the old value (work-bucket slots of the longest-first dispatch)
 __device__ __forceinline__ int atomic_add_int(int* p, int v) { return atomicAdd(p, v); }
 
+// device-scope counter / bit-set updates whose old value nobody needs: no register comes back, so the wave never waits
+// for them (an atomic WITH a return value is waited for where it is issued, and 2048 waves queueing on a handful of
+// addresses made that wait the longest stall of the whole step)
+__device__ __forceinline__ void atomic_add_noret(int* p, int v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void atomic_or_noret(unsigned* p, unsigned v) {
+  (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int popc32(unsigned x) { return __builtin_popcount(x); }
+__device__ __forceinline__ int first_set(unsigned long long x) { return __builtin_ctzll(x); }    // x != 0
+
 // 64-bit value moved with a DPP control word (two v_mov_b32_dpp); every lane reads a lane of its own row of 16
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {

@@ -38,7 +38,8 @@ def lib():
         L.emu_set_step_reset.restype = None
         L.emu_set_tags.argtypes = [P, P, P, ctypes.c_int]
         L.emu_set_tags.restype = None
-        L.emu_set_lpt.argtypes = [P, P]
+        L.emu_set_lpt.argtypes = [P, P, ctypes.c_int]
+        L.emu_lpt_lookup.argtypes = [P, P, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, P]
         L.emu_set_lpt.restype = None
         _lib = L
     return _lib

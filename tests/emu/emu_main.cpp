@@ -67,11 +67,19 @@ void yield_lane() {
   emu_switch(&lane_sp[me], lane_sp[nxt]);
 }
 
-struct Job { const DevModel* m; const mj::StepArgs* a; double* lds; };
+struct Job { const DevModel* m; const mj::StepArgs* a; double* lds; int* lookup_out; int lookup_wg; };
 static Job job;
 
 static void lane_entry() {
-  mj::env_step(*job.m, *job.a, job.lds);
+  if (job.lookup_out) {          // the dispatch lookup alone (emu_lpt_lookup)
+    const int L = wv::lane();
+    int bucket = 0;
+    const int my_count = job.a->lpt_count_in[L & (mj::LPT_BUCKETS - 1)];
+    const int copy = mj::lpt_copy_of(*job.a, L, job.lookup_wg, my_count, bucket);
+    if (L == 0) *job.lookup_out = copy;
+  } else {
+    mj::env_step(*job.m, *job.a, job.lds);
+  }
   int me = cur_lane;
   done[me] = true;
   int nxt = next_live(me);
@@ -82,14 +90,14 @@ static void lane_entry() {
   __builtin_trap();
 }
 
-static int run_wave(const DevModel& m, const mj::StepArgs& a, double* lds) {
+static int run_wave(const DevModel& m, const mj::StepArgs& a, double* lds, int* lookup_out = nullptr, int lookup_wg = 0) {
   const size_t stack_bytes = 1 << 20;
   stacks.resize(64 * stack_bytes + 64);
 #ifdef MJRL_EMU_SANITIZED
   // the fibers of the previous wave never returned: their frames' redzones are still poisoned
   __asan_unpoison_memory_region(stacks.data(), stacks.size());
 #endif
-  job = {&m, &a, lds};
+  job = {&m, &a, lds, lookup_out, lookup_wg};
   for (int i = 0; i < 64; i++) {
     done[i] = false;
     sync_count[i] = 0;
@@ -150,8 +158,20 @@ void emu_set_tags(const int32_t* adr, const int32_t* num, const int32_t* ref, in
 }
 
 // longest-first dispatch tables of the following emu_step calls (launch_step's lpt_count_in / lpt_list_in); null: identity
-static const int *g_lpt_count = nullptr, *g_lpt_list = nullptr;
-void emu_set_lpt(const int* count_in, const int* list_in) { g_lpt_count = count_in; g_lpt_list = list_in; }
+static const int* g_lpt_count = nullptr;
+static const unsigned* g_lpt_mask = nullptr;
+static int g_lpt_words = 0;
+void emu_set_lpt(const int* count_in, const unsigned* mask_in, int words) { g_lpt_count = count_in; g_lpt_mask = mask_in; g_lpt_words = words; }
+
+// the copy workgroup ids[k] of a launch would step, given dispatch tables (mj::lpt_copy_of run by a whole emulated wave)
+int emu_lpt_lookup(const int* count_in, const unsigned* mask_in, int words, int n_env, const int* ids, int n, int* out) {
+  DevModel m{};
+  mj::StepArgs a{};
+  a.lpt_count_in = count_in; a.lpt_mask_in = mask_in; a.lpt_words = words; a.n_env = n_env;
+  for (int k = 0; k < n; k++)
+    if (emu::run_wave(m, a, nullptr, out + k, ids[k])) return 2;
+  return 0;
+}
 
 // one env copy, `nsteps` step() calls with the same actions; state arrays are updated in place
 int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double* ctrl, double* warm, double* sens,
@@ -176,7 +196,7 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.reward = reward; a.term = term; a.trunc = trunc;
   a.prog_i = prog_i; a.prog_f = prog_f; a.n_op = forward_only ? 0 : n_op; a.n_slot = n_slot;
   a.agent_body = agent_body; a.agent_obs_len = agent_obs_len; a.store = store;
-  a.lpt_count_in = g_lpt_count; a.lpt_list_in = g_lpt_list;
+  a.lpt_count_in = g_lpt_count; a.lpt_mask_in = g_lpt_mask; a.lpt_words = g_lpt_words;
   a.tag_adr = g_tag_adr; a.tag_num = g_tag_num; a.tag_ref = g_tag_ref; a.env_base = g_env_base;
   a.max_steps = max_steps; a.n_env = 1;
   a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;

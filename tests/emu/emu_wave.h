@@ -50,6 +50,10 @@ inline unsigned long long clock() { return 0; }
 inline unsigned long long realtime() { return 0; }
 inline void atomic_add(unsigned long long* p, unsigned long long v) { *p += v; }
 inline int atomic_add_int(int* p, int v) { int old = *p; *p += v; return old; }
+inline void atomic_add_noret(int* p, int v) { *p += v; }
+inline void atomic_or_noret(unsigned* p, unsigned v) { *p |= v; }
+inline int popc32(unsigned x) { return __builtin_popcount(x); }
+inline int first_set(unsigned long long x) { return __builtin_ctzll(x); }
 inline double sum_n(double v, int width) {   // all-reduce over aligned groups of `width` lanes (16, 32 or 64)
   for (int mask = 1; mask < width; mask <<= 1) v += shfl_xor(v, mask);
   return v;

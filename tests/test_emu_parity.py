@@ -524,25 +524,52 @@ def test_target_and_pick_up_ops_follow_their_reference_dynamics():
 
 def test_longest_first_lookup_and_a_short_bucket_list():
     """The workgroup -> copy lookup of the longest-first dispatch: a workgroup finds its copy by walking the previous
-    launch's work buckets from the heaviest down; when the bucket counts do not cover the workgroup (they always sum to
-    n_env in launch_step -- this is the guard) the wave must leave without touching anything, not index with -1."""
+    launch's work buckets from the heaviest down and taking the set bit of its rank in the bucket's row; when the bucket
+    counts do not cover the workgroup (they always sum to n_env in launch_step -- this is the guard) the wave must leave
+    without touching anything, not index with -1."""
     from tests.emu.emu import lib, _p
     model, ora, emu = pair("two_agent.xml")
     counts = np.zeros(16, np.int32)
-    lists = np.full((16, 1), 0, np.int32)
+    masks = np.zeros((16, 1), np.uint32)
     counts[7] = 1                                     # the one copy sits in bucket 7
-    lib().emu_set_lpt(_p(counts), _p(lists))
+    masks[7, 0] = 1
+    lib().emu_set_lpt(_p(counts), _p(masks), 1)
     try:
         emu.step()
         ora.step()
         assert np.allclose(emu.qpos, ora.qpos, atol=1e-12) and emu.timestep[0] == 1
-        counts[:] = 0                                 # a list that does not cover workgroup 0
+        counts[:] = 0                                 # tables that do not cover workgroup 0
         before = (emu.qpos.copy(), emu.qvel.copy(), emu.warm.copy(), emu.timestep.copy())
         emu.step()
         for was, now in zip(before, (emu.qpos, emu.qvel, emu.warm, emu.timestep)):
             assert np.array_equal(was, now)
     finally:
-        lib().emu_set_lpt(None, None)
+        lib().emu_set_lpt(None, None, 0)
+
+
+def test_rank_of_a_copy_in_the_dispatch_bit_sets():
+    """The lookup itself over many ranks: the device code's answer for (bucket counts, bit rows, workgroup id) equals
+    the w-th copy of the buckets walked from the heaviest down, for rows longer than one block of 128 words, copies
+    in the last word, empty buckets in between, and every workgroup id of a batch."""
+    from tests.emu.emu import lib, _p
+    rng = np.random.default_rng(5)
+    for n_env in (1, 37, 4096, 5000):
+        words = (n_env + 31) // 32
+        bucket_of = rng.integers(0, 16, n_env)
+        bucket_of[rng.random(n_env) < 0.5] = 3            # one crowded bucket
+        counts = np.bincount(bucket_of, minlength=16).astype(np.int32)
+        masks = np.zeros((16, words), np.uint32)
+        for e, b in enumerate(bucket_of):
+            masks[b, e >> 5] |= np.uint32(1 << (e & 31))
+        order = [e for b in range(15, -1, -1) for e in range(n_env) if bucket_of[e] == b]
+        ids = sorted(set([0, n_env - 1, n_env // 2] + list(rng.integers(0, n_env, 24))))
+        got = np.zeros(len(ids), np.int32)
+        lib().emu_lpt_lookup(_p(counts), _p(masks), words, n_env, _p(np.array(ids, np.int32)), len(ids), _p(got))
+        assert list(got) == [order[w] for w in ids], n_env
+    # a workgroup past the counts gets no copy
+    got = np.zeros(1, np.int32)
+    lib().emu_lpt_lookup(_p(np.zeros(16, np.int32)), _p(np.zeros((16, 1), np.uint32)), 1, 1, _p(np.array([0], np.int32)), 1, _p(got))
+    assert got[0] == -1
 
 
 def test_fixed_identity_frames_in_the_broad_phase_give_the_same_bits():
