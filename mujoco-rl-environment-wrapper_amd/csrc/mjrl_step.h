@@ -588,9 +588,14 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
 // The schedule words of the first FACTOR_AHEAD elimination steps of a factorisation, fetched ahead of it (before the
 // stage in front) so that the factorisation starts without a round trip to L2 of its own.
 enum { FACTOR_AHEAD = 4 };
-struct FactorRing { unsigned q[FACTOR_AHEAD]; };
+struct FactorRing { unsigned q[FACTOR_AHEAD]; int adr0, num; };      // (adr0, num: first dof and dof count of the lane's tree in pass 0)
 __device__ __forceinline__ void factor_prefetch(const DevModel& m, int L, FactorRing& r) {
   const int32_t* sched = m.factor_sched + L;
+  {
+    const int groups = m.ntree > 1 ? 2 : 1, tree = L / (64 / groups);
+    r.adr0 = m.tree_dofadr[tree < m.ntree ? tree : 0];
+    r.num = tree < m.ntree ? m.tree_dofnum[tree] : 0;
+  }
 #pragma unroll
   for (int u = 0; u < FACTOR_AHEAD; u++) {
     const int kk = m.maxtreedof - 1 - u;
@@ -604,7 +609,7 @@ __device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, i
   for (int ps = 0; ps < m.npass; ps++) {
     int tree = ps * groups + g;
     bool has_tree = tree < m.ntree;
-    int adr0 = has_tree ? m.tree_dofadr[tree] : 0, num = has_tree ? m.tree_dofnum[tree] : 0;
+    int adr0 = ps == 0 ? ring.adr0 : (has_tree ? m.tree_dofadr[tree] : 0), num = ps == 0 ? ring.num : (has_tree ? m.tree_dofnum[tree] : 0);
     // the lane's (ancestor, offset) pair of every elimination step comes from the host-built schedule, fetched
     // FACTOR_AHEAD steps before its use (a step is two short LDS phases, far less than a round trip to L2)
     const int32_t* sched = m.factor_sched + (size_t)ps * m.maxtreedof * 64 + L;
@@ -2208,7 +2213,7 @@ __device__ __forceinline__ void load_euler_constants(const DevModel& m, const St
   for (int t = 0; t < MAX_DOF_DEPTH; t++)     // (entries past the lane's row repeat its diagonal and are not used)
     E.mg[t] = integrate ? Mg[K.d_Madr + (t <= K.d_depth ? t : 0)] : 0.0;
   if (integrate) factor_prefetch(m, L, E.ring);
-  else { for (int u = 0; u < FACTOR_AHEAD; u++) E.ring.q[u] = 0u; }
+  else { for (int u = 0; u < FACTOR_AHEAD; u++) E.ring.q[u] = 0u; E.ring.adr0 = 0; E.ring.num = 0; }
   const int j = L < m.njnt ? L : 0;
   E.qa = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
   E.da = m.njnt > 0 ? m.jnt_dofadr[j] : 0;

@@ -24,7 +24,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 CACHE = os.path.join(CSRC, "_spec")
 SOURCES = ["mjrl_spec_kernel.hip", "mjrl_step.h", "mjrl_collide.h", "mjrl_math.h", "mjrl_wave.h", "mjrl_model.h",
            "mjrl_layout.h"]
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-value"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-Wno-unused-value"]
 if os.environ.get("MJRL_SPEC_FLAGS"):          # experiments only: extra compiler flags for the specialised kernel
     FLAGS = FLAGS + os.environ["MJRL_SPEC_FLAGS"].split()
 
