@@ -630,14 +630,16 @@ __device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, i
       int ki = kkadr + 1 + a;
       real tmp = 0, val = 0;
       // the pivot D_kk is final when its step starts (only deeper dofs update it), so its reciprocal is taken from the
-      // same read as the row scaling: the two divisions overlap and the step needs no second LDS round trip.  (The
-      // schedule word carries the pivot's address in every lane of the tree, also in lanes without a pair.)
+      // same read as the row scaling and the step needs no second LDS round trip.  The elimination multiplier is formed
+      // with that reciprocal -- one division per step (a dozen instructions, four of them at quarter rate) instead of
+      // MuJoCo's two; the oracle does the same.  (The schedule word carries the pivot's address in every lane of the
+      // tree, also in lanes without a pair.)
       real dkk = S[ld + kkadr];
+      real rkk = 1.0 / dkk;
       if (valid) {
-        tmp = S[ld + ki] / dkk;
+        tmp = S[ld + ki] * rkk;
         val = S[ld + ijt] - tmp * S[ld + ki + t];
       }
-      real rkk = 1.0 / dkk;
       wv::sync();
       if (valid) {
         S[ld + ijt] = val;
@@ -2120,19 +2122,18 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
       rg_pos = ld3(S + l.xpos + 3 * rg_body0) + rot(bq, rg_gpos);
       rg_mat = qmat(qmul(bq, rg_gquat));
     }
+    // the site's world frame, for every sensor at once in the sensor's lane (it is the same for all lanes of the wave:
+    // computed inside the loop below it cost every sensor a hundred instructions of the whole wave)
+    const Quat k_bq = ldq(S + l.xquat + 4 * k_body);
+    const V3 k_sp = ld3(S + l.xpos + 3 * k_body) + rot(k_bq, k_pos);
+    const M3 k_sm = qmat(qmul(k_bq, k_quat));
     const int ns = m.nsensor - s0 < 64 ? m.nsensor - s0 : 64;
     for (int j = 0; j < ns; j++) {
       const int adr = wv::lane_int(k_adr, j), body = wv::lane_int(k_body, j), type = wv::lane_int(k_type, j);
       const real cutoff = wv::lane_value(k_cut, j);
-      const V3 site_pos = v3(wv::lane_value(k_pos.x, j), wv::lane_value(k_pos.y, j), wv::lane_value(k_pos.z, j));
-      Quat site_quat;
-      site_quat.w = wv::lane_value(k_quat.w, j); site_quat.x = wv::lane_value(k_quat.x, j);
-      site_quat.y = wv::lane_value(k_quat.y, j); site_quat.z = wv::lane_value(k_quat.z, j);
-      Quat bq = ldq(S + l.xquat + 4 * body);
-      V3 sp = ld3(S + l.xpos + 3 * body) + rot(bq, site_pos);
-      M3 sm = qmat(qmul(bq, site_quat));
+      const V3 sp = v3(wv::lane_value(k_sp.x, j), wv::lane_value(k_sp.y, j), wv::lane_value(k_sp.z, j));
       if (type == SENS_RANGEFINDER) {
-        V3 vec = col(sm, 2);
+        const V3 vec = v3(wv::lane_value(k_sm.m[2], j), wv::lane_value(k_sm.m[5], j), wv::lane_value(k_sm.m[8], j));   // col(sm, 2)
         real best = 1e300;
         if (rg_type >= 0 && rg_body != body) {
           // a geom whose bounding sphere the ray misses (or that lies wholly behind the ray's origin) cannot be hit: it
@@ -2172,6 +2173,9 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
         if (cutoff > 0 && out > cutoff) out = cutoff;
         if (L == 0) S[l.sens + adr] = out;
       } else if (type == SENS_ACCELEROMETER) {
+        M3 sm;
+#pragma unroll
+        for (int e = 0; e < 9; e++) sm.m[e] = wv::lane_value(k_sm.m[e], j);
         if (L == 0) {
           int t = T.body_tree(body);
           V3 off = sp - ld3(S + l.com + 3 * (t < 0 ? m.ntree : t));
@@ -2189,7 +2193,8 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
       } else {
         int c = type - SENS_FRAMEXAXIS;
         // (a select, not col(sm, c): a run-time column index would put the matrix in scratch memory)
-        V3 axis = c == 0 ? col(sm, 0) : (c == 1 ? col(sm, 1) : col(sm, 2));
+        const V3 own = c == 0 ? col(k_sm, 0) : (c == 1 ? col(k_sm, 1) : col(k_sm, 2));     // (the sensor's lane holds its axis)
+        const V3 axis = v3(wv::lane_value(own.x, j), wv::lane_value(own.y, j), wv::lane_value(own.z, j));
         if (L == 0) st3(S + l.sens + adr, axis);
       }
     }
@@ -2601,8 +2606,7 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   if (a.lpt_count_out && L == 0) {                                                                           \
     const int* Iw = (const int*)(S + l.ints);                                                                \
     unsigned work = (unsigned)(Iw[I_NEFC] * Iw[I_NITER]);                                                    \
-    int wb = 0;                                                                                              \
-    while (work) { wb++; work >>= 1; }                                                                       \
+    int wb = work ? 32 - __builtin_clz(work) : 0;           /* bit length */                                 \
     if (wb > LPT_BUCKETS - 1) wb = LPT_BUCKETS - 1;                                                          \
     wv::atomic_add_noret(a.lpt_count_out + wb, 1);                                                           \
     wv::atomic_or_noret(a.lpt_mask_out + (size_t)wb * a.lpt_words + (env >> 5), 1u << (env & 31));          \

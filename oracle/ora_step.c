@@ -316,17 +316,20 @@ static void ora_crb(const ora_model* m, ora_data* d) {
   }
 }
 
-/* sparse L^T D L factorisation of a matrix in the dof_Madr layout; in place */
+/* sparse L^T D L factorisation of a matrix in the dof_Madr layout; in place.  (mj_factorI divides every entry of the
+ * pivot row by the pivot; here the entries are multiplied by the pivot's reciprocal, the value that ends up in
+ * qLDiagInv anyway -- the same algorithm with one division per pivot, and the form the device code uses.) */
 static void factor_sparse(const ora_model* m, double* ld, double* diaginv) {
   for (int k = m->nv - 1; k >= 0; k--) {
     int kk = m->dof_Madr[k], ki = kk + 1;
+    const double rk = 1.0 / ld[kk];
     for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i], ki++) {
-      double a = ld[ki] / ld[kk];
+      double a = ld[ki] * rk;
       int ij = m->dof_Madr[i], n = m->dof_depth[i] + 1;
       for (int t = 0; t < n; t++) ld[ij + t] -= a * ld[ki + t];
       ld[ki] = a;
     }
-    diaginv[k] = 1.0 / ld[kk];
+    diaginv[k] = rk;
   }
 }
 
