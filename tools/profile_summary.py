@@ -21,9 +21,17 @@ envs = bench_line["config"]["envs_per_gpu"]
 algo = bench_line["roofline"]["algorithmic_bytes_per_env_step"]
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same directories: earlier runs stay behind, the last one counts"""
+    paths = sorted(glob.glob(pattern), key=os.path.getmtime)
+    if not paths:
+        raise SystemExit(f"nothing matches {pattern}")
+    return paths[-1]
+
+
 def counter(run, name, kernel, last=None):
     vals = []
-    for path in glob.glob(os.path.join(src, run, "*", "*counter_collection.csv")):
+    for path in [newest(os.path.join(src, run, "*", "*counter_collection.csv"))]:
         rows = [r for r in csv.DictReader(open(path)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         vals += [float(r["Counter_Value"]) for r in rows]
@@ -34,10 +42,10 @@ def counter(run, name, kernel, last=None):
     return sum(vals) / len(vals), len(vals)
 
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+stats = [newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))]
 shutil.copy(stats[0], os.path.join(dst, f"r02_kernel_stats_{level}.csv"))
 row = [r for r in csv.DictReader(open(stats[0])) if STEP in r["Name"]][0]
-trace = glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))[0]
+trace = newest(os.path.join(src, "stats", "*", "*kernel_trace.csv"))
 launches = [r for r in csv.DictReader(open(trace)) if STEP in r["Kernel_Name"]]
 launches.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in launches]
