@@ -18,12 +18,12 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 13
+VERSION = 14
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
                "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "has_accel", "nitemmax", "rowmap", "nfactor", "npass",
-               "ntab", "maxkdepth"]
+               "ntab", "maxkdepth", "nchunk", "ntp"]
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
@@ -43,7 +43,7 @@ F64_FIELDS = [
     ("cam_pos", "ncam*3"), ("cam_quat", "ncam*4"), ("cam_fovy", "ncam"),
     ("act_gear", "nu"), ("act_ctrlrange", "nu*2"),
     ("sensor_cutoff", "nsensor"),
-    ("pair_margin", "npair"), ("pair_bound", "npair"), ("pair_gap", "npair"), ("pair_mu", "npair"),
+    ("pair_margin", "npair"), ("pair_bound", "npair"), ("pair_gap", "npair"), ("pair_mu", "npair"), ("tp_reach", "ntp"),
 ]
 I32_FIELDS = [
     ("body_parentid", "nbody"), ("body_rootid", "nbody"), ("body_weldid", "nbody"), ("body_jntnum", "nbody"),
@@ -64,7 +64,7 @@ I32_FIELDS = [
     ("desc_row", "ndesc"), ("M_coldiag", "nM"), ("dof_actid", "nv"),
     ("factor_sched", "nfactor"), ("row_dof", "64"), ("solve_b", "1024"), ("solve_f", "1024"), ("dof_lane", "nv"),
     ("lds_tab", "ntab"), ("pair_word", "npair"), ("pair_reach", "npair"), ("dof_descmask", "nv*2"),
-    ("body_kparent", "nbody"), ("body_kdepth", "nbody"),
+    ("body_kparent", "nbody"), ("body_kdepth", "nbody"), ("chunk_info", "nchunk"), ("tp_root", "ntp*2"),
 ]
 
 
@@ -77,6 +77,8 @@ def _sizes(model) -> dict:
     # kernel otherwise)
     kmax = 1
     for g1, g2 in model.pair_geom:
+        if g1 < 0:                    # a padding entry of the pair list
+            continue
         t = (int(model.geom_type[g1]), int(model.geom_type[g2]))
         kmax = max(kmax, {(0, 3): 2, (0, 6): 8, (3, 3): 4, (3, 6): 2, (6, 6): 16}.get(t, 1))
     s["pair_kmax"] = kmax

@@ -56,7 +56,9 @@ __device__ __forceinline__ void mjrl_model_from_base(DevModel* m, const char MJR
   constexpr int nq = DevModel::nq, nv = DevModel::nv, nu = DevModel::nu, nbody = DevModel::nbody, njnt = DevModel::njnt,
                 ngeom = DevModel::ngeom, nsite = DevModel::nsite, ncam = DevModel::ncam, nsensor = DevModel::nsensor,
                 npair = DevModel::npair, nM = DevModel::nM, ndesc = DevModel::ndesc, nchild = DevModel::nchild,
-                ntree = DevModel::ntree, nfactor = DevModel::nfactor, ntab = DevModel::ntab;
+                ntree = DevModel::ntree, nfactor = DevModel::nfactor, ntab = DevModel::ntab, nchunk = DevModel::nchunk,
+                ntp = DevModel::ntp;
+  (void)nchunk; (void)ntp;
   (void)nfactor; (void)ntab; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
   (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
 #define X(name, count) m->name = (const double MJRL_GLOBAL*)(b + off); off += 8 * (size_t)(count);
@@ -89,7 +91,8 @@ static inline int mjrl_model_from_blob(DevModel* m, const void* host_blob, size_
   const char* b = (const char*)base;
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom, nsite = m->nsite,
       ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nM = m->nM, ndesc = m->ndesc, nchild = m->nchild,
-      ntree = m->ntree, nfactor = m->nfactor, ntab = m->ntab;
+      ntree = m->ntree, nfactor = m->nfactor, ntab = m->ntab, nchunk = m->nchunk, ntp = m->ntp;
+  (void)nchunk; (void)ntp;
   (void)nfactor; (void)ntab; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
   (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
 #define X(name, count) m->name = (const double MJRL_GLOBAL*)(b + off); off += 8 * (size_t)(count);

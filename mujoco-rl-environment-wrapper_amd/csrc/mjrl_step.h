@@ -588,64 +588,86 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
 // The schedule words of the first FACTOR_AHEAD elimination steps of a factorisation, fetched ahead of it (before the
 // stage in front) so that the factorisation starts without a round trip to L2 of its own.
 enum { FACTOR_AHEAD = 4 };
-struct FactorRing { unsigned q[FACTOR_AHEAD]; int adr0, num; };      // (adr0, num: first dof and dof count of the lane's tree in pass 0)
-__device__ __forceinline__ void factor_prefetch(const DevModel& m, int L, FactorRing& r) {
-  const int32_t* sched = m.factor_sched + L;
-  {
-    const int groups = m.ntree > 1 ? 2 : 1, tree = L / (64 / groups);
-    r.adr0 = m.tree_dofadr[tree < m.ntree ? tree : 0];
-    r.num = tree < m.ntree ? m.tree_dofnum[tree] : 0;
-  }
+// (q / adr0 / num: the lane's tree in pass 0; q1 / adr1 / num1: in pass 1, when the model has more than two trees)
+struct FactorRing { unsigned q[FACTOR_AHEAD], q1[FACTOR_AHEAD]; int adr0, num, adr1, num1; };
+__device__ __forceinline__ void factor_ring_load(const DevModel& m, int L, int ps, unsigned* q, int& adr0, int& num) {
+  const int groups = m.ntree > 1 ? 2 : 1, tree = ps * groups + L / (64 / groups);
+  adr0 = m.tree_dofadr[tree < m.ntree ? tree : 0];
+  num = tree < m.ntree ? m.tree_dofnum[tree] : 0;
+  const int32_t* sched = m.factor_sched + (size_t)ps * m.maxtreedof * 64 + L;
 #pragma unroll
   for (int u = 0; u < FACTOR_AHEAD; u++) {
     const int kk = m.maxtreedof - 1 - u;
-    r.q[u] = kk >= 0 ? (unsigned)sched[kk * 64] : 0u;
+    q[u] = kk >= 0 ? (unsigned)sched[kk * 64] : 0u;
+  }
+}
+__device__ __forceinline__ void factor_prefetch(const DevModel& m, int L, FactorRing& r) {
+  factor_ring_load(m, L, 0, r.q, r.adr0, r.num);
+  if (m.npass > 1) factor_ring_load(m, L, 1, r.q1, r.adr1, r.num1);
+  else {
+#pragma unroll
+    for (int u = 0; u < FACTOR_AHEAD; u++) r.q1[u] = 0u;
+    r.adr1 = 0; r.num1 = 0;
   }
 }
 
+// One elimination step of one pass, in two halves around the step's fence: what it reads and computes, what it writes.
+struct FactorStep { bool valid, live; int ijt, ki, t, slot; real val, tmp, rkk; };
+__device__ __forceinline__ void factor_step_read(const real* S, int ld, int dinv, unsigned w, int kk, int adr0, int num,
+                                                 FactorStep& f) {
+  f.live = kk < num; f.valid = (w >> 26) & 1u;
+  const int kkadr = w & 1023, a = (w >> 20) & 7;
+  f.ijt = (w >> 10) & 1023; f.t = (w >> 23) & 7;
+  f.ki = kkadr + 1 + a;
+  f.slot = dinv + adr0 + kk;
+  // the pivot D_kk is final when its step starts (only deeper dofs update it), so its reciprocal is taken from the
+  // same read as the row scaling and the step needs no second LDS round trip.  The elimination multiplier is formed
+  // with that reciprocal -- one division per step (a dozen instructions, four of them at quarter rate) instead of
+  // MuJoCo's two; the oracle does the same.  (The schedule word carries the pivot's address in every lane of the
+  // tree, also in lanes without a pair.)
+  // (no branch on `valid` here: a lane without a pair computes on the entries its zeroed fields address and writes
+  // nothing -- straight-line code lets the two passes' reads and divisions be scheduled into each other)
+  const real dkk = S[ld + kkadr], ski = S[ld + f.ki], sij = S[ld + f.ijt], skt = S[ld + f.ki + f.t];
+  f.rkk = 1.0 / dkk;
+  f.tmp = ski * f.rkk;
+  f.val = sij - f.tmp * skt;
+}
+__device__ __forceinline__ void factor_step_write(real* S, int ld, bool first_lane, const FactorStep& f) {
+  if (f.valid) {
+    S[ld + f.ijt] = f.val;
+    if (f.t == 0) S[ld + f.ki] = f.tmp;
+  }
+  if (f.live && first_lane) S[f.slot] = f.rkk;
+}
+
+// Passes (two trees each) touch disjoint trees, so they are eliminated two passes at a time: step kk of both between the
+// same two fences -- the second pass's LDS round trips and its division run under the first's (a model with four trees
+// otherwise waits out 28 steps one after the other with a single wave on its SIMD).
 __device__ inline void factor_ld(const DevModel& m, real* S, int ld, int dinv, int L, FactorRing ring) {
   const int groups = m.ntree > 1 ? 2 : 1, width = 64 / groups;
-  const int g = L / width, p = L % width;
-  for (int ps = 0; ps < m.npass; ps++) {
-    int tree = ps * groups + g;
-    bool has_tree = tree < m.ntree;
-    int adr0 = ps == 0 ? ring.adr0 : (has_tree ? m.tree_dofadr[tree] : 0), num = ps == 0 ? ring.num : (has_tree ? m.tree_dofnum[tree] : 0);
+  const bool first_lane = L % width == 0;
+  for (int ps = 0; ps < m.npass; ps += 2) {
+    const bool two = ps + 1 < m.npass;
+    if (ps > 0) {
+      factor_ring_load(m, L, ps, ring.q, ring.adr0, ring.num);
+      if (two) factor_ring_load(m, L, ps + 1, ring.q1, ring.adr1, ring.num1);
+    }
     // the lane's (ancestor, offset) pair of every elimination step comes from the host-built schedule, fetched
     // FACTOR_AHEAD steps before its use (a step is two short LDS phases, far less than a round trip to L2)
-    const int32_t* sched = m.factor_sched + (size_t)ps * m.maxtreedof * 64 + L;
-    if (ps > 0) {
-#pragma unroll
-      for (int u = 0; u < FACTOR_AHEAD; u++) {
-        const int kk = m.maxtreedof - 1 - u;
-        ring.q[u] = kk >= 0 ? (unsigned)sched[kk * 64] : 0u;
-      }
-    }
+    const int32_t* sched0 = m.factor_sched + (size_t)ps * m.maxtreedof * 64 + L;
+    const int32_t* sched1 = sched0 + (size_t)m.maxtreedof * 64;
     for (int kk = m.maxtreedof - 1; kk >= 0; kk--) {
-      unsigned w = ring.q[0];
+      const unsigned w0 = ring.q[0], w1 = ring.q1[0];
 #pragma unroll
-      for (int u = 0; u + 1 < FACTOR_AHEAD; u++) ring.q[u] = ring.q[u + 1];
-      ring.q[FACTOR_AHEAD - 1] = kk >= FACTOR_AHEAD ? (unsigned)sched[(kk - FACTOR_AHEAD) * 64] : 0u;
-      bool live = kk < num, valid = (w >> 26) & 1u;
-      int kkadr = w & 1023, ijt = (w >> 10) & 1023, a = (w >> 20) & 7, t = (w >> 23) & 7;
-      int ki = kkadr + 1 + a;
-      real tmp = 0, val = 0;
-      // the pivot D_kk is final when its step starts (only deeper dofs update it), so its reciprocal is taken from the
-      // same read as the row scaling and the step needs no second LDS round trip.  The elimination multiplier is formed
-      // with that reciprocal -- one division per step (a dozen instructions, four of them at quarter rate) instead of
-      // MuJoCo's two; the oracle does the same.  (The schedule word carries the pivot's address in every lane of the
-      // tree, also in lanes without a pair.)
-      real dkk = S[ld + kkadr];
-      real rkk = 1.0 / dkk;
-      if (valid) {
-        tmp = S[ld + ki] * rkk;
-        val = S[ld + ijt] - tmp * S[ld + ki + t];
-      }
+      for (int u = 0; u + 1 < FACTOR_AHEAD; u++) { ring.q[u] = ring.q[u + 1]; ring.q1[u] = ring.q1[u + 1]; }
+      ring.q[FACTOR_AHEAD - 1] = kk >= FACTOR_AHEAD ? (unsigned)sched0[(kk - FACTOR_AHEAD) * 64] : 0u;
+      ring.q1[FACTOR_AHEAD - 1] = (two && kk >= FACTOR_AHEAD) ? (unsigned)sched1[(kk - FACTOR_AHEAD) * 64] : 0u;
+      FactorStep f0, f1;
+      factor_step_read(S, ld, dinv, w0, kk, ring.adr0, ring.num, f0);
+      if (two) factor_step_read(S, ld, dinv, w1, kk, ring.adr1, ring.num1, f1);
       wv::sync();
-      if (valid) {
-        S[ld + ijt] = val;
-        if (t == 0) S[ld + ki] = tmp;
-      }
-      if (live && p == 0) S[dinv + adr0 + kk] = rkk;
+      factor_step_write(S, ld, first_lane, f0);
+      if (two) factor_step_write(S, ld, first_lane, f1);
       wv::sync();
     }
   }
@@ -729,6 +751,8 @@ struct GeomK {
   int body; V3 pos; Quat quat;
   real size[3];                           // geom_size[L], [L + 64], [L + 128] (a longer table takes a loop)
   int word[PAIR_AHEAD], reach[PAIR_AHEAD];
+  int chunk_info;                         // lane c: kind and tree pair of chunk c of the pair list
+  int tp_a, tp_b; real tp_reach;          // lane k: root bodies and reach of tree pair k
 };
 __device__ __forceinline__ void load_geom_constants(const DevModel& m, int L, GeomK& g) {
   const int i = L < m.ngeom ? L : 0;
@@ -743,6 +767,11 @@ __device__ __forceinline__ void load_geom_constants(const DevModel& m, int L, Ge
     g.word[u] = 64 * u < m.npair ? m.pair_word[q] : 0;
     g.reach[u] = 64 * u < m.npair ? m.pair_reach[q] : 0;
   }
+  g.chunk_info = m.nchunk > 0 ? m.chunk_info[L < m.nchunk ? L : 0] : 0;
+  const int k = L < m.ntp ? L : 0;
+  g.tp_a = m.ntp > 0 ? m.tp_root[2 * k] : 0;
+  g.tp_b = m.ntp > 0 ? m.tp_root[2 * k + 1] : 0;
+  g.tp_reach = m.ntp > 0 ? m.tp_reach[k] : 0.0;
 }
 
 __device__ inline void stage_geoms(const DevModel& m, const Lay& l, const GeomK& G, real* S, int L) {
@@ -767,13 +796,32 @@ __device__ inline void stage_geoms(const DevModel& m, const Lay& l, const GeomK&
 __device__ inline void stage_collision(const DevModel& m, const Lay& l, const GeomK& G, real* S, int L) {
   int* I = (int*)(S + l.ints);
   int nitem = 0, warn = 0;
-  // broad phase: bounding spheres (planes: signed distance of the other geom's bounding sphere).  Every surviving
-  // pair expands into its narrow-phase work items, in pair order.
+  // Broad phase.  The candidate pairs come in chunks of ONE kind of test each (mjcf._pair_layout: plane pairs, (sphere |
+  // capsule)-box pairs, box-box pairs, bounding-sphere pairs; padded with empty entries), so a chunk runs one test and a
+  // scalar branch picks it -- a chunk of mixed kinds ran every kind's code under lane masks.  The bounding-sphere pairs
+  // between two kinematic trees form a block per pair of trees, and a block is skipped when the trees themselves are out
+  // of each other's reach (root body positions against a reach no joint configuration exceeds): its pairs would all fail.
+  // Every surviving pair expands into its narrow-phase work items, in list order.
   // one packed word + one float per candidate pair; those of the next PAIR_AHEAD chunks are in flight while this chunk
   // is tested (a chunk without a survivor is a few dozen instructions, much less than a round trip to L2)
+  const int info_reg = G.chunk_info;                // lane c: kind and tree pair of chunk c (first 64 chunks)
+  unsigned long long tp_live = ~0ull;
+  if (m.ntp > 0) {
+    const V3 d = ld3(S + l.xpos + 3 * G.tp_a) - ld3(S + l.xpos + 3 * G.tp_b);
+    tp_live = ~wv::ballot(L < m.ntp && dot(d, d) > G.tp_reach * G.tp_reach);
+  }
   int wring[PAIR_AHEAD], rring[PAIR_AHEAD];
 #pragma unroll
   for (int u = 0; u < PAIR_AHEAD; u++) { wring[u] = G.word[u]; rring[u] = G.reach[u]; }
+  // the two geom centres of the lane's pair are read from LDS one chunk ahead as well (a wave alone on its SIMD -- the
+  // 4-agent arena -- otherwise waits out an LDS round trip at the head of every chunk)
+  V3 c1 = ld3(S + l.gpos + 3 * (wring[0] & 255)), c2 = ld3(S + l.gpos + 3 * ((wring[0] >> 8) & 255));
+  // (the specialised kernel unrolls this loop completely: the prefetch ring then lives in fixed registers.  As a loop
+  // the ring is shifted by register moves, a move has to wait for the load that fills its source, and every chunk began
+  // with a wait for the loads issued one chunk earlier -- most of a chunk's time.)
+#ifdef MJRL_SPEC
+#pragma unroll
+#endif
   for (int base = 0; base < m.npair; base += 64) {
     int p = base + L, items = 0;
     int word = wring[0];
@@ -786,44 +834,51 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, const Ge
       wring[PAIR_AHEAD - 1] = more ? m.pair_word[q] : 0;
       rring[PAIR_AHEAD - 1] = more ? m.pair_reach[q] : 0;
     }
-    if (p < m.npair) {
-      int g1 = word & 255, g2 = (word >> 8) & 255, t1 = (word >> 16) & 15, t2 = (word >> 20) & 15;
-      V3 dif = ld3(S + l.gpos + 3 * g2) - ld3(S + l.gpos + 3 * g1);
-      bool pass;
-      // (bit 24 of the word: the frame this test needs is the identity rotation for good -- the arena's floor and walls --,
-      // so its matrix is neither built nor applied; with an exact identity the general form gives the same bits)
-      const bool fixed = (word >> 24) & 1;
-      if (t1 == GEOM_PLANE) {
-        pass = !((fixed ? dif.z : dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2))) > bound);
-      } else if (t2 == GEOM_BOX && t1 != GEOM_BOX) {
-        // geom1's bounding sphere against the box itself: a long wall's bounding sphere would cover the whole arena
+    const V3 p1 = c1, p2 = c2;
+    c1 = ld3(S + l.gpos + 3 * (wring[0] & 255)); c2 = ld3(S + l.gpos + 3 * ((wring[0] >> 8) & 255));   // (past the list / padding: geom 0, unused)
+    const int chunk = base >> 6;
+    const int info = chunk < 64 ? wv::lane_int(info_reg, chunk) : wv::first_int(m.chunk_info[chunk]);
+    const int kind = info & 255, tp = info >> 8;
+    if (tp > 0 && tp <= 64 && !((tp_live >> (tp - 1)) & 1ull)) continue;      // the two trees are out of reach of each other
+    const bool real_pair = word >= 0;                 // (bit 31: a padding entry)
+    const int g1 = word & 255, g2 = (word >> 8) & 255;
+    const V3 dif = p2 - p1;
+    bool pass = false;
+    // (bit 24 of the word: the frame this test needs is the identity rotation for good -- the arena's floor and walls --,
+    // so its matrix is neither built nor applied; with an exact identity the general form gives the same bits)
+    const bool fixed = (word >> 24) & 1;
+    if (kind == 3) {                                  // bounding spheres (bound = rb1 + rb2 + margin)
+      pass = real_pair && !(dot(dif, dif) > bound * bound);
+    } else if (kind == 0) {                           // a plane: signed distance of the other geom's bounding sphere
+      if (real_pair) pass = !((fixed ? dif.z : dot(dif, col(qmat(ldq(S + l.gquat + 4 * g1)), 2))) > bound);
+    } else if (kind == 1) {
+      // geom1's bounding sphere against the box itself: a long wall's bounding sphere would cover the whole arena
+      if (real_pair) {
         V3 loc = fixed ? dif * -1.0 : mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
         real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
         pass = !(ex * ex + ey * ey + ez * ez > bound * bound);
-      } else if (m.pair_kmax >= 16 && t1 == GEOM_BOX && t2 == GEOM_BOX) {
-        // the same both ways: each box's bounding sphere (+ margin) against the other box (bound = rb1 + rb2 + margin)
-        pass = !(dot(dif, dif) > bound * bound);
-        if (pass) {
-          const real rb1 = m.geom_rbound[g1], rb2 = m.geom_rbound[g2];
-          V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
-          real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
-          const real r1 = bound - rb2;
-          pass = !(ex * ex + ey * ey + ez * ez > r1 * r1);
-          loc = mulT(qmat(ldq(S + l.gquat + 4 * g1)), dif); bs = ld3(S + l.gsize + 3 * g1);
-          ex = fmax(fabs(loc.x) - bs.x, 0.0); ey = fmax(fabs(loc.y) - bs.y, 0.0); ez = fmax(fabs(loc.z) - bs.z, 0.0);
-          const real r2 = bound - rb1;
-          pass = pass && !(ex * ex + ey * ey + ez * ez > r2 * r2);
-        }
-      } else {
-        pass = !(dot(dif, dif) > bound * bound);
       }
+    } else if (m.pair_kmax >= 16) {                   // (compiled out of a specialised kernel whose level has no box-box pair)
+      // box-box, the same both ways: each box's bounding sphere (+ margin) against the other box (bound = rb1 + rb2 + margin)
+      pass = real_pair && !(dot(dif, dif) > bound * bound);
       if (pass) {
-        items = pair_items(t1, t2);
-        if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) {
-          // only (numerically) parallel capsules need the four end-point candidates
-          real c = dot(col(qmat(ldq(S + l.gquat + 4 * g1)), 2), col(qmat(ldq(S + l.gquat + 4 * g2)), 2));
-          if (fabs(1.0 - c * c) >= 1e-12) items = 1;
-        }
+        const real rb1 = m.geom_rbound[g1], rb2 = m.geom_rbound[g2];
+        V3 loc = mulT(qmat(ldq(S + l.gquat + 4 * g2)), dif * -1.0), bs = ld3(S + l.gsize + 3 * g2);
+        real ex = fmax(fabs(loc.x) - bs.x, 0.0), ey = fmax(fabs(loc.y) - bs.y, 0.0), ez = fmax(fabs(loc.z) - bs.z, 0.0);
+        const real r1 = bound - rb2;
+        pass = !(ex * ex + ey * ey + ez * ez > r1 * r1);
+        loc = mulT(qmat(ldq(S + l.gquat + 4 * g1)), dif); bs = ld3(S + l.gsize + 3 * g1);
+        ex = fmax(fabs(loc.x) - bs.x, 0.0); ey = fmax(fabs(loc.y) - bs.y, 0.0); ez = fmax(fabs(loc.z) - bs.z, 0.0);
+        const real r2 = bound - rb1;
+        pass = pass && !(ex * ex + ey * ey + ez * ez > r2 * r2);
+      }
+    }
+    if (pass) {
+      items = 1 << ((word >> 25) & 7);                 // work items of the pair's types (pair_items), from the word
+      if ((word >> 28) & 1) {
+        // only (numerically) parallel capsules need the four end-point candidates
+        real c = dot(col(qmat(ldq(S + l.gquat + 4 * g1)), 2), col(qmat(ldq(S + l.gquat + 4 * g2)), 2));
+        if (fabs(1.0 - c * c) >= 1e-12) items = 1;
       }
     }
     // exclusive prefix of the item counts (1, 2, 4, 8 or 16 per lane) from ballots; most chunks have no survivor
@@ -2218,7 +2273,7 @@ __device__ __forceinline__ void load_euler_constants(const DevModel& m, const St
   for (int t = 0; t < MAX_DOF_DEPTH; t++)     // (entries past the lane's row repeat its diagonal and are not used)
     E.mg[t] = integrate ? Mg[K.d_Madr + (t <= K.d_depth ? t : 0)] : 0.0;
   if (integrate) factor_prefetch(m, L, E.ring);
-  else { for (int u = 0; u < FACTOR_AHEAD; u++) E.ring.q[u] = 0u; E.ring.adr0 = 0; E.ring.num = 0; }
+  else { for (int u = 0; u < FACTOR_AHEAD; u++) { E.ring.q[u] = 0u; E.ring.q1[u] = 0u; } E.ring.adr0 = E.ring.num = E.ring.adr1 = E.ring.num1 = 0; }
   const int j = L < m.njnt ? L : 0;
   E.qa = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
   E.da = m.njnt > 0 ? m.jnt_dofadr[j] : 0;

@@ -127,6 +127,8 @@ class Model:
     nfactor: int = 0
     npass: int = 0
     ntab: int = 0
+    nchunk: int = 0         # chunks of 64 entries of the candidate-pair list
+    ntp: int = 0            # pairs of kinematic trees whose bounding-sphere pairs form a block of their own
     # options
     timestep: float = 0.002
     gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
@@ -360,13 +362,15 @@ SUPPORTED_PAIRS = {
 }
 
 
-def compile_mjcf(xml_path: str, nconmax: int | None = None, njmax: int | None = None, lane_map: bool = True) -> Model:
+def compile_mjcf(xml_path: str, nconmax: int | None = None, njmax: int | None = None, lane_map: bool = True,
+                 broad_cull: bool = True) -> Model:
     with open(xml_path, "r") as fh:
         text = fh.read()
-    return compile_mjcf_string(text, xml_path=xml_path, nconmax=nconmax, njmax=njmax, lane_map=lane_map)
+    return compile_mjcf_string(text, xml_path=xml_path, nconmax=nconmax, njmax=njmax, lane_map=lane_map, broad_cull=broad_cull)
 
 
-def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None, lane_map: bool = True) -> Model:
+def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None, lane_map: bool = True,
+                        broad_cull: bool = True) -> Model:
     """``lane_map=False`` withholds the tree-row lane map even from a model that qualifies for it (a model with more
     than four trees or more than 16 dofs in a tree never gets it): the kernels then take their general paths."""
     c = _Compiler(text)
@@ -680,16 +684,24 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
             if (int(gt[a]), int(gt[b])) not in SUPPORTED_PAIRS:
                 raise ValueError(f"collision pair types {gt[a]},{gt[b]} are outside the supported subset")
             pairs.append((a, b))
-    m.npair = len(pairs)
-    A["pair_geom"] = np.array(pairs, np.int32).reshape(m.npair, 2)
-    # broad-phase constants per pair: contact margin and the bounding-sphere reach (plane pairs: the other geom's)
     rb, mg = A["geom_rbound"], A["geom_margin"]
-    A["pair_margin"] = np.array([max(mg[a], mg[b]) for a, b in pairs], np.float64)
+    pairs, chunk_info, tp_root, tp_reach = _pair_layout(m, A, pairs, broad_cull)
+    m.npair, m.nchunk, m.ntp = len(pairs), len(chunk_info), len(tp_reach)
+    A["chunk_info"] = np.array(chunk_info, np.int32)
+    A["tp_root"] = np.array(tp_root, np.int32).reshape(-1)
+    A["tp_reach"] = np.array(tp_reach, np.float64)
+    real = [pr for pr in pairs if pr is not None]
+    A["pair_geom"] = np.array([pr if pr is not None else (-1, -1) for pr in pairs], np.int32).reshape(m.npair, 2)
+    # per-pair constants (0 in the padding entries); `val(f)` evaluates f(a, b) on the real pairs
+    def val(f):
+        return np.array([f(*pr) if pr is not None else 0.0 for pr in pairs], np.float64)
+    # broad-phase constants per pair: contact margin and the bounding-sphere reach (plane pairs: the other geom's)
+    A["pair_margin"] = val(lambda a, b: max(mg[a], mg[b]))
     # what a contact of the pair takes from its two geoms, so that the narrow phase reads one record per pair instead of
     # following the geom ids: gap and sliding friction, both the larger of the two (MuJoCo's mixing rule for geom pairs)
     gp, fr = A["geom_gap"], np.asarray(A["geom_friction"], np.float64).reshape(-1, 3)
-    A["pair_gap"] = np.array([max(gp[a], gp[b]) for a, b in pairs], np.float64)
-    A["pair_mu"] = np.array([max(fr[a, 0], fr[b, 0]) for a, b in pairs], np.float64)
+    A["pair_gap"] = val(lambda a, b: max(gp[a], gp[b]))
+    A["pair_mu"] = val(lambda a, b: max(fr[a, 0], fr[b, 0]))
     # reach of the broad-phase test: plane pairs and (sphere|capsule)-box pairs test ONE bounding sphere against the
     # plane / the box itself, every other pair tests the two bounding spheres against each other
     def reach(a, b):
@@ -698,7 +710,7 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
         if gt[b] == GEOM_BOX and gt[a] != GEOM_BOX:
             return rb[a]
         return rb[a] + rb[b]
-    A["pair_bound"] = np.array([reach(a, b) + max(mg[a], mg[b]) for a, b in pairs], np.float64)
+    A["pair_bound"] = val(lambda a, b: reach(a, b) + max(mg[a], mg[b]))
 
     # caps per env copy (MuJoCo's <size nconmax njmax>): by default room for 6 contacts per kinematic tree and
     # one limit row per limited joint plus a 4-row pyramid per contact.  The caps size the constraint block of the
@@ -711,6 +723,90 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     _set_const(m)
     _kernel_schedules(m, lane_map)
     return m
+
+
+PAIR_PLANE, PAIR_BOX, PAIR_BOXBOX, PAIR_SPHERES = range(4)      # the broad-phase test of a chunk of candidate pairs
+
+
+def _pair_layout(m: Model, A: dict, pairs: list, broad_cull: bool):
+    """Order of the candidate pairs (= the order of the contacts, shared with the oracle through the blob).
+
+    The broad phase tests 64 pairs at a time, and what a chunk costs is set by the KINDS of test in it (every kind
+    present runs for the whole wave) and by whether it has to run at all.  So the list is laid out in segments of one
+    kind each, padded to whole chunks with empty entries (``None``): plane pairs, (sphere | capsule)-box pairs,
+    box-box pairs, bounding-sphere pairs inside one tree or against static geoms, then one block of bounding-sphere
+    pairs per pair of kinematic trees.  A block is skipped when the two trees' bounding spheres (root body position,
+    a reach that no joint configuration can exceed) are further apart than any contact margin of the block reaches:
+    the pairs of a skipped block would all fail their own tests, so nothing changes but the work.  Inside a segment the
+    pairs keep their (geom1, geom2) order.
+
+    Returns (pairs with padding, chunk_info per chunk = kind | (tree pair + 1) << 8, tp_root, tp_reach)."""
+    gt, gb = A["geom_type"], A["geom_bodyid"]
+    tree_of = [int(A["body_treeid"][gb[g]]) for g in range(len(gt))]
+    ntree = int(m.ntree)
+    # a bound on the distance from a tree's root body origin to any point of its geoms: offsets along the body chain
+    # keep their length under rotation, a slide joint adds at most the larger end of its range
+    reach_of = np.full(max(ntree, 1), np.inf)
+    if broad_cull and 2 <= ntree <= 11:
+        roots = [int(r) for r in A["tree_rootbody"]]
+        slide = np.zeros(m.nbody)
+        ok = True
+        for j in range(m.njnt):
+            if A["jnt_type"][j] == JNT_SLIDE:
+                if not A["jnt_limited"][j]:
+                    ok = False
+                slide[int(A["jnt_bodyid"][j])] += float(np.max(np.abs(A["jnt_range"][j]))) + float(np.linalg.norm(A["jnt_pos"][j]))
+            elif A["jnt_type"][j] in (JNT_HINGE, JNT_BALL):
+                # rotation about an anchor off the body origin moves the origin on a sphere of that radius
+                slide[int(A["jnt_bodyid"][j])] += 2.0 * float(np.linalg.norm(A["jnt_pos"][j]))
+        if ok:
+            reach_of[:] = 0.0
+            for g in range(len(gt)):
+                t = tree_of[g]
+                if t < 0:
+                    continue
+                d = float(np.linalg.norm(A["geom_pos"][g])) + float(A["geom_rbound"][g])
+                b = int(gb[g])
+                while b != roots[t]:
+                    d += float(np.linalg.norm(A["body_pos"][b])) + slide[b]
+                    b = int(A["body_parentid"][b])
+                reach_of[t] = max(reach_of[t], d)
+    blocks = np.all(np.isfinite(reach_of)) and broad_cull and 2 <= ntree <= 11
+    segs = {("P",): [], ("B",): [], ("BB",): [], ("S",): []}
+    order = [("P",), ("B",), ("BB",), ("S",)]
+    for a, b in pairs:
+        ta, tb = int(gt[a]), int(gt[b])
+        if ta == GEOM_PLANE:
+            key = ("P",)
+        elif tb == GEOM_BOX and ta != GEOM_BOX:
+            key = ("B",)
+        elif ta == GEOM_BOX and tb == GEOM_BOX:
+            key = ("BB",)
+        else:
+            s1, s2 = sorted((tree_of[a], tree_of[b]))
+            key = ("S", s1, s2) if (blocks and s1 >= 0 and s1 != s2) else ("S",)
+            if key not in segs:
+                segs[key] = []
+                order.append(key)
+        segs[key].append((int(a), int(b)))
+    order = order[:4] + sorted(order[4:])
+    kind_of = {"P": PAIR_PLANE, "B": PAIR_BOX, "BB": PAIR_BOXBOX, "S": PAIR_SPHERES}
+    mg = A["geom_margin"]
+    out, chunk_info, tp_root, tp_reach = [], [], [], []
+    for key in order:
+        seg = segs[key]
+        if not seg:
+            continue
+        tp = 0
+        if len(key) == 3:
+            tp_root += [int(A["tree_rootbody"][key[1]]), int(A["tree_rootbody"][key[2]])]
+            margin = max(max(mg[a], mg[b]) for a, b in seg)
+            tp_reach.append(float(np.nextafter(reach_of[key[1]] + reach_of[key[2]] + margin, np.inf)) * (1.0 + 1e-12))
+            tp = len(tp_reach)
+        nch = (len(seg) + 63) // 64
+        out += seg + [None] * (64 * nch - len(seg))
+        chunk_info += [kind_of[key[0]] | (tp << 8)] * nch
+    return out, chunk_info, tp_root, tp_reach
 
 
 def _kernel_schedules(m: Model, lane_map: bool = True):
@@ -821,8 +917,19 @@ def _kernel_schedules(m: Model, lane_map: bool = True):
         if gt[b] == GEOM_BOX and gt[a] != GEOM_BOX:
             return fixed_identity(b)
         return False
-    A["pair_word"] = np.array([int(a) | (int(b) << 8) | (int(gt[a]) << 16) | (int(gt[b]) << 20) | (int(frame_flag(a, b)) << 24)
-                               for a, b in pg], np.int32)
+    # bits 25-27: log2 of the narrow-phase work items of the pair (1, 2, 4, 8 or 16), bit 28: a capsule-capsule pair (its
+    # four items are needed only when the capsules are parallel; otherwise one).  Bit 31: a padding entry, never a pair.
+    items_log2 = {(GEOM_PLANE, GEOM_CAPSULE): 1, (GEOM_PLANE, GEOM_BOX): 3, (GEOM_CAPSULE, GEOM_CAPSULE): 2,
+                  (GEOM_CAPSULE, GEOM_BOX): 1, (GEOM_BOX, GEOM_BOX): 4}
+    def word_of(a, b):
+        if a < 0:
+            return -(1 << 31)
+        ta, tb = int(gt[a]), int(gt[b])
+        w = int(a) | (int(b) << 8) | (ta << 16) | (tb << 20) | (int(frame_flag(a, b)) << 24)
+        w |= items_log2.get((ta, tb), 0) << 25
+        w |= int(ta == GEOM_CAPSULE and tb == GEOM_CAPSULE) << 28
+        return w
+    A["pair_word"] = np.array([word_of(int(a), int(b)) for a, b in pg], np.int64).astype(np.int32)
     A["pair_reach"] = (np.nextafter(A["pair_bound"].astype(np.float32), np.float32(np.inf))).view(np.int32) \
         if len(pg) else np.zeros(0, np.int32)
 

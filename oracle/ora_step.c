@@ -91,8 +91,8 @@ ora_model* ora_model_create(const void* blob, size_t nbytes) {
 #undef X
   p += 8 * ORA_NOPTS;
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom, nsite = m->nsite, nM = m->nM, ndesc = m->ndesc, nchild = m->nchild, ntree = m->ntree,
-      ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nfactor = m->nfactor, ntab = m->ntab;
-  (void)nfactor; (void)ntab;
+      ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nfactor = m->nfactor, ntab = m->ntab, nchunk = m->nchunk, ntp = m->ntp;
+  (void)nfactor; (void)ntab; (void)nchunk; (void)ntp;
   (void)nM; (void)ndesc; (void)nchild; (void)ntree; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor; (void)npair;
 #define X(name, count) m->name = (const double*)p; p += 8 * (size_t)(count);
   ORA_F64_FIELDS(X)
@@ -399,8 +399,11 @@ static int add_contact(const ora_model* m, ora_data* d, const ora_rawcon* rc, in
 static void ora_collision(const ora_model* m, ora_data* d) {
   d->ncon = 0;
   d->warn_con = 0;
+  /* the candidate pairs in the order of the model compiler's list (mjcf._pair_layout: segments by kind of broad-phase
+   * test, one block per pair of kinematic trees, padded to chunks of 64 with empty entries) -- the order of the contacts */
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
+    if (g1 < 0) continue;                    /* padding entry */
     int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
     double margin = m->geom_margin[g1] > m->geom_margin[g2] ? m->geom_margin[g1] : m->geom_margin[g2];
     double gap = m->geom_gap[g1] > m->geom_gap[g2] ? m->geom_gap[g1] : m->geom_gap[g2];

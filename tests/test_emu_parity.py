@@ -580,7 +580,7 @@ def test_fixed_identity_frames_in_the_broad_phase_give_the_same_bits():
     flagged = int(((model.pair_word >> 24) & 1).sum())
     assert flagged > 200                                        # every ant geom against the floor and the eight boxes
     plain = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
-    plain.arrays["pair_word"] = (plain.pair_word & 0x00FFFFFF).astype(np.int32)
+    plain.arrays["pair_word"] = (plain.pair_word & ~np.int32(1 << 24)).astype(np.int32)
     a, b = EmuEnv(model, blob.pack(model)), EmuEnv(plain, blob.pack(plain))
     rng = np.random.default_rng(12)
     for env in (a, b):
@@ -595,6 +595,40 @@ def test_fixed_identity_frames_in_the_broad_phase_give_the_same_bits():
     assert most > 0
     for name in ("qpos", "qvel", "warm", "sens"):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_skipping_the_blocks_of_trees_out_of_reach_changes_nothing():
+    """The bounding-sphere pairs between two kinematic trees are a block of the pair list that the broad phase skips when
+    the trees' own bounding spheres are apart (mjcf._pair_layout).  A model whose blocks can never be skipped (reach =
+    1e300) steps to identical bits -- with the two ants far apart (blocks skipped), while one walks into the other (live:
+    contacts between the ants) and after they part again."""
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    assert model.ntp == 1 and 2.0 < model.tp_reach[0] < 3.0
+    never = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    never.arrays["tp_reach"] = np.full(1, 1e300)
+    a, b = EmuEnv(model, blob.pack(model)), EmuEnv(never, blob.pack(never))
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == mjcf.JNT_FREE]
+    qa0, qa1 = int(model.jnt_qposadr[free[0]]), int(model.jnt_qposadr[free[1]])
+    da1 = int(model.jnt_dofadr[free[1]])
+    rng = np.random.default_rng(3)
+    between = 0
+    for env in (a, b):
+        env.qpos[qa1:qa1 + 2] = env.qpos[qa0:qa0 + 2] + [1.6, 0.0]      # the second ant next to the first
+        env.qpos[qa0 + 2] = env.qpos[qa1 + 2] = 0.6
+        env.step(forward_only=True)
+    tree_of = lambda g: int(model.body_treeid[model.geom_bodyid[g]])
+    for k in range(300):
+        ctrl = rng.uniform(-1, 1, model.nu)
+        for env in (a, b):
+            env.ctrl[:model.nu] = ctrl
+            if 40 <= k < 120:
+                env.qvel[da1] = -2.0                                        # pushed into the first ant, then let go
+        img = a.step()
+        b.step()
+        between += sum(1 for g1, g2 in img.contact_geoms() if tree_of(g1) >= 0 and tree_of(g2) >= 0 and tree_of(g1) != tree_of(g2))
+        for name in ("qpos", "qvel", "warm"):
+            assert np.array_equal(getattr(a, name), getattr(b, name)), (k, name)
+    assert between > 10
 
 
 def test_in_launch_reset_with_several_frames_per_step():
