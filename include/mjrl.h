@@ -117,6 +117,17 @@ int mjrl_set_step_reset_mask(mjrl_env* env, const uint8_t* d_mask);
  *   d_reward  [n_env][n_agent]            d_term / d_trunc [n_env][n_agent] (bytes) */
 int mjrl_step_device(mjrl_env* env, const double* d_actions, int act_dim, int skip_frames, double* d_obs,
                      double* d_reward, uint8_t* d_term, uint8_t* d_trunc);
+/* Host buffers without copies: pinned host memory owned by the handle and mapped into the device's address space.
+ * mjrl_host_buffers returns (allocating on the first call, and again when act_dim or the observation width grew) the
+ * buffers mjrl_step_pinned works on: the caller writes actions [n_env][n_agent][act_dim] into *h_actions, calls
+ * mjrl_step_pinned (synchronous), and reads obs / reward / term / trunc in place -- the kernel reads the action rows
+ * and writes the result rows over PCIe itself, the observations under the rest of the launch, so a step costs the launch
+ * and not the launch plus five copies.  The buffers stay valid until the handle is destroyed or a later
+ * mjrl_host_buffers call has to grow them; every step overwrites them.  What mjrl_step_host does for caller-owned
+ * (pageable) arrays -- the shape of the reference's numpy API (mujoco_rl.py:243-289 returns fresh dicts every step). */
+int mjrl_host_buffers(mjrl_env* env, int act_dim, double** h_actions, double** h_obs, double** h_reward,
+                      uint8_t** h_term, uint8_t** h_trunc);
+int mjrl_step_pinned(mjrl_env* env, int act_dim, int skip_frames);
 /* Same with host buffers (PCIe copies in and out, synchronous). */
 int mjrl_step_host(mjrl_env* env, const double* h_actions, int act_dim, int skip_frames, double* h_obs,
                    double* h_reward, uint8_t* h_term, uint8_t* h_trunc);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
-    "mjrl_step_truncated",
+    "mjrl_step_truncated", "mjrl_host_buffers", "mjrl_step_pinned",
     "mjrl_reset_device", "mjrl_set_step_reset_mask", "mjrl_set_tag_tables", "mjrl_set_env_base", "mjrl_set_variants",
     "mjrl_encoder_load", "mjrl_encode_device", "mjrl_encode_host", "mjrl_set_camera_obs",
 ]
@@ -79,6 +79,8 @@ def load():
     L.mjrl_cap_overflows.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     L.mjrl_step_timeline.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t]
     L.mjrl_step_truncated.argtypes = [vp, ctypes.c_int]
+    L.mjrl_host_buffers.argtypes = [vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 5
+    L.mjrl_step_pinned.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     _lib = L
     return L
 
@@ -274,6 +276,24 @@ class Handle:
         act_dim = 0 if actions is None else int(actions.shape[-1])
         self._check(self._lib.mjrl_step_host(self._h, _host_ptr(actions), act_dim, int(skip_frames), _host_ptr(obs),
                                              _host_ptr(reward), _host_ptr(term), _host_ptr(trunc)))
+
+    def host_buffers(self, act_dim: int):
+        """Pinned host arrays ``(actions, obs, reward, term, trunc)`` that ``step_pinned`` reads and writes in place
+        (numpy views of memory owned by the handle; every step overwrites them)."""
+        ptrs = [ctypes.c_void_p() for _ in range(5)]
+        self._check(self._lib.mjrl_host_buffers(self._h, int(act_dim), *[ctypes.byref(p) for p in ptrs]))
+        n_agent, obs_dim = max(self.size("n_agent"), 1), max(self.size("obs_dim"), 1)
+        def view(ptr, ctype, shape):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array((ctype * n).from_address(ptr.value)).reshape(shape)
+        return (view(ptrs[0], ctypes.c_double, (self.n_env, n_agent, max(int(act_dim), 1))),
+                view(ptrs[1], ctypes.c_double, (self.n_env, n_agent, obs_dim)),
+                view(ptrs[2], ctypes.c_double, (self.n_env, n_agent)),
+                view(ptrs[3], ctypes.c_uint8, (self.n_env, n_agent)),
+                view(ptrs[4], ctypes.c_uint8, (self.n_env, n_agent)))
+
+    def step_pinned(self, act_dim: int, skip_frames: int):
+        self._check(self._lib.mjrl_step_pinned(self._h, int(act_dim), int(skip_frames)))
 
     def get_field(self, name: str):
         per = {"qpos": "nq", "qvel": "nv", "ctrl": "nu", "qacc_warmstart": "nv", "sensordata": "nsensordata"}

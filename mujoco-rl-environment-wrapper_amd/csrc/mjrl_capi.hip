@@ -269,6 +269,10 @@ struct mjrl_env {
   double *s_act = nullptr, *s_obs = nullptr, *s_rew = nullptr;
   unsigned char *s_term = nullptr, *s_trunc = nullptr;
   size_t s_act_n = 0, s_obs_n = 0;
+  // pinned host buffers mapped into the device's address space (mjrl_host_buffers / mjrl_step_pinned)
+  double *p_act = nullptr, *p_obs = nullptr, *p_rew = nullptr;
+  unsigned char *p_term = nullptr, *p_trunc = nullptr;
+  size_t p_act_n = 0, p_obs_n = 0;
   std::string err;
 };
 
@@ -314,6 +318,8 @@ void mjrl_destroy(mjrl_env* e) {
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->inertia, e->overflow};
   for (void* p : ptrs) if (p) hipFree(p);
+  void* pinned[] = {e->p_act, e->p_obs, e->p_rew, e->p_term, e->p_trunc};
+  for (void* p : pinned) if (p) hipHostFree(p);
   if (e->spec_module) hipModuleUnload(e->spec_module);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
@@ -971,6 +977,60 @@ int mjrl_step_host(mjrl_env* e, const double* h_actions, int act_dim, int skip_f
   if (h_reward) MJRL_HIP(e, hipMemcpyAsync(h_reward, e->s_rew, sizeof(double) * na, hipMemcpyDeviceToHost, e->stream));
   if (h_term) MJRL_HIP(e, hipMemcpyAsync(h_term, e->s_term, na, hipMemcpyDeviceToHost, e->stream));
   if (h_trunc) MJRL_HIP(e, hipMemcpyAsync(h_trunc, e->s_trunc, na, hipMemcpyDeviceToHost, e->stream));
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// Pinned host buffers the step kernel reads and writes in place: the observation rows travel over PCIe as the waves
+// that produce them finish, under the rest of the launch, instead of in copies after it.
+int mjrl_host_buffers(mjrl_env* e, int act_dim, double** h_actions, double** h_obs, double** h_reward, uint8_t** h_term,
+                      uint8_t** h_trunc) {
+  MJRL_ENTER(e);
+  if (act_dim < 0) MJRL_FAIL(e, 4, "host_buffers: act_dim %d", act_dim);
+  const size_t na = (size_t)e->n_env * std::max(e->n_agent, 1);
+  const size_t act_n = na * std::max(act_dim, 1), obs_n = na * std::max(e->obs_dim, 1);
+  if (act_n > e->p_act_n) {
+    if (e->p_act) hipHostFree(e->p_act);
+    e->p_act = nullptr; e->p_act_n = 0;
+    MJRL_HIP(e, hipHostMalloc((void**)&e->p_act, sizeof(double) * act_n, hipHostMallocMapped));
+    memset(e->p_act, 0, sizeof(double) * act_n);
+    e->p_act_n = act_n;
+  }
+  if (obs_n > e->p_obs_n) {
+    if (e->p_obs) hipHostFree(e->p_obs);
+    e->p_obs = nullptr; e->p_obs_n = 0;
+    MJRL_HIP(e, hipHostMalloc((void**)&e->p_obs, sizeof(double) * obs_n, hipHostMallocMapped));
+    memset(e->p_obs, 0, sizeof(double) * obs_n);
+    e->p_obs_n = obs_n;
+  }
+  if (!e->p_rew) {
+    MJRL_HIP(e, hipHostMalloc((void**)&e->p_rew, sizeof(double) * na, hipHostMallocMapped));
+    MJRL_HIP(e, hipHostMalloc((void**)&e->p_term, na, hipHostMallocMapped));
+    MJRL_HIP(e, hipHostMalloc((void**)&e->p_trunc, na, hipHostMallocMapped));
+    memset(e->p_rew, 0, sizeof(double) * na); memset(e->p_term, 0, na); memset(e->p_trunc, 0, na);
+  }
+  if (h_actions) *h_actions = e->p_act;
+  if (h_obs) *h_obs = e->p_obs;
+  if (h_reward) *h_reward = e->p_rew;
+  if (h_term) *h_term = e->p_term;
+  if (h_trunc) *h_trunc = e->p_trunc;
+  return 0;
+}
+
+int mjrl_step_pinned(mjrl_env* e, int act_dim, int skip_frames) {
+  MJRL_ENTER(e);
+  const size_t na = (size_t)e->n_env * std::max(e->n_agent, 1);
+  if (!e->p_rew || na * std::max(act_dim, 1) > e->p_act_n || na * std::max(e->obs_dim, 1) > e->p_obs_n)
+    MJRL_FAIL(e, 4, "step_pinned: call mjrl_host_buffers with this act_dim (and after the gather tables are set) first");
+  void *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_term = nullptr, *d_trunc = nullptr;
+  MJRL_HIP(e, hipHostGetDevicePointer(&d_act, e->p_act, 0));
+  MJRL_HIP(e, hipHostGetDevicePointer(&d_obs, e->p_obs, 0));
+  MJRL_HIP(e, hipHostGetDevicePointer(&d_rew, e->p_rew, 0));
+  MJRL_HIP(e, hipHostGetDevicePointer(&d_term, e->p_term, 0));
+  MJRL_HIP(e, hipHostGetDevicePointer(&d_trunc, e->p_trunc, 0));
+  int rc = launch_step(e, act_dim > 0 ? (const double*)d_act : nullptr, act_dim, skip_frames, e->d_gather ? (double*)d_obs : nullptr,
+                       (double*)d_rew, (uint8_t*)d_term, (uint8_t*)d_trunc, nullptr, 0, 0);
+  if (rc) return rc;
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   return 0;
 }

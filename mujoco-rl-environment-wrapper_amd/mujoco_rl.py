@@ -38,6 +38,8 @@ except Exception:
 class MuJoCoRL(_ParallelBase, MuJoCoParent):
     metadata = {"name": "mjrl_amd_v0", "render_modes": ["none"]}
 
+    _pinned = None          # (handle, actions, obs, reward, term, trunc): the handle's pinned host buffers, step_batched
+
     def __init__(self, config_dict: dict):
         self.agents = config_dict.get("agents", [])
         self.possible_agents = self.agents
@@ -444,18 +446,30 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
 
         ``actions``: ``[numEnvs, n_agent, act_dim]`` float64, numpy array or torch CUDA tensor.  With torch
         tensors nothing leaves HBM and the launch is asynchronous on the current torch stream; outputs are
-        torch tensors (pass preallocated ones to avoid allocations).  Returns ``(obs, reward, term, trunc)``.
+        torch tensors (pass preallocated ones to avoid allocations).  With a numpy array and no output arrays the
+        step runs on the handle's pinned host buffers (``mjrl_step_pinned``: the kernel reads the actions and writes
+        the results over PCIe itself, no copies) and the returned arrays are views of those buffers -- the next step
+        overwrites them, copy what has to survive it; pass output arrays to get copies (``mjrl_step_host``).
+        Returns ``(obs, reward, term, trunc)``.
         """
         if self._program is None and (self.environment_dynamics or self.reward_functions or self.done_functions):
             raise Exception("step_batched runs no host plugins; use step() or the fused vocabulary (dynamics.py)")
         n_agent, obs_dim = len(self.agents), self._handle.size("obs_dim")
         if isinstance(actions, np.ndarray):
-            actions = np.ascontiguousarray(actions, dtype=np.float64)
-            obs = np.zeros((self.n_env, n_agent, obs_dim)) if obs is None else obs
-            reward = np.zeros((self.n_env, n_agent)) if reward is None else reward
-            term = np.zeros((self.n_env, n_agent), np.uint8) if term is None else term
-            trunc = np.zeros((self.n_env, n_agent), np.uint8) if trunc is None else trunc
-            self._handle.step_host(actions, self.skip_frames, obs, reward, term, trunc)
+            if obs is None and reward is None and term is None and trunc is None:
+                act_dim = int(actions.shape[-1])
+                if self._pinned is None or self._pinned[0] is not self._handle or self._pinned[1].shape[-1] != act_dim:
+                    self._pinned = (self._handle,) + self._handle.host_buffers(act_dim)
+                _, p_act, obs, reward, term, trunc = self._pinned
+                np.copyto(p_act, actions.reshape(p_act.shape))
+                self._handle.step_pinned(act_dim, self.skip_frames)
+            else:
+                actions = np.ascontiguousarray(actions, dtype=np.float64)
+                obs = np.zeros((self.n_env, n_agent, obs_dim)) if obs is None else obs
+                reward = np.zeros((self.n_env, n_agent)) if reward is None else reward
+                term = np.zeros((self.n_env, n_agent), np.uint8) if term is None else term
+                trunc = np.zeros((self.n_env, n_agent), np.uint8) if trunc is None else trunc
+                self._handle.step_host(actions, self.skip_frames, obs, reward, term, trunc)
         else:
             import torch
             dev = actions.device

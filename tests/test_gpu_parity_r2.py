@@ -613,3 +613,30 @@ def test_random_scenes_on_the_device():
                 assert (stats[:, 0] == ora.ncon).all() and (stats[:, 1] == ora.nefc).all() and (stats[:, 2] == ora.niter).all(), (seed, step)
         assert rel(h.get_field("qpos"), np.tile(ora.qpos, (3, 1))) < 1e-8, seed
         h.close()
+
+
+@pytest.mark.gpu
+def test_pinned_host_buffers_give_what_the_copying_host_path_gives():
+    """``step_batched(numpy actions)`` without output arrays runs on the handle's pinned host buffers (the kernel reads
+    the action rows and writes the result rows over PCIe itself, ``mjrl_step_pinned``) and returns views of them; with
+    output arrays it is ``mjrl_step_host`` (copies).  Two envs stepped the two ways agree bit for bit, fused Language
+    channel, truncation flags and in-place reuse of the views included."""
+    from mjrl_amd.dynamics import Language
+    cfg = {"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 96, "maxSteps": 12,
+           "environmentDynamics": [Language]}
+    a, b = MuJoCoRL(dict(cfg)), MuJoCoRL(dict(cfg))
+    a.reset(); b.reset()
+    n_agent, obs_dim = 2, a._handle.size("obs_dim")
+    obs = np.zeros((96, n_agent, obs_dim)); rew = np.zeros((96, n_agent))
+    term = np.zeros((96, n_agent), np.uint8); trunc = np.zeros((96, n_agent), np.uint8)
+    rng = np.random.default_rng(4)
+    first = None
+    for t in range(16):
+        act = rng.uniform(-1, 1, (96, n_agent, 9))
+        out = a.step_batched(act)
+        b.step_batched(act, obs, rew, term, trunc)
+        for x, y in zip(out, (obs, rew, term, trunc)):
+            assert np.array_equal(x, y), t
+        first = out[0] if first is None else first
+        assert out[0] is first or np.shares_memory(out[0], first)      # the same pinned buffer every step
+    assert trunc.any() and np.abs(obs).sum() > 0
