@@ -2682,7 +2682,113 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   MJ_FOR(ag, a.n_agent) {
     if (a.trunc) a.trunc[(size_t)env * a.n_agent + ag] = ts >= a.max_steps;
   }
-  if (L == 0) {
+  // Rewards start at 0, terminations at false (mujoco_rl.py:262-263); the fused ops then run like the plugin loop.
+  // With the program staged in LDS (or no program) LANE ag IS AGENT ag: the reward and the flag are two registers, every
+  // agent's op runs at once.  The reference's loop is agent-minor and sequential, which shows in one place only -- an
+  // agent hears what a lower-numbered agent said THIS step and what a higher-numbered one said last step -- and that
+  // is reproduced by reading the other agent's slot before and after the writes.  (A program too large for the staging
+  // area keeps its rows in HBM and runs in lane 0, one agent after the other.)
+  if (a.n_op == 0 || ops_staged) {
+    const int ag = L;
+    const bool on = L < a.n_agent;
+    real rew = 0;
+    bool term = false;
+    if (a.n_op > 0) {
+      const real* act = a.actions ? S + l.bias : nullptr;
+      real* store = S + l.bias + t_store;
+      const int* TI = (const int*)(S + l.bias);
+      const real* prog_f = S + l.bias + t_pf;
+      const int32_t* prog_i = (const int32_t*)(TI + 2 * t_pi);
+      const int32_t* obs_len = (const int32_t*)(TI + 2 * t_ag);
+      const int32_t* agent_body = (const int32_t*)(TI + 2 * t_ag + a.n_agent);
+      auto ref_pos = [&](int ref) {
+        const int kind = ref >> 16, id = ref & 0xFFFF;
+        V3 t;
+        if (kind == 0) t = ld3(S + l.xpos + 3 * id) + rot(ldq(S + l.xquat + 4 * id), ld3(m.body_ipos + 3 * id));
+        else { Quat tq; geom_frame(m, l, S, id, t, tq); }
+        return t;
+      };
+      const unsigned long long genv = (unsigned long long)(a.env_base + env);
+      const int me = on ? ag : 0;                       // (lanes past the agents compute on agent 0 and write nothing)
+      for (int op = 0; op < a.n_op; op++) {
+        const int32_t* pi = prog_i + 8 * op;
+        const real* pf = prog_f + 4 * op;
+        const int kind = wv::first_int(pi[0]);
+        if (kind == OP_LANGUAGE) {
+          const int other = me == 0 ? 1 : 0;
+          const real before = other < a.n_agent ? store[other * a.n_slot + pi[2]] : 0.0;
+          wv::sync();
+          if (on) store[me * a.n_slot + pi[2]] = act ? (real)(long long)act[me * a.act_dim + pi[1]] : 0.0;
+          wv::sync();
+          const real after = other < a.n_agent ? store[other * a.n_slot + pi[2]] : 0.0;
+          real heard = other < me ? after : before;
+          if (heard != heard) heard = 0.0;
+          if (on && a.obs) a.obs[((size_t)env * a.n_agent + me) * a.obs_dim + obs_len[me] + pi[3]] = heard;
+        } else if (kind == OP_TARGET) {
+          if (on) {
+            const int body = agent_body[me];
+            const int adr = a.tag_adr[pi[1]], num = a.tag_num[pi[1]];
+            const unsigned long long seed = (unsigned long long)pf[2];
+            real* cur_slot = store + me * a.n_slot + pi[2];
+            real* inv_slot = pi[3] >= 0 ? store + me * a.n_slot + pi[3] : nullptr;
+            if (*cur_slot != *cur_slot) {            // first call of the episode: choose a target, empty the inventory
+              *cur_slot = (real)pick_of(mix64(seed, genv, (unsigned long long)me, (unsigned long long)ts, 0), num);
+              if (inv_slot) *inv_slot = 0.0;
+            }
+            int cur = (int)*cur_slot;
+            V3 p = ld3(S + l.xpos + 3 * body) + rot(ldq(S + l.xquat + 4 * body), ld3(m.body_ipos + 3 * body));
+            V3 t = ref_pos(a.tag_ref[adr + cur]);
+            V3 d3 = p - t;
+            real dist = sqrt(dot(d3, d3));
+            if (dist < pf[0]) {
+              if (inv_slot) *inv_slot = 1.0 - *inv_slot;
+              rew += pf[1];
+              cur = pick_of(mix64(seed, genv, (unsigned long long)me, (unsigned long long)ts, 1), num);
+              *cur_slot = (real)cur;
+              t = ref_pos(a.tag_ref[adr + cur]);
+              if (pi[5] >= 0) { V3 e3 = p - t; store[me * a.n_slot + pi[5]] = sqrt(dot(e3, e3)); }
+            }
+            if (a.obs) {
+              real* o = a.obs + ((size_t)env * a.n_agent + me) * a.obs_dim + obs_len[me] + pi[4];
+              o[0] = t.x; o[1] = t.y; o[2] = t.z;
+              if (inv_slot) o[3] = *inv_slot;
+            }
+          }
+        } else if (on) {
+          const int body = agent_body[me];
+          V3 p = ld3(S + l.xpos + 3 * body) + rot(ldq(S + l.xquat + 4 * body), ld3(m.body_ipos + 3 * body));
+          V3 t = v3(0, 0, 0);
+          bool have = true;
+          if (pi[1] == 2) {
+            const real held = store[me * a.n_slot + pi[5]];
+            have = held == held;                     // (no current target yet: the op does nothing)
+            if (have) t = ref_pos(a.tag_ref[a.tag_adr[pi[2]] + (int)held]);
+          } else {
+            t = ref_pos((pi[1] << 16) | pi[2]);
+          }
+          if (have) {
+            V3 d3 = p - t;
+            real dist = sqrt(dot(d3, d3));
+            if (kind == OP_DIST_REWARD) {
+              if (pi[4] == 0) {
+                rew += pf[0] * (-dist);
+              } else {
+                real prev = store[me * a.n_slot + pi[3]];
+                if (prev == prev) rew += pf[0] * (prev - dist);
+              }
+              if (pi[3] >= 0) store[me * a.n_slot + pi[3]] = dist;
+            } else if (kind == OP_DIST_DONE) {
+              term = term || dist < pf[0];
+            }
+          }
+        }
+      }
+    }
+    if (on) {
+      if (a.reward) a.reward[(size_t)env * a.n_agent + ag] = rew;
+      if (a.term) a.term[(size_t)env * a.n_agent + ag] = term;
+    }
+  } else if (L == 0) {
     // rewards start at 0, terminations at false (mujoco_rl.py:262-263); the fused ops then run like the plugin loop
     real rew[MAX_AGENT];
     bool term[MAX_AGENT];
