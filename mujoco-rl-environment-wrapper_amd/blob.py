@@ -18,12 +18,13 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 14
+VERSION = 15
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
                "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "has_accel", "nitemmax", "rowmap", "nfactor", "npass",
-               "ntab", "maxkdepth", "nchunk", "ntp"]
+               "ntab", "maxkdepth", "nchunk", "ntp", "nchunk_plane", "nchunk_box", "nchunk_boxbox",
+               "reserved_size"]        # (an even number of size fields keeps the float64 sections 8-byte aligned)
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
@@ -72,6 +73,8 @@ def _sizes(model) -> dict:
     s = {k: int(getattr(model, k)) for k in SIZE_FIELDS if hasattr(model, k) and not k.startswith("reserved")
          and k != "maxdepth"}
     s["maxdepth"] = int(model.body_depth.max()) if model.nbody else 0
+    s["reserved_size"] = 0
+    assert len(SIZE_FIELDS) % 2 == 0
     # narrow-phase work items one candidate pair can need (box-box 16, plane-box 8, capsule-capsule 4, capsule ends 2);
     # 16 also tells the kernels that the level has box-box pairs at all (the routine is compiled out of a specialised
     # kernel otherwise)

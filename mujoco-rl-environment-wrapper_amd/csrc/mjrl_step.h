@@ -838,7 +838,11 @@ __device__ inline void stage_collision(const DevModel& m, const Lay& l, const Ge
     c1 = ld3(S + l.gpos + 3 * (wring[0] & 255)); c2 = ld3(S + l.gpos + 3 * ((wring[0] >> 8) & 255));   // (past the list / padding: geom 0, unused)
     const int chunk = base >> 6;
     const int info = chunk < 64 ? wv::lane_int(info_reg, chunk) : wv::first_int(m.chunk_info[chunk]);
-    const int kind = info & 255, tp = info >> 8;
+    // (the kind follows from the chunk's place in the list -- sizes of the model, so constants in a specialised kernel,
+    // whose unrolled chunks then hold one test each and no dispatch)
+    const int kind = chunk < m.nchunk_plane ? 0 : (chunk < m.nchunk_plane + m.nchunk_box ? 1 :
+                     (chunk < m.nchunk_plane + m.nchunk_box + m.nchunk_boxbox ? 2 : 3));
+    const int tp = info >> 8;
     if (tp > 0 && tp <= 64 && !((tp_live >> (tp - 1)) & 1ull)) continue;      // the two trees are out of reach of each other
     const bool real_pair = word >= 0;                 // (bit 31: a padding entry)
     const int g1 = word & 255, g2 = (word >> 8) & 255;

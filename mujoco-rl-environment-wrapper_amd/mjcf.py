@@ -129,6 +129,9 @@ class Model:
     ntab: int = 0
     nchunk: int = 0         # chunks of 64 entries of the candidate-pair list
     ntp: int = 0            # pairs of kinematic trees whose bounding-sphere pairs form a block of their own
+    nchunk_plane: int = 0   # the list starts with this many chunks of plane pairs, then nchunk_box chunks of (sphere |
+    nchunk_box: int = 0     # capsule)-box pairs, then nchunk_boxbox chunks of box-box pairs; the rest are bounding-sphere
+    nchunk_boxbox: int = 0  # chunks (sizes, so a specialised kernel knows every chunk's test at compile time)
     # options
     timestep: float = 0.002
     gravity: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -9.81]))
@@ -687,6 +690,9 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     rb, mg = A["geom_rbound"], A["geom_margin"]
     pairs, chunk_info, tp_root, tp_reach = _pair_layout(m, A, pairs, broad_cull)
     m.npair, m.nchunk, m.ntp = len(pairs), len(chunk_info), len(tp_reach)
+    kinds = [ci & 255 for ci in chunk_info]
+    m.nchunk_plane, m.nchunk_box, m.nchunk_boxbox = kinds.count(PAIR_PLANE), kinds.count(PAIR_BOX), kinds.count(PAIR_BOXBOX)
+    assert kinds == sorted(kinds)               # the segments come in the order of the kinds' codes
     A["chunk_info"] = np.array(chunk_info, np.int32)
     A["tp_root"] = np.array(tp_root, np.int32).reshape(-1)
     A["tp_reach"] = np.array(tp_reach, np.float64)
