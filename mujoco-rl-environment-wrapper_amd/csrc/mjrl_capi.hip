@@ -306,7 +306,9 @@ struct DeviceGuard {
 
 extern "C" {
 
-const char* mjrl_version(void) { return "mjrl-hip 0.6 (blob layout 13, gfx950)"; }
+#define MJRL_STR_(x) #x
+#define MJRL_STR(x) MJRL_STR_(x)
+const char* mjrl_version(void) { return "mjrl-hip 0.7 (blob layout " MJRL_STR(MJRL_BLOB_VERSION) ", gfx950)"; }
 
 const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 
