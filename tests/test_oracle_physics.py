@@ -278,3 +278,70 @@ def test_soft_contact_rests_at_the_depth_its_reference_acceleration_dictates():
         if k * d * r < g * (1.0 / d - 1.0): lo = r
         else: hi = r
     assert pen == pytest.approx(0.5 * (lo + hi), rel=1e-3)
+
+
+def _contact_state(level, steps=260, seed=11, tight=True):
+    """A contact-rich state of an ant level in the oracle (random actions from just above the floor); with `tight` the
+    solver runs to its fixed point (tolerance 0, 4000 sweeps)."""
+    model = mjcf.compile_mjcf(levels.level_path(level))
+    if tight:
+        model.tolerance, model.iterations = 0.0, 4000
+    env = OracleEnv(blob.pack(model))
+    rng = np.random.default_rng(seed)
+    for j in range(model.njnt):
+        if model.jnt_type[j] == mjcf.JNT_FREE:
+            env.qpos[model.jnt_qposadr[j] + 2] = 0.6
+    for k in range(2000):                       # (the ants hop: wait for a step with several feet on the ground)
+        env.ctrl[:] = rng.uniform(-1, 1, model.nu)
+        env.step()
+        if k >= steps and env.ncon >= 3:
+            break
+    env.ctrl[:] = rng.uniform(-1, 1, model.nu)
+    env.forward()
+    return model, env
+
+
+@pytest.mark.parametrize("level", ["two_agent.xml", "four_agent.xml"])
+def test_solver_output_satisfies_the_complementarity_conditions(level):
+    """What the constraint solver returns is checked against the problem it is meant to solve, in numpy and without any
+    of its code: with A = J M^-1 J' + diag(R) and b = J qacc_smooth - aref, the forces of the pyramidal-cone dual obey
+    f >= 0, g = A f + b >= 0 and f'g = 0 (run to the fixed point: tolerance 0), qfrc_constraint is J'f and qacc is
+    qacc_smooth + M^-1 J'f."""
+    model, env = _contact_state(level)
+    n = env.nefc
+    assert env.ncon >= 3 and n >= 8
+    J, R, f = env.efc_J[:n].copy(), env.efc_R[:n].copy(), env.efc_force[:n].copy()
+    M = env.qMdense.copy()
+    A = J @ np.linalg.solve(M, J.T) + np.diag(R)
+    b = J @ env.qacc_smooth - env.efc_aref[:n]
+    g = A @ f + b
+    scale = np.abs(b).max()
+    assert (f >= 0).all()
+    assert g.min() > -1e-7 * scale, g.min() / scale
+    assert np.abs(f * g).max() < 1e-7 * scale * max(f.max(), 1.0)
+    assert (f > 0).sum() >= 3                                   # the ants stand on something
+    assert np.allclose(env.qfrc_constraint, J.T @ f, rtol=0, atol=1e-9 * max(1.0, np.abs(J.T @ f).max()))
+    assert np.allclose(env.qacc, env.qacc_smooth + np.linalg.solve(M, J.T @ f), rtol=0, atol=1e-8 * max(1.0, np.abs(env.qacc).max()))
+
+
+def test_contact_rows_are_the_pyramid_edges_of_the_relative_contact_velocity():
+    """Every contact row against the independent numpy Jacobian of its two bodies: row 2k / 2k+1 of a contact is
+    n' (J2 - J1) +/- mu t_k' (J2 - J1) at the contact point (the pyramidal cone's edges), J_b the translational Jacobian of
+    the point moving with body b (mjcf.body_jacobian_numpy)."""
+    model, env = _contact_state("two_agent.xml", tight=False)
+    xpos, xquat = env.xpos.copy(), env.xquat.copy()
+    checked = 0
+    for c in env.contacts():
+        adr = c["efc_address"]
+        if adr < 0:
+            continue
+        b1, b2 = int(model.geom_bodyid[c["geom1"]]), int(model.geom_bodyid[c["geom2"]])
+        dj = mjcf.body_jacobian_numpy(model, xpos, xquat, b2, c["pos"])[:3] - mjcf.body_jacobian_numpy(model, xpos, xquat, b1, c["pos"])[:3]
+        frame = np.asarray(c["frame"]).reshape(3, 3)
+        mu = max(model.geom_friction[c["geom1"]][0], model.geom_friction[c["geom2"]][0])
+        for k in range(2):
+            for s, sign in enumerate((1.0, -1.0)):
+                expect = frame[0] @ dj + sign * mu * (frame[1 + k] @ dj)
+                assert np.allclose(env.efc_J[adr + 2 * k + s], expect, rtol=0, atol=1e-12), (adr, k, s)
+                checked += 1
+    assert checked >= 8
