@@ -345,3 +345,42 @@ def test_contact_rows_are_the_pyramid_edges_of_the_relative_contact_velocity():
                 assert np.allclose(env.efc_J[adr + 2 * k + s], expect, rtol=0, atol=1e-12), (adr, k, s)
                 checked += 1
     assert checked >= 8
+
+
+def test_contact_rows_reference_acceleration_and_regularisation_follow_the_documented_formulas():
+    """aref, R and the impedance of every contact row recomputed in numpy from MuJoCo's documented solver-parameter
+    formulas (solref = (timeconst, dampratio), solimp = (d0, dwidth, width, midpoint, power); "Solver parameters" of the
+    MuJoCo documentation): d(x) the power-law sigmoid of x = |pos - margin| / width, K = 1 / (dmax^2 tc^2 dr^2),
+    B = 2 / (dmax tc), aref = -B vel - K d (pos - margin), R = (1 - d) / d * diagApprox (pyramid edges: 2 mu^2 times that,
+    diagApprox = (1 + mu^2) (invweight0[body1] + invweight0[body2]))."""
+    model, env = _contact_state("two_agent.xml", tight=False)
+    n = env.nefc
+    vel = env.efc_J[:n] @ env.qvel
+    checked = 0
+    for c in env.contacts():
+        adr = c["efc_address"]
+        if adr < 0:
+            continue
+        g1, g2 = c["geom1"], c["geom2"]
+        assert np.array_equal(model.geom_solref[g1], model.geom_solref[g2]) and np.array_equal(model.geom_solimp[g1], model.geom_solimp[g2])
+        tc, dr = model.geom_solref[g1]
+        d0, dw, width, mid, power = model.geom_solimp[g1]
+        tc = max(tc, 2 * model.timestep)
+        margin = max(model.geom_margin[g1], model.geom_margin[g2]) - max(model.geom_gap[g1], model.geom_gap[g2])
+        x = min(abs(c["dist"] - margin) / width, 1.0)
+        if x <= mid:
+            y = x ** power / mid ** (power - 1)
+        else:
+            y = 1.0 - (1.0 - x) ** power / (1.0 - mid) ** (power - 1)
+        imp = d0 + y * (dw - d0)
+        dmax = min(max(dw, 1e-4), 0.9999)
+        K, B = 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
+        mu = max(model.geom_friction[g1][0], model.geom_friction[g2][0])
+        b1, b2 = int(model.geom_bodyid[g1]), int(model.geom_bodyid[g2])
+        tran = model.body_invweight0[b1][0] + model.body_invweight0[b2][0]
+        R = 2 * mu * mu * (1 - imp) / imp * (tran + mu * mu * tran)
+        for r in range(adr, adr + 4):
+            assert np.isclose(env.efc_aref[r], -B * vel[r] - K * imp * (c["dist"] - margin), rtol=1e-12, atol=1e-12), r
+            assert np.isclose(env.efc_R[r], R, rtol=1e-12), r
+            checked += 1
+    assert checked >= 8
