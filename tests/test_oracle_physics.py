@@ -384,3 +384,31 @@ def test_contact_rows_reference_acceleration_and_regularisation_follow_the_docum
             assert np.isclose(env.efc_R[r], R, rtol=1e-12), r
             checked += 1
     assert checked >= 8
+
+
+def test_a_step_is_the_semi_implicit_euler_update_of_its_own_forward_pass():
+    """One step of the 2-agent level against numpy: with the forces of the step's forward pass, the new velocity is
+    v + h (M + h diag(damping))^-1 (qfrc_smooth + qfrc_constraint) (MuJoCo's Euler integrator with joint damping treated
+    implicitly), hinge positions move by h v', a free joint's position by h v' and its quaternion by the rotation
+    h |w'| about w' (body frame), renormalised."""
+    model, env = _contact_state("two_agent.xml", tight=False)
+    h = model.timestep
+    q0, v0 = env.qpos.copy(), env.qvel.copy()
+    env.step()
+    M = env.qMdense.copy()
+    rhs = env.qfrc_smooth + env.qfrc_constraint
+    v1 = v0 + h * np.linalg.solve(M + h * np.diag(model.dof_damping), rhs)
+    assert np.allclose(env.qvel, v1, rtol=0, atol=1e-11 * max(1.0, np.abs(v1).max()))
+    for j in range(model.njnt):
+        qa, da = int(model.jnt_qposadr[j]), int(model.jnt_dofadr[j])
+        if model.jnt_type[j] == mjcf.JNT_FREE:
+            assert np.allclose(env.qpos[qa:qa + 3], q0[qa:qa + 3] + h * v1[da:da + 3], atol=1e-13)
+            w = v1[da + 3:da + 6]
+            ang = h * np.linalg.norm(w)
+            axis = w / np.linalg.norm(w)
+            dq = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+            a = q0[qa + 3:qa + 7] / np.linalg.norm(q0[qa + 3:qa + 7])
+            q = np.array([a[0] * dq[0] - a[1:] @ dq[1:], *(a[0] * dq[1:] + dq[0] * a[1:] + np.cross(a[1:], dq[1:]))])
+            assert np.allclose(env.qpos[qa + 3:qa + 7], q / np.linalg.norm(q), atol=1e-13)
+        else:
+            assert np.isclose(env.qpos[qa], q0[qa] + h * v1[da], atol=1e-13)
