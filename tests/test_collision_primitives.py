@@ -1,0 +1,115 @@
+"""Known answers for the narrow phase of the oracle AND of the device source (its CPU lane emulation, checked against the
+oracle's contact list in every scene below): distances, normals and contact points of the primitive pairs in closed form --
+sphere / capsule / box against a plane, sphere and capsule against each other and against a box.  MuJoCo's convention:
+the normal points from geom1 to geom2, the contact point lies halfway between the two surfaces."""
+import numpy as np
+import pytest
+
+from mjrl_amd import blob, mjcf
+from oracle.oracle import OracleEnv
+from tests.emu.emu import EmuEnv
+
+
+def scene(bodies: str, plane: bool = False):
+    floor = '<geom name="floor" type="plane" size="5 5 0.1" margin="0.05"/>' if plane else ""
+    xml = f'<mujoco><option timestep="0.002" gravity="0 0 0"/><worldbody>{floor}{bodies}</worldbody></mujoco>'
+    model = mjcf.compile_mjcf_string(xml)
+    packed = blob.pack(model)
+    env = OracleEnv(packed)
+    # the device source on the same scene: the same contacts, in the same order
+    img = EmuEnv(model, packed).step(forward_only=True)
+    assert img.ncon == env.ncon
+    dev = img.region("con")
+    for k, c in enumerate(env.contacts()):
+        assert np.isclose(dev[k, 0], c["dist"], rtol=1e-13, atol=1e-15) and np.allclose(dev[k, 1:4], c["pos"], rtol=1e-13, atol=1e-15)
+        assert np.allclose(dev[k, 4:13].reshape(3, 3), c["frame"], rtol=1e-13, atol=1e-15)
+    return model, env
+
+
+def body(name, pos, geom, quat="1 0 0 0"):
+    return (f'<body name="{name}" pos="{pos[0]} {pos[1]} {pos[2]}" quat="{quat}"><joint type="free"/>'
+            f'<geom name="{name}" margin="0.05" {geom}/></body>')
+
+
+def test_sphere_on_a_plane():
+    for z in (0.08, 0.1, 0.13):                        # penetrating, touching, inside the margin
+        _, env = scene(body("s", (0.3, -0.2, z), 'type="sphere" size="0.1"'), plane=True)
+        (c,) = env.contacts()
+        assert np.isclose(c["dist"], z - 0.1, atol=1e-14)
+        assert np.allclose(c["frame"][0], [0, 0, 1], atol=1e-14)
+        assert np.allclose(c["pos"], [0.3, -0.2, (z - 0.1) / 2], atol=1e-14)      # halfway between sphere bottom and plane
+    _, env = scene(body("s", (0, 0, 0.2), 'type="sphere" size="0.1"'), plane=True)
+    assert env.ncon == 0                               # beyond the margin
+
+
+def test_capsule_on_a_plane_has_a_contact_per_end():
+    # a capsule along x (rotated about y by 90 degrees), radius 0.05, half-length 0.2, tilted by raising one end
+    for tilt in (0.0, 0.1):
+        c, s = np.cos((np.pi / 2 + tilt) / 2), np.sin((np.pi / 2 + tilt) / 2)
+        _, env = scene(body("c", (0, 0, 0.07), 'type="capsule" size="0.05 0.2"', quat=f"{c} 0 {s} 0"), plane=True)
+        cons = env.contacts()
+        axis = np.array([np.sin(np.pi / 2 + tilt), 0, np.cos(np.pi / 2 + tilt)])
+        ends = [np.array([0, 0, 0.07]) + sgn * 0.2 * axis for sgn in (1, -1)]
+        expect = sorted(e[2] - 0.05 for e in ends if e[2] - 0.05 < 0.05)
+        assert np.allclose(sorted(k["dist"] for k in cons), expect, atol=1e-13)
+        for k in cons:
+            assert np.allclose(k["frame"][0], [0, 0, 1], atol=1e-14)
+
+
+def test_two_spheres():
+    p1, p2 = np.array([0.0, 0.0, 1.0]), np.array([0.12, 0.09, 1.2])
+    _, env = scene(body("a", p1, 'type="sphere" size="0.1"') + body("b", p2, 'type="sphere" size="0.15"'))
+    (c,) = env.contacts()
+    d = np.linalg.norm(p2 - p1)
+    n = (p2 - p1) / d
+    assert np.isclose(c["dist"], d - 0.25, atol=1e-14) and np.allclose(c["frame"][0], n, atol=1e-14)
+    assert np.allclose(c["pos"], p1 + n * (0.1 + (d - 0.25) / 2), atol=1e-14)
+
+
+def test_crossed_capsules_touch_at_the_common_perpendicular():
+    # one capsule along z at the origin, one along x at height 0 passing at y = 0.13: the segments' closest points are
+    # (0, 0, 0) and (0, 0.13, 0)
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    _, env = scene(body("a", (0, 0, 0), 'type="capsule" size="0.05 0.3"') +
+                   body("b", (0, 0.13, 0), 'type="capsule" size="0.04 0.3"', quat=f"{c} 0 {s} 0"))
+    (k,) = env.contacts()
+    assert np.isclose(k["dist"], 0.13 - 0.09, atol=1e-13)
+    assert np.allclose(np.abs(k["frame"][0]), [0, 1, 0], atol=1e-12)
+    assert np.allclose(k["pos"], [0, 0.05 + 0.02, 0], atol=1e-12)
+
+
+def test_parallel_capsules_share_the_overlap_of_their_segments():
+    # both along z, axes 0.12 apart, the second shifted up by 0.2: the overlap of the segments is z in [-0.1, 0.3]
+    _, env = scene(body("a", (0, 0, 0), 'type="capsule" size="0.05 0.3"') + body("b", (0.12, 0, 0.2), 'type="capsule" size="0.05 0.3"'))
+    cons = env.contacts()
+    assert len(cons) >= 2
+    for k in cons:
+        assert np.isclose(k["dist"], 0.02, atol=1e-13) and np.allclose(np.abs(k["frame"][0]), [1, 0, 0], atol=1e-12)
+        assert np.isclose(k["pos"][0], 0.06, atol=1e-12) and -0.1 - 1e-12 <= k["pos"][2] <= 0.3 + 1e-12
+    zs = sorted(k["pos"][2] for k in cons)
+    assert np.isclose(zs[0], -0.1, atol=1e-12) and np.isclose(zs[-1], 0.3, atol=1e-12)
+
+
+def test_sphere_against_a_box_face_edge_and_corner():
+    half = np.array([0.3, 0.2, 0.1])
+    for p, closest in (((0.1, -0.05, 0.22), (0.1, -0.05, 0.1)),           # above the top face
+                       ((0.38, 0.0, 0.18), (0.3, 0.0, 0.1)),              # off an edge
+                       ((0.36, 0.26, 0.16), (0.3, 0.2, 0.1))):            # off a corner
+        p, closest = np.array(p), np.array(closest)
+        _, env = scene('<geom name="box" type="box" size="0.3 0.2 0.1" margin="0.05"/>' + body("s", p, 'type="sphere" size="0.1"'))
+        (k,) = env.contacts()
+        d = np.linalg.norm(p - closest)
+        assert np.isclose(k["dist"], d - 0.1, atol=1e-13)
+        n = k["frame"][0] * (1 if k["geom1"] == 0 else -1)               # box -> sphere
+        assert np.allclose(n, (p - closest) / d, atol=1e-12)
+        assert np.allclose(k["pos"], closest + (p - closest) / d * (d - 0.1) / 2, atol=1e-12)
+
+
+def test_box_on_a_plane_touches_with_its_four_lower_corners():
+    _, env = scene(body("b", (0.2, 0.1, 0.11), 'type="box" size="0.3 0.2 0.1"'), plane=True)
+    cons = env.contacts()
+    assert len(cons) == 4
+    corners = np.array(sorted((k["pos"][0], k["pos"][1]) for k in cons))
+    assert np.allclose(corners, sorted((0.2 + sx * 0.3, 0.1 + sy * 0.2) for sx in (-1, 1) for sy in (-1, 1)), atol=1e-13)
+    for k in cons:
+        assert np.isclose(k["dist"], 0.01, atol=1e-14) and np.allclose(k["frame"][0], [0, 0, 1], atol=1e-14)
