@@ -113,3 +113,21 @@ def test_box_on_a_plane_touches_with_its_four_lower_corners():
     assert np.allclose(corners, sorted((0.2 + sx * 0.3, 0.1 + sy * 0.2) for sx in (-1, 1) for sy in (-1, 1)), atol=1e-13)
     for k in cons:
         assert np.isclose(k["dist"], 0.01, atol=1e-14) and np.allclose(k["frame"][0], [0, 0, 1], atol=1e-14)
+
+
+def test_capsule_against_a_box_face():
+    box = '<geom name="box" type="box" size="0.3 0.2 0.1" margin="0.05"/>'
+    # lying flat above the top face (axis along x): both ends are 0.02 above the face
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    _, env = scene(box + body("c", (0.0, 0.05, 0.1 + 0.04 + 0.02), 'type="capsule" size="0.04 0.15"', quat=f"{c} 0 {s} 0"))
+    cons = env.contacts()
+    assert len(cons) == 2
+    for k in cons:
+        n = k["frame"][0] * (1 if k["geom1"] == 0 else -1)               # box -> capsule
+        assert np.isclose(k["dist"], 0.02, atol=1e-13) and np.allclose(n, [0, 0, 1], atol=1e-12)
+        assert np.isclose(k["pos"][2], 0.11, atol=1e-12) and np.isclose(k["pos"][1], 0.05, atol=1e-12)
+    assert np.allclose(sorted(k["pos"][0] for k in cons), [-0.15, 0.15], atol=1e-12)
+    # standing on the face: one contact under the lower end cap
+    _, env = scene(box + body("c", (0.1, 0.0, 0.1 + 0.15 + 0.04 + 0.01), 'type="capsule" size="0.04 0.15"'))
+    (k,) = env.contacts()
+    assert np.isclose(k["dist"], 0.01, atol=1e-13) and np.allclose(k["pos"], [0.1, 0.0, 0.105], atol=1e-12)
