@@ -700,7 +700,7 @@ static int launch_encoder(mjrl_env* e, const uint8_t* d_rgb, int n_img, float* d
   hipLaunchKernelGGL(enc::mjrl_encoder_conv_kernel, dim3(n_img), dim3(256), conv_lds, e->stream, d_rgb, n_img,
                      (const enc::frag_ab*)e->enc_w1, e->enc_b1, (const enc::frag_ab*)e->enc_w2, e->enc_b2, e->enc_a2);
   MJRL_HIP(e, hipGetLastError());
-  hipLaunchKernelGGL(enc::mjrl_encoder_dense_kernel, dim3((n_img + 15) / 16, e->enc_tiles), dim3(64 * enc::DENSE_WAVES), 0, e->stream, e->enc_a2, n_img,
+  hipLaunchKernelGGL(enc::mjrl_encoder_dense_kernel, dim3((n_img + 15) / 16, (e->enc_tiles + enc::DENSE_TILES - 1) / enc::DENSE_TILES), dim3(64 * enc::DENSE_WAVES), 0, e->stream, e->enc_a2, n_img,
                      (const enc::frag_ab*)e->enc_wd, e->enc_bd, e->enc_latent, e->enc_tiles, e->enc_relu, d_latent, d_obs,
                      d_obs_row, e->obs_dim);
   MJRL_HIP(e, hipGetLastError());

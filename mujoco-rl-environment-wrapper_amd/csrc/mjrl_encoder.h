@@ -9,9 +9,9 @@
 //                              [32 ch] from the uint8 image staged in LDS, its output (32x32x32 bf16, 64 KB) kept in
 //                              LDS; conv2 as 9 taps x ([256 px] x [32] x [64 ch]) reading 16-byte channel runs of that
 //                              LDS image; output 16x16x64 bf16 in flatten order (h, w, c) to HBM.
-//   mjrl_encoder_dense_kernel  [n_img] x [16384] x [latent]: a workgroup of 8 waves per 16 images x 16 latent columns,
-//                              K split eight ways and summed through LDS; bias, relu, fp32 latents and, when asked,
-//                              their scatter into the observation rows (float64).
+//   mjrl_encoder_dense_kernel  [n_img] x [16384] x [latent]: a workgroup of 8 waves per 16 images x up to 128 latent
+//                              columns, K split eight ways and summed through LDS; bias, relu, fp32 latents and, when
+//                              asked, their scatter into the observation rows (float64).
 // Weight fragments are packed on the host in the lane order of the MFMA operands (lane l holds B[k = 8 (l >> 4) + j]
 // [col = l & 15], j = 0..7), so a lane's fragment is one 16-byte load.
 #ifndef MJRL_ENCODER_H
@@ -127,54 +127,75 @@ __global__ __launch_bounds__(256) void mjrl_encoder_conv_kernel(const unsigned c
   for (int i = tid; i < FLAT * 2 / 16; i += 256) out[i] = src[i];
 }
 
-// grid (ceil(n_img / 16), latent tiles), 8 waves per workgroup: a workgroup owns 16 images x 16 latent columns, its
-// waves split K = 16384 eight ways (64 k-steps each, the loads of 8 steps in flight) and the partial tiles are summed
-// through LDS in wave order -- a single wave walking all 512 k-steps left the chip at one or two waves per CU, bound by
-// the latency of its own loads.
-enum { DENSE_WAVES = 8 };
+// grid (ceil(n_img / 16), ceil(latent tiles / DENSE_TILES)), 8 waves per workgroup: a workgroup owns 16 images x up to
+// DENSE_TILES x 16 latent columns, its waves split K = 16384 eight ways (64 k-steps each) and the partial tiles are
+// summed through LDS in wave order.  An activation fragment is fetched once per k-step and multiplied into every latent
+// tile of the group; the weight fragments of a k-step's tiles are adjacent in memory.  Measured on config 5 with the
+// encoder (512 copies, latent 100 = 7 tiles): 1, 2, 4, 8 tiles per group give 0.291, 0.288, 0.324, 0.302 ms per step --
+// fewer, fatter workgroups read the activations fewer times but leave CUs idle (64 image tiles is all there is); 2.
+#ifndef MJRL_DENSE_TILES
+#define MJRL_DENSE_TILES 2
+#endif
+enum { DENSE_WAVES = 8, DENSE_TILES = MJRL_DENSE_TILES };
 __global__ __launch_bounds__(64 * DENSE_WAVES) void mjrl_encoder_dense_kernel(
     const unsigned short* __restrict__ a2, int n_img, const frag_ab* __restrict__ wdp, const float* __restrict__ bd,
     int latent, int n_tile, int relu, float* __restrict__ out, double* __restrict__ obs, const int* __restrict__ img_obs_row,
     int obs_dim) {
-  __shared__ float part[DENSE_WAVES][64][4];
+  __shared__ float part[DENSE_WAVES][DENSE_TILES][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, grp = lane >> 4;
-  const int img0 = blockIdx.x * 16, nt = blockIdx.y;
+  const int img0 = blockIdx.x * 16, nt0 = blockIdx.y * DENSE_TILES;
+  const int tiles = n_tile - nt0 < DENSE_TILES ? n_tile - nt0 : DENSE_TILES;      // latent tiles of this workgroup
   const int my_img = img0 + row < n_img ? img0 + row : n_img - 1;           // (rows past the batch repeat the last image)
   const frag_ab* arow = (const frag_ab*)(a2 + (size_t)my_img * FLAT) + grp;  // k = 32 kk + 8 grp + j
-  const frag_ab* bcol = wdp + (size_t)nt * 64 + lane;                        // fragment (kk, nt): wdp[(kk * n_tile + nt) * 64 + lane]
-  frag_cd acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  const frag_ab* bcol = wdp + (size_t)nt0 * 64 + lane;                       // fragment (kk, nt): wdp[(kk * n_tile + nt) * 64 + lane]
+  frag_cd acc[DENSE_TILES];
+#pragma unroll
+  for (int t = 0; t < DENSE_TILES; t++) acc[t] = frag_cd{0, 0, 0, 0};
   constexpr int STEPS = FLAT / 32 / DENSE_WAVES;
   const int k0 = wave * STEPS;
-  for (int kk = k0; kk < k0 + STEPS; kk += 8) {
-    frag_ab a[8], b[8];
+  // (no branch on `tiles` in the loop: a group with fewer than DENSE_TILES tiles multiplies its last tile again and drops
+  // the result -- with conditional loads the compiler kept every fragment live on both paths and spilled)
+  int toff[DENSE_TILES];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { a[u] = arow[(kk + u) * 4]; b[u] = bcol[(size_t)(kk + u) * n_tile * 64]; }
+  for (int t = 0; t < DENSE_TILES; t++) toff[t] = (t < tiles ? t : tiles - 1) * 64;
+  for (int kk = k0; kk < k0 + STEPS; kk += 2) {
+    frag_ab a[2], b[2][DENSE_TILES];
 #pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u + 1], b[u + 1], acc1, 0, 0, 0);
+    for (int u = 0; u < 2; u++) {
+      a[u] = arow[(kk + u) * 4];
+      const frag_ab* bk = bcol + (size_t)(kk + u) * n_tile * 64;
+#pragma unroll
+      for (int t = 0; t < DENSE_TILES; t++) b[u][t] = bk[toff[t]];
     }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int t = 0; t < DENSE_TILES; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u][t], acc[t], 0, 0, 0);
   }
 #pragma unroll
-  for (int r = 0; r < 4; r++) part[wave][lane][r] = acc0[r] + acc1[r];
+  for (int t = 0; t < DENSE_TILES; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave][t][lane][r] = acc[t][r];
   __syncthreads();
-  if (wave != 0) return;
-  const int n = 16 * nt + row;                                               // this lane's latent column
-  if (n >= latent) return;
-  const float bias = bd[n];
+  // the sums and the epilogue: wave w takes the latent tiles w, w + 8, ... of the group
+  for (int t = wave; t < tiles; t += DENSE_WAVES) {
+    const int n = 16 * (nt0 + t) + row;                                      // this lane's latent column
+    if (n >= latent) continue;
+    const float bias = bd[n];
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int image = img0 + 4 * grp + r;
-    if (image >= n_img) continue;
-    float v = part[0][lane][r];
+    for (int r = 0; r < 4; r++) {
+      const int image = img0 + 4 * grp + r;
+      if (image >= n_img) continue;
+      float v = part[0][t][lane][r];
 #pragma unroll
-    for (int w = 1; w < DENSE_WAVES; w++) v += part[w][lane][r];
-    v += bias;
-    if (relu) v = fmaxf(v, 0.0f);
-    if (out) out[(size_t)image * latent + n] = v;
-    if (obs && img_obs_row) {
-      const int at = img_obs_row[image];        // index of the first latent slot in the flat observation tensor, or -1
-      if (at >= 0) obs[(size_t)at + n] = (double)v;
+      for (int w = 1; w < DENSE_WAVES; w++) v += part[w][t][lane][r];
+      v += bias;
+      if (relu) v = fmaxf(v, 0.0f);
+      if (out) out[(size_t)image * latent + n] = v;
+      if (obs && img_obs_row) {
+        const int at = img_obs_row[image];        // index of the first latent slot in the flat observation tensor, or -1
+        if (at >= 0) obs[(size_t)at + n] = (double)v;
+      }
     }
   }
 }
