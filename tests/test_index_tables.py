@@ -91,3 +91,27 @@ def test_generated_level_compiles_like_the_reference_file(name):
         get = lambda d: [x.get("@name", x.get("@joint")) for x in xmldict.find_in_nested_dict(d, parent=parent)]
         assert get(a) == get(b), parent
     assert xmldict.find_in_nested_dict(a, parent="sensor") == xmldict.find_in_nested_dict(b, parent="sensor")
+
+
+def test_blob_sections_are_aligned_to_their_element_size():
+    """The float64 sections of a packed model start on 8-byte boundaries and the int32 sections on 4-byte ones (the
+    header is 8 bytes + 4 bytes per size field, so the number of size fields has to be even): the device reads them with
+    dwordx2 / dwordx4 loads and the CPU builds are sanitized for misaligned access."""
+    import struct
+    from mjrl_amd import blob, levels, mjcf
+    assert len(blob.SIZE_FIELDS) % 2 == 0
+    for level in ("two_agent.xml", "single_agent.xml", "sensor_touch.xml"):
+        packed = blob.pack(mjcf.compile_mjcf(levels.level_path(level)))
+        sizes = dict(zip(blob.SIZE_FIELDS, struct.unpack_from(f"<{len(blob.SIZE_FIELDS)}i", packed, 8)))
+        off = 8 + 4 * len(blob.SIZE_FIELDS)
+        assert off % 8 == 0
+        off += 8 * len(blob.OPT_FIELDS)
+        for name, expr in blob.F64_FIELDS:
+            assert off % 8 == 0, name
+            assert blob.section_range(packed, name)[0] == off
+            off += 8 * eval(expr, {}, sizes)
+        for name, expr in blob.I32_FIELDS:
+            assert off % 4 == 0, name
+            n = eval(expr, {}, sizes)
+            off += 4 * (n + (n % 2))
+        assert off == len(packed)
