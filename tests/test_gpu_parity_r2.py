@@ -640,3 +640,39 @@ def test_pinned_host_buffers_give_what_the_copying_host_path_gives():
         first = out[0] if first is None else first
         assert out[0] is first or np.shares_memory(out[0], first)      # the same pinned buffer every step
     assert trunc.any() and np.abs(obs).sum() > 0
+
+
+@pytest.mark.gpu
+def test_every_copy_is_stepped_exactly_once_for_odd_batch_sizes():
+    """The longest-first dispatch hands workgroup w the copy of the w-th set bit of the previous launch's work buckets
+    (bit rows of (n_env + 31) / 32 words, two words per lane and block of 128).  Batches that are not a multiple of 32 or
+    64, a single copy, and one with more than one block of words: after every launch every copy's step counter has moved
+    by exactly one (a copy skipped or stepped twice would show), the lost-workgroup counter stays zero, and copies at the
+    ends and in the middle follow the oracle."""
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    packed = blob.pack(model)
+    for n_env in (1, 33, 130, 5000):
+        h = _capi.Handle(packed, n_env)
+        h.reset()
+        rng = np.random.default_rng(n_env)
+        watch = sorted({0, n_env // 2, n_env - 1})
+        oras = {e: OracleEnv(packed) for e in watch}
+        z = rng.uniform(0.12, 0.9, n_env)                       # different heights: different work, so several buckets fill
+        q = np.tile(model.qpos0, (n_env, 1))
+        q[:, 2] = z
+        h.set_field("qpos", q)
+        for e, o in oras.items():
+            o.qpos[:] = q[e]
+        for t in range(6):
+            ctrl = rng.uniform(-1, 1, (n_env, model.nu))
+            h.set_field("ctrl", ctrl)
+            h.step_device(None, 0, 1)
+            assert np.array_equal(h.get_field("timestep"), np.full(n_env, t + 1)), (n_env, t)
+            for e, o in oras.items():
+                o.ctrl[:] = ctrl[e]
+                o.step()
+        assert h.cap_overflows() == (0, 0)                       # (raises if a workgroup found no copy)
+        got = h.get_field("qpos")
+        for e, o in oras.items():
+            assert np.allclose(got[e], o.qpos, rtol=0, atol=1e-10), (n_env, e)
+        h.close()
