@@ -19,7 +19,13 @@ namespace {
 // __restrict__ pointer every field is a scalar load at its point of use.
 __global__ __launch_bounds__(64) void mjrl_step_kernel(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
-  mj::env_step(*mp, a, lds);
+  mj::env_step_t<false>(*mp, *mj::kernarg_step_args(8), lds);      // (the arguments where the packet left them: mjrl_step.h)
+}
+// The same step with the diagnostics compiled in (stage clock, wave timeline, LDS dump, stage cuts): the launches of
+// mjrl_step_debug / _profile / _timeline / _truncated and the LDS read-back of mjrl_query.  Same arithmetic, same bits.
+__global__ __launch_bounds__(64) void mjrl_step_kernel_diag(const DevModel* __restrict__ mp, mj::StepArgs a) {
+  extern __shared__ double lds[];
+  mj::env_step_t<true>(*mp, *mj::kernarg_step_args(8), lds);
 }
 
 // Masked reset of the HBM state: mj_resetData + mj_forward (mujoco_parent.py:349-350) for the selected copies.  Every
@@ -212,6 +218,7 @@ struct mjrl_env {
   mj::Lay lay{};
   hipModule_t spec_module = nullptr;     // model-specialised step kernel, if one was attached (mjrl_load_kernel)
   hipFunction_t spec_fn = nullptr;
+  bool spec_diag = false;                // that code object was built with the diagnostics (-DMJRL_DIAG)
   void* d_blob = nullptr;
   DevModel* d_model = nullptr;     // device copy of `dm`
   int n_env = 0, device = 0;
@@ -398,6 +405,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     CK(hipMemset(e->lpt_mask[g], 0, sizeof(unsigned) * mj::LPT_BUCKETS * (size_t)e->lpt_words));
   }
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_camera_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 #undef CK
   // the reset image: reset every copy (zero warm start, as mj_resetData leaves it), run mj_forward once, keep copy 0's
@@ -873,10 +881,15 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
       e->lpt_cur = out;
       e->lpt_valid = true;
     }
-    if (e->spec_fn) {
+    // launches that use a diagnostic (LDS dump, stage clock, timeline, stage cut) need a build that has them
+    const bool diag = a.dbg || a.stamps || a.timeline || a.stop_after;
+    if (e->spec_fn && (!diag || e->spec_diag)) {
       const void* image = e->d_blob;        // the specialised kernel derives every section from the image base
       void* params[] = {(void*)&image, (void*)&a};
       MJRL_HIP(e, hipModuleLaunchKernel(e->spec_fn, e->n_env, 1, 1, 64, 1, 1, (unsigned)lds_bytes, e->stream, params, nullptr));
+    } else if (diag) {
+      hipLaunchKernelGGL(mjrl_step_kernel_diag, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
+      MJRL_HIP(e, hipGetLastError());
     } else {
       hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
       MJRL_HIP(e, hipGetLastError());
@@ -907,7 +920,7 @@ int mjrl_cap_overflows(mjrl_env* e, unsigned long long* h_counts, int clear) {
 int mjrl_load_kernel(mjrl_env* e, const char* path) {
   MJRL_ENTER(e);
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
-  if (e->spec_module) { hipModuleUnload(e->spec_module); e->spec_module = nullptr; e->spec_fn = nullptr; }
+  if (e->spec_module) { hipModuleUnload(e->spec_module); e->spec_module = nullptr; e->spec_fn = nullptr; e->spec_diag = false; }
   if (!path) return 0;                      // back to the generic kernel
   hipModule_t mod = nullptr;
   if (hipModuleLoad(&mod, path) != hipSuccess) MJRL_FAIL(e, 6, "load_kernel: cannot load code object %s", path);
@@ -933,6 +946,14 @@ int mjrl_load_kernel(mjrl_env* e, const char* path) {
   }
   e->spec_module = mod;
   e->spec_fn = fn;
+  // (a code object built with -DMJRL_DIAG says so; without the symbol it is a production build)
+  hipDeviceptr_t d_diag = nullptr;
+  size_t nd = 0;
+  int has_diag = 0;
+  if (hipModuleGetGlobal(&d_diag, &nd, mod, "mjrl_spec_diag") == hipSuccess && nd == sizeof(int))
+    if (hipMemcpy(&has_diag, d_diag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) has_diag = 0;
+  e->spec_diag = has_diag != 0;
+  (void)hipGetLastError();      // (a production build has no such symbol: the failed lookup must not linger as the last error)
   return 0;
 }
 

@@ -21,9 +21,20 @@ extern "C" __device__ const int mjrl_spec_sizes[MJRL_NSIZES] = {
 #define MJRL_SPEC_OCCUPANCY
 #endif
 
+// Production build: no diagnostics in the kernel (mj::env_step_t<false>).  -DMJRL_DIAG (MJRL_SPEC_FLAGS, the profiling
+// tools under tools/) builds the variant with the stage clock, the wave timeline, the LDS dump and -- with
+// -DMJRL_STAGE_CUT -- the stage cuts, and exports mjrl_spec_diag so that mjrl_load_kernel knows which one it holds.
+#ifdef MJRL_DIAG
+extern "C" __device__ const int mjrl_spec_diag = 1;
+#define MJRL_SPEC_DIAG true
+#else
+#define MJRL_SPEC_DIAG false
+#endif
+
 extern "C" __global__ __launch_bounds__(64) MJRL_SPEC_OCCUPANCY void mjrl_step_kernel_spec(const char* __restrict__ image, mj::StepArgs a) {
   extern __shared__ double lds[];
   DevModel m;
   mjrl_model_from_base(&m, (const char MJRL_GLOBAL*)image);
-  mj::env_step(m, a, lds);
+  // (`a` is read where the dispatch packet left it, field by field at its point of use: mj::kernarg_step_args)
+  mj::env_step_t<MJRL_SPEC_DIAG>(m, *mj::kernarg_step_args(8), lds);
 }

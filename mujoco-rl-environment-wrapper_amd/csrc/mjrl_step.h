@@ -1088,10 +1088,11 @@ __device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK
 // dump of the raw rows was requested) immediately projects it:  J <- J L^-1  by back substitution restricted to the
 // row's own dof chains, and AR_ii = sum_d B_id^2 / D_d + R_i.  A row only touches the dof chains of its (at most
 // two) bodies; the chains are read from the LDS structure tables.
+template <bool DIAG>
 __device__ inline void stage_rows(const DevModel& m, const Lay& l, const ActK& A, real* S, int L, bool project,
                                   Stamps* stamps) {
 #define MJ_SUBSTAMP(k)                                                     \
-  if (stamps) {                                                            \
+  if constexpr (DIAG) if (stamps) {                                        \
     unsigned long long t_now = wv::clock();                                \
     if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
     stamps->prev = t_now;                                                  \
@@ -1379,22 +1380,29 @@ __device__ __forceinline__ real wide_bcast(real v) {
   if constexpr (K < 16) return wv::half_to_all<false>(wv::bcast16<K>(v));
   else return wv::half_to_all<true>(wv::bcast16<K - 16>(v));
 }
+// (Inlined.  As a function of its own it cost the kernel a stack frame: its callee-saved registers and, while its
+// arguments were a struct, the struct -- the only scratch memory of the step kernel.  Early in round 1 the inlined form
+// drove the register allocation to 512 VGPRs; with the kernel as it is now it fits the 256 of two waves per SIMD.)
+#ifndef MJRL_WIDE_INLINE
+#define MJRL_WIDE_INLINE inline __attribute__((always_inline))
+#endif
 #define MJ_ROWS32(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
                      X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 // (A real function, not inlined: inlined into the step kernel its 32 unrolled row steps drove the kernel's register
 // allocation to 512 VGPRs plus scratch.  It takes plain values only -- a reference to the model or the layout would
 // force those structs into memory.)
-struct WideArgs {
-  int o_rowid, o_row, o_J, o_Dinv;      // LDS offsets (Lay)
-  int iterations, adr0, tn;             // sweep cap; first dof and dof count of the lane's tree
-  real tolerance, scale;
-};
-__device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int* I, int L, int cnt_w, int base_w, int tmax,
-                                                             bool dof, WideArgs w, int* iter_io) {
-  struct { int i_rowid, row, J, Dinv; } l = {w.o_rowid, w.o_row, w.o_J, w.o_Dinv};
-  struct { int iterations; real tolerance; } m = {w.iterations, w.tolerance};
-  const real scale = w.scale;
-  int iter = wv::first_int(*iter_io);
+// (plain scalars, each in a register of its own: a struct by value travels through the stack -- scratch memory)
+// (the sweep count goes in and comes back by value: a pointer to the caller's counter pinned that counter -- which every
+// solver path increments once per sweep -- to scratch memory)
+struct WideOut { real u; int iter; };
+__device__ MJRL_WIDE_INLINE WideOut pgs_wide_registers(real* S, const int* I, int L, int cnt_w, int base_w, int tmax,
+                                                        bool dof, int o_rowid, int o_row, int o_J, int o_Dinv, int iterations,
+                                                        int adr0_in, real tolerance, real scale_in, int iter_in) {
+  // o_*: LDS offsets (Lay); iterations: sweep cap; adr0_in: first dof of the lane's tree
+  struct { int i_rowid, row, J, Dinv; } l = {o_rowid, o_row, o_J, o_Dinv};
+  struct { int iterations; real tolerance; } m = {iterations, tolerance};
+  const real scale = scale_in;
+  int iter = wv::first_int(iter_in);
   tmax = wv::first_int(tmax);              // (arguments arrive in vector registers; these two are wave-uniform)
   m.iterations = wv::first_int(m.iterations);
   const int tree = (L >> 4) & 1;
@@ -1406,7 +1414,7 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
   real fi = has_row ? Rm[ROW_F] : 0.0, bi = has_row ? Rm[ROW_B] : 0.0, Ri = has_row ? Rm[ROW_R] : 0.0;
   const real aii = has_row ? Rm[ROW_ARII] : 1.0;
   const real ainv = 1.0 / aii;
-  const int adr0 = w.adr0;
+  const int adr0 = adr0_in;
   real W[16], A[32];
 #pragma unroll
   for (int d = 0; d < 16; d++)
@@ -1494,12 +1502,13 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
   if (pending && wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
   while (guarded && iter < m.iterations) {
     real imp = 0;
+    const int kme_g = wv::opaque_lane(kme);     // (per sweep, as above: 32 hoisted lane masks do not fit the scalar registers)
 #define MJ_GSTEP(KK)                                                                  \
     if (KK < tmax) {                                                                  \
       real fn = fmax(fi - sr, 0.0);                                                   \
       real delta = fn - fi;                                                           \
       real change = delta * delta * haii + delta * (sr * aii);                        \
-      bool act = kme == KK && has_row && !(change > 1e-10);                           \
+      bool act = kme_g == KK && has_row && !(change > 1e-10);                         \
       if (!act) { delta = 0; change = 0; fn = fi; }                                   \
       fi = fn;                                                                        \
       imp -= change;                                                                  \
@@ -1521,8 +1530,9 @@ __device__ __attribute__((noinline)) real pgs_wide_registers(real* S, const int*
     }
   do { MJ_ROWS32(MJ_USTEP) } while (0);
 #undef MJ_USTEP
-  *iter_io = iter;
-  return u;
+  WideOut out;
+  out.u = u; out.iter = iter;
+  return out;
 }
 #undef MJ_ROWS32
 
@@ -1538,10 +1548,12 @@ __device__ inline bool pgs_coupled_schedule(const DevModel& m, const Lay& l, rea
   const int C = m.njmax / m.ntree, n = wv::first_int(nefc);
   for (int k = L; k < m.ntree * C; k += 64) I[l.i_rowid + k] = -1;
   wv::sync();
-  int n0 = 0, n1 = 0, n2 = 0, n3 = 0;        // entries used in each tree's list (wave-uniform)
+  // entries used in each tree's list (wave-uniform), 16 bits per tree in one scalar: four counters selected by a
+  // run-time tree index became an indexed array in scratch memory
+  unsigned long long packed = 0ull;
   bool fits = true;
-  auto used = [&](int t) { return t == 0 ? n0 : (t == 1 ? n1 : (t == 2 ? n2 : n3)); };
-  auto set_used = [&](int t, int v) { if (t == 0) n0 = v; else if (t == 1) n1 = v; else if (t == 2) n2 = v; else n3 = v; };
+  auto used = [&](int t) { return (int)((packed >> (16 * t)) & 0xFFFFull); };
+  auto set_used = [&](int t, int v) { packed = (packed & ~(0xFFFFull << (16 * t))) | ((unsigned long long)(v & 0xFFFF) << (16 * t)); };
   for (int i = 0; i < n; i++) {
     const int info = wv::first_int(I[l.i_rowinfo + i]);
     const int rt = (info >> CHAIN_BITS) - 2;
@@ -1557,6 +1569,7 @@ __device__ inline bool pgs_coupled_schedule(const DevModel& m, const Lay& l, rea
       set_used(t2, p + 1);
     }
   }
+  const int n0 = used(0), n1 = used(1), n2 = used(2), n3 = used(3);
   len = n0 > n1 ? n0 : n1;
   len = n2 > len ? n2 : len;
   len = n3 > len ? n3 : len;
@@ -1588,14 +1601,14 @@ struct SchedArgs {
   real tolerance, scale, dinv, u;
 };
 template <int NP>       // 16: one position per lane; 32: two (more than 256 registers: for images that hold a CU to 4 copies anyway)
-__device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool dof, SchedArgs w, int* iter_io) {
+__device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool dof, SchedArgs w, int& iter_io) {
   const int k = L & 15, mytree = L >> 4;
   // (the sweep length is wave-uniform -- lane 0's, tree 0 always exists --; the rows of 16 lanes of a tree the model does
   // not have come in with length 0 and hold no list: treated as a tree they would walk tree 0's list on their own,
   // write their forces over the real ones and add to the sweep's improvement)
   const bool mine = w.len > 0;
   const int len = wv::first_int(w.len), iterations = wv::first_int(w.iterations);
-  int iter = wv::first_int(*iter_io);
+  int iter = wv::first_int(iter_io);
   const unsigned char* t8 = (const unsigned char*)(S + w.o_tab);
   auto dof_tree = [&](int d) { return w.tab_bytes ? (int)t8[w.tab_dtree + d] : (int)((const unsigned short*)t8)[w.tab_dtree + d]; };
   auto entry = [&](int p) { return (mine && p < len) ? I[w.o_rowid + w.base + p] : -1; };
@@ -1690,7 +1703,7 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
   }
   if (o0.has) S[w.o_row + ROW_STRIDE * o0.row + ROW_F] = o0.f;
   if (o1.has) S[w.o_row + ROW_STRIDE * o1.row + ROW_F] = o1.f;
-  *iter_io = iter;
+  iter_io = iter;
   return u;
 }
 
@@ -1707,10 +1720,11 @@ __device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
 // multiply-add.  In the tree-row lane map a constraint row that touches one kinematic tree only involves that tree's
 // row of 16 lanes, so the trees sweep their own rows side by side (rows of different trees commute, the order inside
 // a tree is the solver's row order); a step with a row that couples two trees falls back to the serial sweep.
+template <bool DIAG>
 __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L,
                                  Stamps* stamps) {
 #define MJ_SUBSTAMP(k)                                                     \
-  if (stamps) {                                                            \
+  if constexpr (DIAG) if (stamps) {                                        \
     unsigned long long t_now = wv::clock();                                \
     if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
     stamps->prev = t_now;                                                  \
@@ -1784,12 +1798,10 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   int iter = 0;
   if (wide) {
     const int wtree = (L >> 4) & 1;
-    WideArgs w;
-    w.o_rowid = l.i_rowid; w.o_row = l.row; w.o_J = l.J; w.o_Dinv = l.Dinv;
-    w.iterations = m.iterations; w.tolerance = m.tolerance; w.scale = scale;
-    w.adr0 = wtree < m.ntree ? m.tree_dofadr[wtree] : 0;
-    w.tn = wtree < m.ntree ? m.tree_dofnum[wtree] : 0;
-    u = pgs_wide_registers(S, I, L, cnt_w, base_w, tmax, dof, w, &iter);
+    const int wadr0 = wtree < m.ntree ? m.tree_dofadr[wtree] : 0;
+    const WideOut wo = pgs_wide_registers(S, I, L, cnt_w, base_w, tmax, dof, l.i_rowid, l.row, l.J, l.Dinv, m.iterations, wadr0,
+                                          m.tolerance, scale, iter);
+    u = wo.u; iter = wv::first_int(wo.iter);
     wv::sync();
   } else if (in_registers) {
     // Residual form, all in registers: with at most 16 rows per tree, lane k of a tree's 16 lanes owns the tree's
@@ -1933,12 +1945,13 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     }
     while (guarded && iter < m.iterations) {
       real imp = 0;
+      const int kme_g = wv::opaque_lane(kme);
 #define MJ_GSTEP(KK)                                                                  \
       if (KK < tmax) {                                                                \
         real fn = fmax(fi - sr, 0.0);                                                 \
         real delta = fn - fi;                                                         \
         real change = delta * delta * haii + delta * (sr * aii);                      \
-        bool act = kme == KK && has_row && !(change > 1e-10);                         \
+        bool act = kme_g == KK && has_row && !(change > 1e-10);                       \
         if (!act) { delta = 0; change = 0; fn = fi; }                                 \
         fi = fn;                                                                      \
         imp -= change;                                                                \
@@ -1991,7 +2004,9 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       w.tab_dtree = T.dtree; w.tab_bytes = T.bytes ? 1 : 0;
       w.depth = RK.depth; w.below = RK.below;
       w.tolerance = m.tolerance; w.scale = scale; w.dinv = dinv; w.u = u;
-      u = sched_len <= 16 ? pgs_schedule_registers<16>(S, I, L, dof, w, &iter) : pgs_schedule_registers<32>(S, I, L, dof, w, &iter);
+      int it = iter;        // (a local of its own: the counter of the other solver paths never has its address taken)
+      u = sched_len <= 16 ? pgs_schedule_registers<16>(S, I, L, dof, w, it) : pgs_schedule_registers<32>(S, I, L, dof, w, it);
+      iter = it;
       wv::sync();
     } else {
     struct Rec { int i, info; bool has; real bid, fi, Ri, bi, aii, ainv; };
@@ -2417,16 +2432,23 @@ __device__ inline int lpt_copy_of(const StepArgs& a, int L, int wg, int my_count
 }
 
 // ------------------------------------------------------------------ one env copy, one step() call
-__device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
+// DIAG = false is the production build: the stage clock, the wave timeline, the LDS dump and the stage cuts (StepArgs::
+// stamps / timeline / dbg / stop_after) do not exist in it -- as run-time branches they cost the shipped kernel a stack
+// object (the clock), a hundred scalar registers' worth of spills and an exec-masked block per stage.  Launches that ask
+// for any of them go to the DIAG = true build (mjrl_step_kernel_diag; a specialised kernel built with -DMJRL_DIAG).
+template <bool DIAG>
+__device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real* S) {
+  const StepArgs& a = a_in;
   const int L = wv::lane();
   int env = wv::env_index();
-  const unsigned long long t_begin = a.timeline ? wv::realtime() : 0ull;
+  unsigned long long t_begin = 0ull;
+  if constexpr (DIAG) t_begin = a.timeline ? wv::realtime() : 0ull;
   // The prologue is a chain of dependent round trips to L2 / HBM (bucket counts -> the copy's id -> the copy's rows),
   // and nothing else of the wave can start before it ends.  So every load that does not need the copy's id is issued
   // before the id is known, and every load that needs it is issued before the first of them is waited for: three round
   // trips in all (they were eleven when each block of state was fetched and stored in turn).
 #ifndef MJRL_STAGE_CUT
-  if (a.stop_after) return;          // (a truncated launch on a kernel without the cuts must not run a whole step)
+  if constexpr (DIAG) if (a.stop_after) return;     // (a truncated launch on a kernel without the cuts must not run a whole step)
 #endif
   int my_count = 0;
   if (a.lpt_count_in) my_count = a.lpt_count_in[L & (LPT_BUCKETS - 1)];
@@ -2454,18 +2476,22 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // diagnostic stage clock: lane k accumulates the cycles of stage k in a register and adds them to the batch totals
   // when the wave is done -- nothing of the measurement touches memory while a stage is being timed
   Stamps clock_state;
-  clock_state.prev = a.stamps ? wv::clock() : 0ull;
+  clock_state.prev = 0ull;
   clock_state.mine = 0;
-  Stamps* const stamps = a.stamps ? &clock_state : nullptr;
+  Stamps* stamps = nullptr;
+  if constexpr (DIAG) {
+    clock_state.prev = a.stamps ? wv::clock() : 0ull;
+    stamps = a.stamps ? &clock_state : nullptr;
+  }
   // (the stage cuts of mjrl_step_truncated exist in diagnostic builds only, -DMJRL_STAGE_CUT through MJRL_SPEC_FLAGS:
   // an exit after every stage costs the 4-agent kernel 1.4 KB of scratch per lane)
 #ifdef MJRL_STAGE_CUT
-#define MJ_CUT(k) if (a.stop_after == (k) + 1) return;
+#define MJ_CUT(k) if constexpr (DIAG) if (a.stop_after == (k) + 1) return;
 #else
 #define MJ_CUT(k)
 #endif
 #define MJ_STAMP(k)                                                        \
-  if (stamps) {                                                            \
+  if constexpr (DIAG) if (stamps) {                                        \
     unsigned long long t_now = wv::clock();                                \
     if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
     stamps->prev = t_now;                                                  \
@@ -2546,45 +2572,54 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
   // spill space against 218 without the loop).  Between launches the state round-trips through HBM, 2.5 KB per copy.
   EulerK EK;
   EK.gcode[0] = EK.gcode[1] = -3;          // (-3: not fetched -- a launch without a physics frame reads the table below)
+  // Every stage gets the lane id as a value the optimiser has not seen before (MJ_L: no instruction).  The lane masks
+  // a stage derives from it (L < nv, L < nbody, L == 0 ...) are then formed where the stage uses them -- one compare --
+  // instead of once at the top of the kernel for all stages: kept that long they do not fit the scalar registers, and
+  // every use fetched its mask back from a spilled register with two v_readlane.
+#define MJ_L wv::opaque_lane(L)
   if (a.skip_frames) {
-    stage_kinematics(m, l, K, KK, S, L);
+    stage_kinematics(m, l, K, KK, S, MJ_L);
     MJ_STAMP(ST_KIN)
-    stage_com_inertia(m, l, K, KK, CK, S, L);
+    stage_com_inertia(m, l, K, KK, CK, S, MJ_L);
     MJ_STAMP(ST_COM)
     // (model constants of a stage are fetched a stage or two ahead of it: with two waves on a SIMD nothing else hides a
     // round trip to L2 at the head of a stage)
     GeomK GK;
-    load_geom_constants(m, L, GK);
+    load_geom_constants(m, MJ_L, GK);
     FactorRing ring;
-    factor_prefetch(m, L, ring);
-    stage_crb(m, l, K, S, L, a.inertia + (size_t)env * m.nM);
+    factor_prefetch(m, MJ_L, ring);
+    stage_crb(m, l, K, S, MJ_L, a.inertia + (size_t)env * m.nM);
     MJ_STAMP(ST_CRB)
-    factor_ld(m, S, l.LD, l.Dinv, L, ring);
+    factor_ld(m, S, l.LD, l.Dinv, MJ_L, ring);
     MJ_STAMP(ST_FACTOR)
-    stage_geoms(m, l, GK, S, L);
+    stage_geoms(m, l, GK, S, MJ_L);
     MJ_STAMP(ST_GEOM)
     ActK AK;
-    load_act_constants(m, L, K, AK);
-    stage_collision(m, l, GK, S, L);
+    load_act_constants(m, MJ_L, K, AK);
+    stage_collision(m, l, GK, S, MJ_L);
     MJ_STAMP(ST_COLLIDE)
-    stage_velocity(m, l, K, S, L, false);
+    stage_velocity(m, l, K, S, MJ_L, false);
     MJ_STAMP(ST_VEL)
-    stage_smooth(m, l, K, RK, AK, S, L);
+    RK.dof = wv::opaque_lane(RK.dof);      // (the same for the mask "this lane holds a dof" of the tree-row lane map)
+    stage_smooth(m, l, K, RK, AK, S, MJ_L);
     MJ_STAMP(ST_SMOOTH)
     // (a raw-row debug dump keeps J unprojected; such a launch is for inspection only)
-    stage_rows(m, l, AK, S, L, !(a.dbg && a.dbg_stage == 1), stamps);
+    bool raw_rows = false;
+    if constexpr (DIAG) raw_rows = a.dbg && a.dbg_stage == 1;
+    stage_rows<DIAG>(m, l, AK, S, MJ_L, !raw_rows, stamps);
     MJ_STAMP(ST_ROWS)
-    if (a.dbg && a.dbg_stage == 1)
-      MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
-    stage_pgs(m, l, K, RK, S, L, stamps);
+    if constexpr (DIAG)
+      if (raw_rows) MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
+    RK.dof = wv::opaque_lane(RK.dof);
+    stage_pgs<DIAG>(m, l, K, RK, S, MJ_L, stamps);
     MJ_STAMP(ST_PGS)
     const bool integrate = !a.forward_only && m.integrator == 0;
-    load_euler_constants(m, a, K, L, a.inertia + (size_t)env * m.nM, integrate, EK);
+    load_euler_constants(m, a, K, MJ_L, a.inertia + (size_t)env * m.nM, integrate, EK);
     // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)
-    if (m.integrator == 0 || a.rk_stage == 0) stage_sensors(m, l, K, S, L);
+    if (m.integrator == 0 || a.rk_stage == 0) stage_sensors(m, l, K, S, MJ_L);
     MJ_STAMP(ST_SENSORS)
-    if (a.dbg && a.dbg_stage == 0)
-      MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
+    if constexpr (DIAG)
+      if (a.dbg && a.dbg_stage == 0) MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     if (a.frames) {
       real* F = a.frames + (size_t)env * frame_doubles(m);
       const int* I = (const int*)(S + l.ints);
@@ -2604,8 +2639,9 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
       }
     }
     if (!a.forward_only) {
-      if (m.integrator == 0) stage_euler(m, l, K, RK, EK, S, L);
-      else stage_rk4(m, l, S, L, a.rk_stage, a.rk + (size_t)env * (m.nq + 3 * m.nv));
+      RK.dof = wv::opaque_lane(RK.dof);
+      if (m.integrator == 0) stage_euler(m, l, K, RK, EK, S, MJ_L);
+      else stage_rk4(m, l, S, MJ_L, a.rk_stage, a.rk + (size_t)env * (m.nq + 3 * m.nv));
     }
     if (ops_staged) {
       int* TI = (int*)(S + l.bias);
@@ -2619,6 +2655,14 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     MJ_STAMP(ST_EULER)
   }
   // state out
+  // The end of the step reads its arguments and the copy's id afresh (wv::fresh: the same values, their origin hidden
+  // from the optimiser).  Otherwise every row address the prologue formed -- base pointer + copy x stride, a dozen
+  // 64-bit scalars -- is kept for the stores down here, a whole step later, and waits for them in spilled registers.
+  const int env_done = env, L_all = L;
+  {
+  const StepArgs& a = *wv::fresh(&a_in);
+  const int env = wv::opaque_uniform(env_done);
+  const int L = wv::opaque_lane(L_all);
   if (!a.forward_only) {
     MJ_FOR(i, m.nq) a.qpos[(size_t)env * m.nq + i] = S[l.qpos + i];
     MJ_FOR(i, m.nv) a.qvel[(size_t)env * m.nv + i] = S[l.qvel + i];
@@ -2671,13 +2715,13 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     wv::atomic_or_noret(a.lpt_mask_out + (size_t)wb * a.lpt_words + (env >> 5), 1u << (env & 31));          \
   }
 #define MJ_TIMELINE                                                                        \
-  if (a.timeline && L == 0) {                                                              \
+  if constexpr (DIAG) if (a.timeline && L == 0) {                                          \
     unsigned long long* tl = a.timeline + 3 * (size_t)wv::env_index();                     \
     tl[0] = t_begin; tl[1] = wv::realtime(); tl[2] = (unsigned long long)env;              \
   }
   if (a.forward_only || a.more_frames) {
     MJ_STAMP(ST_TAIL)
-    if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+    if constexpr (DIAG) if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
     MJ_FILE_WORK
     MJ_TIMELINE
     return;
@@ -2897,15 +2941,34 @@ __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) {
     a.variant[env] = pick_of(mix64(a.variant_seed, (unsigned long long)(a.env_base + env), 0ull, (unsigned long long)ep, 2), a.n_variant);
   }
   MJ_STAMP(ST_TAIL)
-  if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+  if constexpr (DIAG) if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
   MJ_FILE_WORK
   MJ_TIMELINE
+  }
 #undef MJ_TIMELINE
 #undef MJ_FILE_WORK
 #undef MJ_STAMP
 #undef MJ_CUT
 #undef MJ_FOR
+#undef MJ_L
 }
+
+#if defined(__HIPCC__)
+// The step arguments where the dispatch packet left them.  A kernel that names its by-value StepArgs parameter gets every
+// field it uses loaded into scalar registers in its entry block (that is how kernel arguments are lowered) -- some forty
+// pointers and twenty sizes, the whole scalar register file, live from the first instruction to wherever each is used
+// and spilled to vector-register lanes in between (v_writelane / v_readlane: vector-issue slots in a kernel bound by
+// vector issue).  Read through the kernarg segment pointer instead, a field is a scalar load from constant memory where
+// it is used.  `offset`: byte offset of the StepArgs parameter in the kernel's argument list.
+__device__ __forceinline__ const StepArgs* kernarg_step_args(int offset) {
+  const char __attribute__((address_space(4)))* base =
+      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  return (const StepArgs*)(const StepArgs __attribute__((address_space(4)))*)(base + offset);
+}
+#endif
+
+// the diagnostic build under its historical name (the CPU emulation under tests/emu steps copies through this one)
+__device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) { env_step_t<true>(m, a, S); }
 
 }  // namespace mj
 

@@ -124,6 +124,15 @@ __device__ __forceinline__ double first(double v) {
 // each, too many for the scalar registers, and come back through v_readlane at every use.
 __device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
+// The same (wave-uniform) pointer as a value the optimiser has not seen before: what is loaded through it is not merged
+// with earlier loads through the original, so nothing fetched early stays live in registers until here.
+template <typename T>
+__device__ __forceinline__ const T* fresh(const T* p) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return (const T*)(((unsigned long long)hi << 32) | lo);
+}
 
 // issue priority of this wave among the waves of its SIMD (0 lowest .. 3 highest); p is wave-uniform
 __device__ __forceinline__ void set_priority(int p) {

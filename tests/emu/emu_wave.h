@@ -61,6 +61,8 @@ inline double sum_n(double v, int width) {   // all-reduce over aligned groups o
 inline double sum(double v) { return sum_n(v, 64); }
 inline int opaque_lane(int v) { return v; }
 inline int opaque_uniform(int v) { return v; }
+template <typename T>
+inline const T* fresh(const T* p) { return p; }
 inline void set_priority(int) {}
 inline int first_int(int v) { return shfl(v, 0); }
 inline double first(double v) { return shfl(v, 0); }   // lane 0's value in every lane
