@@ -195,7 +195,10 @@ int mjrl_step_profile(mjrl_env* env, const double* d_actions, int act_dim, int s
  * the stage order of mjrl_step_profile; 1..15 are the stages of the step proper) and nothing is written back: the copies'
  * state is untouched.  Hardware counters (rocprofv3 --pmc) of launches cut at successive stages give each stage's
  * instruction mix by difference (tools/stage_mix.py).  The cuts exist only in a specialised kernel built with
- * -DMJRL_STAGE_CUT (MJRL_SPEC_FLAGS); any other kernel leaves such a launch at once. */
+ * -DMJRL_DIAG -DMJRL_STAGE_CUT (MJRL_SPEC_FLAGS); any other kernel leaves such a launch at once.  (Round 3: the production
+ * kernels carry no diagnostics at all; mjrl_step_debug / _profile / _timeline / _truncated and the LDS read-back of
+ * mjrl_query launch the diagnostic build -- mjrl_step_kernel_diag of the library, or a specialised kernel built with
+ * -DMJRL_DIAG.  Same source, same arithmetic, same bits.) */
 int mjrl_step_truncated(mjrl_env* env, int stop_after);
 
 /* Diagnostic: one step whose waves record when they ran.  h_out[3*w + 0..2] = start and end of workgroup w's wave on

@@ -40,10 +40,14 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
                                   int env_base) {
   int env = blockIdx.x;
   if (env >= n_env || (mask && !mask[env])) return;
-  if (variant && threadIdx.x == 0) {         // a new episode: a new level variant (random.choice, mujoco_parent.py:352)
+  // A new episode.  The episode count of a copy always moves (it is part of the key of every on-device random choice,
+  // so that episodes differ from one another the way the reference's random.randint draws do); with level variants on,
+  // the copy also gets a new variant (random.choice, mujoco_parent.py:352).
+  if (episode && threadIdx.x == 0) {
     const int ep = episode[env] + 1;
     episode[env] = ep;
-    variant[env] = mj::pick_of(mj::mix64(variant_seed, (unsigned long long)(env_base + env), 0ull, (unsigned long long)ep, 2), n_variant);
+    if (variant)
+      variant[env] = mj::pick_of(mj::mix64(variant_seed, (unsigned long long)(env_base + env), 0ull, (unsigned long long)ep, 2), n_variant);
   }
   // an empty data store (mujoco_rl.py:312): every slot "absent"
   for (int i = threadIdx.x; i < store_per_env; i += blockDim.x) store[(size_t)env * store_per_env + i] = __longlong_as_double(0x7FF8000000000000ll);
@@ -279,7 +283,7 @@ struct mjrl_env {
   // pinned host buffers mapped into the device's address space (mjrl_host_buffers / mjrl_step_pinned)
   double *p_act = nullptr, *p_obs = nullptr, *p_rew = nullptr;
   unsigned char *p_term = nullptr, *p_trunc = nullptr;
-  size_t p_act_n = 0, p_obs_n = 0;
+  size_t p_act_n = 0, p_obs_n = 0, p_na = 0;     // elements allocated: actions, observations, rewards / flags
   std::string err;
 };
 
@@ -395,6 +399,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMemset(e->overflow, 0, sizeof(unsigned long long) * 3));
   CK(hipMalloc(&e->sens, sizeof(double) * n_env * (m.nsensordata > 0 ? m.nsensordata : 1)));
   CK(hipMalloc(&e->timestep, sizeof(int) * n_env));
+  CK(hipMalloc(&e->episode, sizeof(int) * n_env));          // resets so far, per copy (kept whether or not variants are on)
+  CK(hipMemset(e->episode, 0, sizeof(int) * n_env));
   CK(hipMalloc(&e->d_mask, n_env));
   e->lpt_enabled = !(flags & 1u);
   e->lpt_words = (n_env + 31) / 32;
@@ -420,6 +426,7 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     he = hipMemcpyAsync(s0, e->sens, sizeof(double) * m.nsensordata, hipMemcpyDeviceToDevice, e->stream);
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
   e->reset_warm = w0; e->reset_sens = s0;
+  if (he == hipSuccess) he = hipMemset(e->episode, 0, sizeof(int) * n_env);     // (the reset above was not an episode's)
   if (he != hipSuccess) return fail(6, std::string("reset image: ") + hipGetErrorString(he));
   *out = e;
   return 0;
@@ -452,8 +459,11 @@ static int upload_gather(mjrl_env* e) {
   std::vector<int32_t> table((size_t)e->n_agent * dim, -1);
   for (int a = 0; a < e->n_agent; a++) {
     for (int k = 0; k < e->base_obs_dim; k++) table[(size_t)a * dim + k] = e->h_gather[(size_t)a * e->base_obs_dim + k];
-    // slots the step kernel's gather leaves alone: the fused program's, then the camera latents (written by the encoder)
-    for (int k = 0; k < e->n_extra + e->n_cam_obs; k++) table[(size_t)a * dim + e->h_obs_len[a] + k] = -2;
+    // slots the step kernel's gather leaves alone: the fused program's, then the camera latents (written by the encoder).
+    // An agent without a camera has no image and nobody writes its latent slots: they stay -1, which the gather writes
+    // as 0 every step (include/mjrl.h: "slots of an agent without a camera read 0").
+    const bool has_cam = a < (int)e->h_agent_cam.size() && e->h_agent_cam[a] >= 0;
+    for (int k = 0; k < e->n_extra + (has_cam ? e->n_cam_obs : 0); k++) table[(size_t)a * dim + e->h_obs_len[a] + k] = -2;
   }
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   if (e->d_gather) { hipFree(e->d_gather); e->d_gather = nullptr; }
@@ -621,17 +631,16 @@ int mjrl_set_env_base(mjrl_env* e, int first_env_id) {
 int mjrl_set_variants(mjrl_env* e, int n_variant, const double* rgba, unsigned long long seed) {
   MJRL_ENTER(e);
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
-  for (void** p : {(void**)&e->variant, (void**)&e->episode, (void**)&e->variant_rgba})
+  for (void** p : {(void**)&e->variant, (void**)&e->variant_rgba})
     if (*p) { hipFree(*p); *p = nullptr; }
   e->n_variant = 0;
   if (n_variant <= 0) return 0;
   if (!rgba) MJRL_FAIL(e, 1, "set_variants: no colour table");
   const size_t n = (size_t)n_variant * 4 * e->hm.ngeom;
   MJRL_HIP(e, hipMalloc(&e->variant, sizeof(int) * e->n_env));
-  MJRL_HIP(e, hipMalloc(&e->episode, sizeof(int) * e->n_env));
   MJRL_HIP(e, hipMalloc(&e->variant_rgba, sizeof(double) * std::max<size_t>(n, 1)));
   MJRL_HIP(e, hipMemset(e->variant, 0, sizeof(int) * e->n_env));
-  MJRL_HIP(e, hipMemset(e->episode, 0, sizeof(int) * e->n_env));
+  MJRL_HIP(e, hipMemset(e->episode, 0, sizeof(int) * e->n_env));     // (variants are drawn from episode 1 on)
   MJRL_HIP(e, hipMemcpy(e->variant_rgba, rgba, sizeof(double) * n, hipMemcpyHostToDevice));
   e->n_variant = n_variant;
   e->variant_seed = seed;
@@ -1026,11 +1035,26 @@ int mjrl_host_buffers(mjrl_env* e, int act_dim, double** h_actions, double** h_o
     memset(e->p_obs, 0, sizeof(double) * obs_n);
     e->p_obs_n = obs_n;
   }
-  if (!e->p_rew) {
-    MJRL_HIP(e, hipHostMalloc((void**)&e->p_rew, sizeof(double) * na, hipHostMallocMapped));
-    MJRL_HIP(e, hipHostMalloc((void**)&e->p_term, na, hipHostMallocMapped));
-    MJRL_HIP(e, hipHostMalloc((void**)&e->p_trunc, na, hipHostMallocMapped));
-    memset(e->p_rew, 0, sizeof(double) * na); memset(e->p_term, 0, na); memset(e->p_trunc, 0, na);
+  // rewards and flags: one element per (copy, agent).  Re-sized when the agent count grew since the last call (a first
+  // call before the gather / scatter tables exist sees n_agent = 0), and handed out only when all three exist: the
+  // kernel writes n_env x n_agent elements through these pointers into host memory.
+  if (na > e->p_na) {
+    void* old3[] = {e->p_rew, e->p_term, e->p_trunc};
+    for (void* q : old3) if (q) hipHostFree(q);
+    e->p_rew = nullptr; e->p_term = nullptr; e->p_trunc = nullptr; e->p_na = 0;
+    double* rew = nullptr;
+    unsigned char *term = nullptr, *trunc = nullptr;
+    hipError_t he = hipHostMalloc((void**)&rew, sizeof(double) * na, hipHostMallocMapped);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&term, na, hipHostMallocMapped);
+    if (he == hipSuccess) he = hipHostMalloc((void**)&trunc, na, hipHostMallocMapped);
+    if (he != hipSuccess) {
+      if (rew) hipHostFree(rew);
+      if (term) hipHostFree(term);
+      if (trunc) hipHostFree(trunc);
+      MJRL_FAIL(e, 100 + (int)he, "host_buffers: hipHostMalloc of the reward / flag buffers failed: %s", hipGetErrorString(he));
+    }
+    memset(rew, 0, sizeof(double) * na); memset(term, 0, na); memset(trunc, 0, na);
+    e->p_rew = rew; e->p_term = term; e->p_trunc = trunc; e->p_na = na;
   }
   if (h_actions) *h_actions = e->p_act;
   if (h_obs) *h_obs = e->p_obs;
@@ -1043,7 +1067,8 @@ int mjrl_host_buffers(mjrl_env* e, int act_dim, double** h_actions, double** h_o
 int mjrl_step_pinned(mjrl_env* e, int act_dim, int skip_frames) {
   MJRL_ENTER(e);
   const size_t na = (size_t)e->n_env * std::max(e->n_agent, 1);
-  if (!e->p_rew || na * std::max(act_dim, 1) > e->p_act_n || na * std::max(e->obs_dim, 1) > e->p_obs_n)
+  if (!e->p_rew || !e->p_term || !e->p_trunc || na > e->p_na || na * std::max(act_dim, 1) > e->p_act_n ||
+      na * std::max(e->obs_dim, 1) > e->p_obs_n)
     MJRL_FAIL(e, 4, "step_pinned: call mjrl_host_buffers with this act_dim (and after the gather tables are set) first");
   void *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_term = nullptr, *d_trunc = nullptr;
   MJRL_HIP(e, hipHostGetDevicePointer(&d_act, e->p_act, 0));

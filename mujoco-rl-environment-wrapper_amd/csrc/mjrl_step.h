@@ -175,7 +175,7 @@ struct StepArgs {
   // Per-copy level variant (an xmlPath list whose levels differ in colours only, Testing/levels/Model2-10.xml): chosen at
   // every reset like the reference's random.choice (mujoco_parent.py:352), keyed on (seed, global copy id, episode)
   int* variant;                // [n_env], may be null
-  int* episode;                // [n_env] resets so far
+  int* episode;                // [n_env] resets so far (always kept: part of the key of every on-device random choice)
   int n_variant;
   unsigned long long variant_seed;
   // Optional copy of the forward pass's frames for host-side plugin queries (data.body().xipos, data.contact ...,
@@ -229,8 +229,9 @@ enum {
 };
 
 // The counter-based generator behind every on-device random choice (splitmix64 finaliser over a linear key): a pure
-// function of (seed, global copy id, agent, episode step, salt), so the host plugin of the same name (dynamics.py) and
-// any shard of the batch draw the same numbers.
+// function of (seed, global copy id, agent, episode << 32 | episode step, salt), so the host plugin of the same name
+// (dynamics.py) and any shard of the batch draw the same numbers -- and a copy's episodes differ from one another (the
+// reference draws with random.randint, Testing/EnvironmentDynamic.py:26-29, Pick_Up_Dynamic.py:28,38).
 __host__ __device__ inline unsigned long long mix64(unsigned long long seed, unsigned long long env, unsigned long long agent,
                                                     unsigned long long step, unsigned long long salt) {
   unsigned long long z = seed * 0x9E3779B97F4A7C15ull + env * 0xBF58476D1CE4E5B9ull + agent * 0x94D049BB133111EBull +
@@ -2464,6 +2465,10 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
   load_kin_constants(m, L, K, KK);
   ComK CK;
   load_com_constants(m, L, CK);
+  // (the dispatch tables of the launch after next are cleared here, before a workgroup without a copy can leave)
+  if (a.lpt_count_clear && wv::env_index() == 0 && L < LPT_BUCKETS) a.lpt_count_clear[L] = 0;
+  if (a.lpt_mask_clear && wv::env_index() < a.lpt_words && L < LPT_BUCKETS)
+    a.lpt_mask_clear[(size_t)L * a.lpt_words + wv::env_index()] = 0u;
   if (a.lpt_count_in) {
     int bucket = 0;
     env = lpt_copy_of(a, L, env, my_count, bucket);
@@ -2490,19 +2495,20 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
 #else
 #define MJ_CUT(k)
 #endif
-#define MJ_STAMP(k)                                                        \
+#define MJ_STAMP_ONLY(k)                                                   \
   if constexpr (DIAG) if (stamps) {                                        \
     unsigned long long t_now = wv::clock();                                \
     if (L == (k)) stamps->mine += t_now - stamps->prev;                    \
     stamps->prev = t_now;                                                  \
-  }                                                                        \
-  MJ_CUT(k)
+  }
+#define MJ_STAMP(k) MJ_STAMP_ONLY(k) MJ_CUT(k)
 #define MJ_FOR(i, n) for (int i = L; i < (n); i += 64)
   // state in: the copy's rows (one element per lane and array, a second one of qpos when nq > 64), fetched whether or
   // not the copy is flagged for an in-launch reset -- the flag arrives with them
   const bool may_reset = a.reset_mask != nullptr && !a.forward_only;
   const int r_mask = may_reset ? (int)a.reset_mask[env] : 0;
   const int r_ts = a.forward_only ? 0 : a.timestep[env];
+  const int r_ep = (a.episode && a.n_op > 0) ? a.episode[env] : 0;
   const real r_qpos0 = a.qpos[(size_t)env * m.nq + (L < m.nq ? L : 0)];
   const real r_qpos1 = m.nq > 64 ? a.qpos[(size_t)env * m.nq + (L + 64 < m.nq ? L + 64 : 0)] : 0.0;
   const real r_qvel = a.qvel[(size_t)env * m.nv + (L < m.nv ? L : 0)];
@@ -2537,6 +2543,8 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
   // -- every load of the prologue is in flight; from here on their values are used --
   const bool resetting = may_reset && wv::first_int(r_mask) != 0;
   const int ts = (a.forward_only || resetting) ? 0 : wv::first_int(r_ts);
+  // the episode this step belongs to: an in-launch reset starts the next one
+  const unsigned long long ep_key = (unsigned long long)(unsigned)(wv::first_int(r_ep) + (resetting ? 1 : 0)) << 32;
   if (resetting) store_reg = __builtin_nan("");          // (reset: an empty store)
   if (resetting && a.first_frame) {
     MJ_FOR(i, m.nq) S[l.qpos + i] = m.qpos0[i];
@@ -2654,6 +2662,9 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     }
     MJ_STAMP(ST_EULER)
   }
+  // (a launch cut at `store` ends here: cut launches write no state back, so the launches cut at successive stages
+  // of tools/stage_mix.py all run on the same states; the inertia scratch row is rewritten by every step anyway)
+  MJ_CUT(ST_STORE)
   // state out
   // The end of the step reads its arguments and the copy's id afresh (wv::fresh: the same values, their origin hidden
   // from the optimiser).  Otherwise every row address the prologue formed -- base pointer + copy x stride, a dozen
@@ -2690,10 +2701,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
       a.obs[(size_t)env * a.n_agent * a.obs_dim + it] = v;
     }
   }
-  MJ_STAMP(ST_STORE)
-  if (a.lpt_count_clear && wv::env_index() == 0 && L < LPT_BUCKETS) a.lpt_count_clear[L] = 0;
-  if (a.lpt_mask_clear && wv::env_index() < a.lpt_words && L < LPT_BUCKETS)
-    a.lpt_mask_clear[(size_t)L * a.lpt_words + wv::env_index()] = 0u;
+  MJ_STAMP_ONLY(ST_STORE)
   if (a.stats && a.skip_frames && L < 4) {
     const int* I = (const int*)(S + l.ints);
     a.stats[4 * (size_t)env + L] = I[L == 0 ? I_NCON : (L == 1 ? I_NEFC : (L == 2 ? I_NITER : I_WARN))];
@@ -2780,7 +2788,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
             real* cur_slot = store + me * a.n_slot + pi[2];
             real* inv_slot = pi[3] >= 0 ? store + me * a.n_slot + pi[3] : nullptr;
             if (*cur_slot != *cur_slot) {            // first call of the episode: choose a target, empty the inventory
-              *cur_slot = (real)pick_of(mix64(seed, genv, (unsigned long long)me, (unsigned long long)ts, 0), num);
+              *cur_slot = (real)pick_of(mix64(seed, genv, (unsigned long long)me, ep_key | (unsigned long long)ts, 0), num);
               if (inv_slot) *inv_slot = 0.0;
             }
             int cur = (int)*cur_slot;
@@ -2791,7 +2799,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
             if (dist < pf[0]) {
               if (inv_slot) *inv_slot = 1.0 - *inv_slot;
               rew += pf[1];
-              cur = pick_of(mix64(seed, genv, (unsigned long long)me, (unsigned long long)ts, 1), num);
+              cur = pick_of(mix64(seed, genv, (unsigned long long)me, ep_key | (unsigned long long)ts, 1), num);
               *cur_slot = (real)cur;
               t = ref_pos(a.tag_ref[adr + cur]);
               if (pi[5] >= 0) { V3 e3 = p - t; store[me * a.n_slot + pi[5]] = sqrt(dot(e3, e3)); }
@@ -2879,7 +2887,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
           real* cur_slot = store + ag * a.n_slot + pi[2];
           real* inv_slot = pi[3] >= 0 ? store + ag * a.n_slot + pi[3] : nullptr;
           if (*cur_slot != *cur_slot) {            // first call of the episode: choose a target, empty the inventory
-            *cur_slot = (real)pick_of(mix64(seed, genv, (unsigned long long)ag, (unsigned long long)ts, 0), num);
+            *cur_slot = (real)pick_of(mix64(seed, genv, (unsigned long long)ag, ep_key | (unsigned long long)ts, 0), num);
             if (inv_slot) *inv_slot = 0.0;
           }
           int cur = (int)*cur_slot;
@@ -2890,7 +2898,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
           if (dist < pf[0]) {
             if (inv_slot) *inv_slot = 1.0 - *inv_slot;
             rew[ag] += pf[1];
-            cur = pick_of(mix64(seed, genv, (unsigned long long)ag, (unsigned long long)ts, 1), num);
+            cur = pick_of(mix64(seed, genv, (unsigned long long)ag, ep_key | (unsigned long long)ts, 1), num);
             *cur_slot = (real)cur;
             t = ref_pos(a.tag_ref[adr + cur]);
             if (pi[5] >= 0) { V3 e3 = p - t; store[ag * a.n_slot + pi[5]] = sqrt(dot(e3, e3)); }
@@ -2935,10 +2943,11 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
   wv::sync();
   if (ops_staged && a.store && L < n_store_row) a.store[(size_t)env * n_store_row + L] = S[l.bias + t_store + L];
   if (L == 0) a.timestep[env] = ts + 1;
-  if (resetting && a.variant && L == 0) {          // a new episode: a new level variant, as mjrl_reset chooses it
+  if (resetting && a.episode && L == 0) {          // a new episode (and a new level variant), as mjrl_reset counts / chooses it
     const int ep = a.episode[env] + 1;
     a.episode[env] = ep;
-    a.variant[env] = pick_of(mix64(a.variant_seed, (unsigned long long)(a.env_base + env), 0ull, (unsigned long long)ep, 2), a.n_variant);
+    if (a.variant)
+      a.variant[env] = pick_of(mix64(a.variant_seed, (unsigned long long)(a.env_base + env), 0ull, (unsigned long long)ep, 2), a.n_variant);
   }
   MJ_STAMP(ST_TAIL)
   if constexpr (DIAG) if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
@@ -2948,6 +2957,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
 #undef MJ_TIMELINE
 #undef MJ_FILE_WORK
 #undef MJ_STAMP
+#undef MJ_STAMP_ONLY
 #undef MJ_CUT
 #undef MJ_FOR
 #undef MJ_L

@@ -124,14 +124,17 @@ __device__ __forceinline__ double first(double v) {
 // each, too many for the scalar registers, and come back through v_readlane at every use.
 __device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
-// The same (wave-uniform) pointer as a value the optimiser has not seen before: what is loaded through it is not merged
-// with earlier loads through the original, so nothing fetched early stays live in registers until here.
+// The same (wave-uniform) pointer INTO CONSTANT MEMORY (the kernel's argument segment) as a value the optimiser has not
+// seen before: what is loaded through it is not merged with earlier loads through the original, so nothing fetched early
+// stays live in registers until here.  The result is re-typed as a constant-address-space pointer before it goes back
+// to a generic one: the loads through it stay scalar loads (through a pointer of unknown origin they would be flat
+// vector loads, every lane fetching the same word).
 template <typename T>
 __device__ __forceinline__ const T* fresh(const T* p) {
   unsigned long long v = (unsigned long long)p;
   unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
   asm volatile("" : "+s"(lo), "+s"(hi));
-  return (const T*)(((unsigned long long)hi << 32) | lo);
+  return (const T*)(const T __attribute__((address_space(4)))*)(((unsigned long long)hi << 32) | lo);
 }
 
 // issue priority of this wave among the waves of its SIMD (0 lowest .. 3 highest); p is wave-uniform

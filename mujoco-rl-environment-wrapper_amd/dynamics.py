@@ -28,16 +28,25 @@ _M = (1 << 64) - 1
 
 def mix64(seed, env, agent, step, salt):
     """The counter-based generator of the device's random choices (csrc/mjrl_step.h ``mix64``), bit for bit: a pure function
-    of (seed, global copy id, agent index, episode step, salt).  ``env`` may be an array."""
+    of (seed, global copy id, agent index, step key, salt).  ``env`` and ``step`` may be arrays.  The plugins' step key is
+    ``episode_key(env)``: the copy's episode count in the upper and its episode step in the lower 32 bits, so that a
+    copy's episodes draw different targets (the reference draws with random.randint)."""
     env = np.asarray(env, dtype=np.uint64)
+    step = np.asarray(step, dtype=np.uint64)
     with np.errstate(over="ignore"):
         z = (np.uint64(int(seed) * 0x9E3779B97F4A7C15 & _M) + env * np.uint64(0xBF58476D1CE4E5B9)
-             + np.uint64(int(agent) * 0x94D049BB133111EB & _M) + np.uint64(int(step) * 0xD6E8FEB86659FD93 & _M)
+             + np.uint64(int(agent) * 0x94D049BB133111EB & _M) + step * np.uint64(0xD6E8FEB86659FD93)
              + np.uint64(int(salt) * 0xA0761D6478BD642F & _M))
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return z
+
+
+def episode_key(env):
+    """``episode << 32 | episode step`` of every copy of ``env`` (uint64 array): the step key of the device's draws."""
+    episode = np.asarray(getattr(env, "episode", 0), dtype=np.uint64).reshape(-1)
+    return (episode << np.uint64(32)) | np.uint64(int(env.timestep))
 
 
 def pick_of(z, n: int):
@@ -74,8 +83,8 @@ class TargetDynamic:
     ``tag`` in the level's info JSON are the targets; every agent has a current one (``data_store[agent]["current_target"]``,
     its index in ``filter_by_tag(tag)``), chosen at random when the episode starts and again whenever the agent comes
     within ``threshold`` of it; the observation is the current target's position.  Subclass to change ``tag``,
-    ``threshold``, ``seed``.  The random choices come from ``mix64`` keyed on (seed, global copy id, agent, episode step),
-    so the host loop and the fused op draw the same targets."""
+    ``threshold``, ``seed``.  The random choices come from ``mix64`` keyed on (seed, global copy id, agent, episode count and
+    episode step), so the host loop and the fused op draw the same targets, and every episode of a copy its own."""
     tag, threshold, reach_reward, inventory, seed = "target", 1.0, 0.0, False, 0
 
     def __init__(self, mujoco_gym):
@@ -94,7 +103,7 @@ class TargetDynamic:
             store["targets"] = env.tagged_names(self.tag)
         names = store["targets"]
         if "current_target" not in store:
-            store["current_target"] = pick_of(mix64(self.seed, ids, k, env.timestep, 0), len(names))
+            store["current_target"] = pick_of(mix64(self.seed, ids, k, episode_key(env), 0), len(names))
             if self.inventory:
                 store["inventory"] = np.zeros(env.n_env)
         cur = np.asarray(store["current_target"]).reshape(env.n_env)
@@ -107,7 +116,7 @@ class TargetDynamic:
         if self.inventory:
             inv = np.asarray(store["inventory"], np.float64).reshape(env.n_env)
             store["inventory"] = np.where(reached, 1.0 - inv, inv)
-        fresh = pick_of(mix64(self.seed, ids, k, env.timestep, 1), len(names))
+        fresh = pick_of(mix64(self.seed, ids, k, episode_key(env), 1), len(names))
         cur = np.where(reached, fresh, cur)
         store["current_target"] = cur
         if reached.any():

@@ -42,8 +42,12 @@ def _source_digest() -> str:
     for name in SOURCES:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:12]
+
+
+def _flags_digest() -> str:
+    """Builds with other flags (the diagnostic build, ``MJRL_SPEC_FLAGS=-DMJRL_DIAG``) are cached side by side."""
+    return hashlib.sha1(" ".join(FLAGS).encode()).hexdigest()[:6]
 
 
 def spec_header(sizes: dict) -> str:
@@ -52,7 +56,7 @@ def spec_header(sizes: dict) -> str:
 
 def object_path(sizes: dict) -> str:
     key = hashlib.sha1(spec_header(sizes).encode()).hexdigest()[:16]
-    return os.path.join(CACHE, f"step_{key}_{_source_digest()}.hsaco")
+    return os.path.join(CACHE, f"step_{key}{_flags_digest()}_{_source_digest()}.hsaco")
 
 
 def hipcc() -> str | None:

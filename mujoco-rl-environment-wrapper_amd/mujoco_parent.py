@@ -183,6 +183,15 @@ class MuJoCoParent:
             self._handle.set_variants(self._variants["rgba"], self._variant_seed)
         self.model = ModelView(self._compiled)
         self.data = DataView(self)
+        self._episode = None
+
+    @property
+    def episode(self) -> np.ndarray:
+        """Resets so far, per copy (part of the key of the plugins' random draws, dynamics.py); fetched from the device
+        on first use after a reset."""
+        if self._episode is None:
+            self._episode = self._handle.get_field("episode")
+        return self._episode
 
     def set_stream(self, hip_stream):
         """Launch on a caller-provided HIP stream (integer handle; None = the library's own).  Kept across the handle
@@ -348,6 +357,7 @@ class MuJoCoParent:
                 self._after_init_environment()
         self.cap_overflows(report=True)
         self._handle.reset()
+        self._episode = None
         if self._variants is not None:
             # every copy drew its own level variant; `xml_path` names copy 0's (with one copy: the reference's attribute)
             self.xml_path = self._variants["paths"][int(self.variant_ids()[0])]

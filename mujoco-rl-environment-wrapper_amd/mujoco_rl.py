@@ -287,7 +287,12 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
             rewards = {a: float(v) for a, v in rewards.items()}
             terminations = {a: bool(v) for a, v in terminations.items()}
         infos = {a: {d.__class__.__name__: {} for d in self.environment_dynamics} for a in self.agents}
-        truncations = self._check_truncations()
+        # the kernel's own flags: evaluated per copy against the copy's own step counter (mujoco_rl.py:406-417 before the
+        # counter moves), so that copies reset on their own (reset_batched(mask), in-launch resets) are told apart --
+        # the single host counter below is copy 0's
+        flags = trunc[:, 0].astype(bool)
+        truncations = {a: (bool(flags[0]) if self.n_env == 1 else flags.copy()) for a in self.agents}
+        truncations["__all__"] = bool(flags[0]) if self.n_env == 1 else flags.copy()
         if len(self.done_functions) != 0:
             if self.n_env == 1:
                 terminations["__all__"] = any(terminations.values())
@@ -412,12 +417,20 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
                     data[key] = value
         return data
 
+    def close(self):
+        """Release the device state (and the views of the handle's pinned host buffers).  Defined here, not only on the
+        parent: where pettingzoo is installed ``ParallelEnv.close`` -- a no-op -- comes first in the method resolution
+        order and would shadow it (the reference's parent has no close at all; this port's owns HBM)."""
+        self._pinned = None
+        MuJoCoParent.close(self)
+
     # ------------------------------------------------------------------ array path
     def reset_batched(self, mask=None):
         """Reset every copy (or the copies flagged in ``mask``) without building per-agent dicts; asynchronous on
         the handle's stream.  The array-path counterpart of ``reset()`` for runs without host plugins."""
         self._handle.reset(mask)
         self.timestep = 0 if mask is None else self.timestep
+        self._episode = None
         self._obs_cache = None
 
     def _check_device_buffers(self, actions, obs, reward, term, trunc):

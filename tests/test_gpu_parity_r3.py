@@ -1,0 +1,193 @@
+"""Round-3 tests on the MI355X, through the C-ABI: the fixes of the round-2 review (pinned host buffers re-sized when the
+agent count changes, a copy's episodes draw different targets, latent slots of an agent without a camera read 0,
+``MuJoCoRL.close`` releases the device state under a ParallelEnv base, truncation flags per copy) and the production /
+diagnostic kernel split (the diagnostic entry points still work and give the production kernel's bits)."""
+import numpy as np
+import pytest
+
+from mjrl_amd import _capi, blob, levels, mjcf
+from mjrl_amd.mujoco_rl import MuJoCoRL
+from oracle.oracle import OracleEnv
+
+pytestmark = pytest.mark.gpu
+
+AGENTS = ["sender", "receiver"]
+INFO_JSON = __file__.rsplit("/", 1)[0] + "/golden/two_agent_info.json"
+
+
+def test_pinned_buffers_follow_the_agent_count():
+    """mjrl_host_buffers before the gather / scatter tables exist sees no agents and sizes the reward / flag buffers for
+    one element per copy; a second call after the tables are set must re-size them (the kernel writes n_env x n_agent
+    elements through the mapped pointers), and step_pinned must refuse a stale set."""
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    h = _capi.Handle(blob.pack(model), 40)
+    h.reset()
+    early = h.host_buffers(8)
+    assert early[2].shape == (40, 1)                       # no agents yet
+    env = MuJoCoRL.tables_only(levels.level_path("two_agent.xml"))
+    sens, qp, qv, scat = [], [], [], []
+    for a in AGENTS:
+        env.get_observation_space_mujoco(a)
+        env.get_action_space_mujoco(a)
+        idx = env.agents_observation_index[a]
+        sens.append(idx["sensors"]); qp.append(idx["qpos"]); qv.append(idx["qvel"])
+        scat.append(env.agents_action_index[a])
+    h.set_gather_tables(sens, qp, qv)
+    h.set_scatter_tables(scat, 0)
+    with pytest.raises(Exception, match="host_buffers"):
+        h.step_pinned(8, 1)                               # the early buffers are too small for two agents
+    act, obs, rew, term, trunc = h.host_buffers(8)
+    assert rew.shape == (40, 2) and term.shape == (40, 2) and obs.shape == (40, 2, 59)
+    rew[:] = 7.0; term[:] = 9; trunc[:] = 9
+    rng = np.random.default_rng(0)
+    act[:] = rng.uniform(-1, 1, act.shape)
+    h.step_pinned(8, 1)
+    assert not rew.any() and not term.any() and not trunc.any()          # all 80 elements were written by the kernel
+    ora = OracleEnv(blob.pack(model))
+    ora.reset()
+    for k in range(2):
+        ora.ctrl[scat[k]] = act[39, k]
+    ora.step()
+    assert np.allclose(obs[39, 0, 1:31], ora.qpos, atol=1e-12)
+    h.close()
+
+
+def test_target_draws_differ_between_episodes_and_match_the_host_plugin():
+    """The key of an on-device random choice holds the copy's episode count (kept whether or not level variants are on):
+    the first target of a copy's second episode is not tied to the first episode's, the host plugin of the same name
+    draws the same numbers over two episodes, and an in-launch reset counts an episode like mjrl_reset does."""
+    import torch
+    from mjrl_amd.dynamics import PickUpDynamic, episode_key, mix64, pick_of
+
+    class Pick(PickUpDynamic):
+        threshold, seed = 0.01, 7          # (never reached: what is under test are the episodes' first draws)
+
+    def make_env(fused, n=64):
+        return MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "infoJson": INFO_JSON, "agents": AGENTS, "numEnvs": n,
+                         "environmentDynamics": [Pick], "fusedPlugins": fused, "firstEnvId": 100, "maxSteps": 6})
+    fused, host = make_env(True), make_env(False)
+    firsts = []
+    rng = np.random.default_rng(1)
+    for episode in range(2):
+        np.random.seed(0); fused.reset()
+        np.random.seed(0); host.reset()
+        assert np.array_equal(fused.episode, np.full(64, episode + 1)) and np.array_equal(host.episode, fused.episode)
+        for step in range(5):
+            action = {a: rng.uniform(-1, 1, (64, 8)) for a in AGENTS}
+            f, h = fused.step(action), host.step(action)
+            for a in AGENTS:
+                assert np.allclose(f[0][a], h[0][a], atol=1e-12), (episode, step, a)
+                assert np.allclose(f[1][a], h[1][a], atol=1e-10)
+            if step == 0:
+                firsts.append(fused.device_store["sender"]["current_target"].copy())
+                assert (episode_key(host) == ((np.uint64(episode + 1) << np.uint64(32)) | np.uint64(1))).all()
+                want = pick_of(mix64(7, 100 + np.arange(64), 0, np.full(64, np.uint64(episode + 1) << np.uint64(32)), 0), 3)
+                assert np.array_equal(firsts[-1], want.astype(np.float64))
+    assert (firsts[0] != firsts[1]).any()                 # fresh choices each episode (random.randint in the reference)
+    # in-launch reset: the flagged copies start episode 3 inside the step launch and draw that episode's first target
+    mask = np.zeros(64, np.uint8); mask[::3] = 1
+    d_mask = torch.from_numpy(mask).cuda()
+    fused._handle.set_step_reset_mask(d_mask.data_ptr())
+    act = torch.zeros((64, 2, 8), dtype=torch.float64, device="cuda")
+    fused.step_batched(act)
+    torch.cuda.synchronize()
+    fused._handle.set_step_reset_mask(None)
+    ep = fused._handle.get_field("episode")
+    assert np.array_equal(ep, 2 + mask)
+    cur = fused.device_store["sender"]["current_target"]
+    want3 = pick_of(mix64(7, 100 + np.arange(64), 0, (np.uint64(3) << np.uint64(32)), 0), 3).astype(np.float64)
+    assert np.array_equal(cur[mask == 1], want3[mask == 1])
+    fused.close(); host.close()
+
+
+def test_latent_slots_of_an_agent_without_a_camera_read_zero():
+    """include/mjrl.h: with mjrl_set_camera_obs, the latent slots of an agent whose camera id is -1 read 0 every step
+    (nobody writes them: they used to hold whatever the caller's buffer held)."""
+    import torch
+    from tests.test_gpu_encoder import make_weights
+    latent = 16
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 8, "agentCameras": True,
+                    "cameraEncoder": {"weights": make_weights(latent, seed=2), "relu": True}})
+    env._handle.set_camera_obs([0, -1])                   # the receiver loses its camera
+    env.reset_batched()
+    obs = torch.full((8, 2, 59 + latent), 123.0, dtype=torch.float64, device="cuda")
+    act = torch.zeros((8, 2, 8), dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        env.step_batched(act, obs)
+    torch.cuda.synchronize()
+    o = obs.cpu().numpy()
+    assert not o[:, 1, 59:].any()                         # zeros, not the 123s of the caller's buffer
+    assert np.abs(o[:, 0, 59:]).max() > 0 and not (o[:, 0, 59:] == 123.0).any()
+    env.close()
+    assert model.ncam == 2
+
+
+def test_close_releases_the_device_state_under_a_parallel_env_base():
+    """Where pettingzoo is installed ``ParallelEnv.close`` (a no-op) comes first in the MRO: ``MuJoCoRL.close`` must still
+    destroy the handle and drop the views of its pinned buffers."""
+    class StubParallelEnv:
+        def close(self):
+            pass
+
+    class Env(StubParallelEnv, MuJoCoRL):
+        pass
+
+    env = Env({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 4})
+    env.reset_batched()
+    env.step_batched(np.zeros((4, 2, 8)))
+    assert env._pinned is not None and env._handle is not None
+    MuJoCoRL.close(env)
+    assert env._handle is None and env._pinned is None
+
+
+def test_truncation_flags_of_the_dict_api_are_per_copy():
+    """A masked reset_batched leaves the copies at different points of their episodes; the dict API's truncation flags
+    are the kernel's (each copy's own step counter), the same as step_batched returns."""
+    from mjrl_amd.dynamics import Language
+    cfg = {"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 4, "maxSteps": 3,
+           "environmentDynamics": [Language]}
+    env = MuJoCoRL(cfg)
+    env.reset()
+    zero = {a: np.zeros((4, 9)) for a in AGENTS}
+    for _ in range(2):
+        env.step(zero)
+    env.reset_batched(mask=np.array([0, 1, 0, 1], np.uint8))
+    out = [env.step(zero)[3] for _ in range(3)]
+    # copies 0 and 2 are at steps 2, 3, 4 of their episode (truncated from step 3 on), copies 1 and 3 at 0, 1, 2
+    assert out[0]["sender"].tolist() == [False, False, False, False]
+    assert out[1]["sender"].tolist() == [True, False, True, False]
+    assert out[2]["__all__"].tolist() == [True, False, True, False]
+    env.close()
+
+
+def test_diagnostic_launches_give_the_production_bits():
+    """The production kernels carry no diagnostics; mjrl_step_debug / _profile / _timeline launch the diagnostic build.
+    A batch stepped through step_debug (LDS dump) and one stepped through step_device end in the same state, bit for
+    bit, and the dump shows the solver's work."""
+    import torch
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    packed = blob.pack(model)
+    a, b = _capi.Handle(packed, 32), _capi.Handle(packed, 32)
+    assert a.kernel == "specialised"
+    for h in (a, b):
+        h.reset()
+        h.set_scatter_tables([list(range(model.nu))], 0)
+    rng = np.random.default_rng(5)
+    q = np.tile(model.qpos0, (32, 1)); q[:, 2] = rng.uniform(0.1, 0.6, 32); q[:, 17] = rng.uniform(0.1, 0.6, 32)
+    a.set_field("qpos", q); b.set_field("qpos", q)
+    ioff = a.lds_offset("ints")
+    for t in range(30):
+        ctrl = torch.from_numpy(rng.uniform(-1, 1, (32, model.nu))).cuda()
+        img = a.step_debug(ctrl.data_ptr(), model.nu, 1, 0)
+        b.step_device(ctrl.data_ptr(), model.nu, 1)
+    for f in ("qpos", "qvel", "qacc_warmstart"):
+        assert np.array_equal(a.get_field(f), b.get_field(f)), f
+    ints = img[:, ioff:ioff + 4].copy().view(np.int32)
+    stats = b.get_field("solver_stats")
+    assert np.array_equal(ints[:, 0], stats[:, 0]) and np.array_equal(ints[:, 1], stats[:, 1]) and stats[:, 1].max() > 8
+    prof = b.step_profile()
+    assert prof["pgs"] + prof["pgs_sweeps"] > 0 and prof["kin"] > 0
+    tl = b.step_timeline()
+    assert (tl[:, 1] > tl[:, 0]).all() and sorted(tl[:, 2].tolist()) == list(range(32))
+    a.close(); b.close()

@@ -29,7 +29,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summary":
     print(f"{'total':10s}" + "".join(f"{prev[n]:16.1f}" for n in names))
     sys.exit(0)
 
-os.environ["MJRL_SPEC_FLAGS"] = (os.environ.get("MJRL_SPEC_FLAGS", "") + " -DMJRL_STAGE_CUT").strip()   # the diagnostic build
+os.environ["MJRL_SPEC_FLAGS"] = (os.environ.get("MJRL_SPEC_FLAGS", "") + " -DMJRL_DIAG -DMJRL_STAGE_CUT").strip()   # the diagnostic build
 import numpy as np
 import __graft_entry__ as entry
 entry.load_package()

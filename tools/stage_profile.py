@@ -5,6 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+os.environ["MJRL_SPEC_FLAGS"] = (os.environ.get("MJRL_SPEC_FLAGS", "") + " -DMJRL_DIAG").strip()   # the diagnostic build of the specialised kernel
 import __graft_entry__ as entry
 entry.load_package()
 from mjrl_amd import mjcf, levels, blob, _capi
