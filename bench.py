@@ -47,7 +47,17 @@ WORKLOADS = {
     # BASELINE config 5: every step also ray-casts both agent cameras (64x64x3 uint8 each) into HBM; 512 copies
     "camera": dict(level="two_agent.xml", agents=["sender", "receiver"], cameras=True, envs=512,
                    what="2-agent ant arena + both agent cameras (64x64x3 uint8 each, ray cast) per step, BASELINE config 5"),
+    # BASELINE config 5 as a vision policy consumes it: the images are encoded on the matrix cores (vision/autoencoder.py:
+    # 12-18, latent 100 as vision/train.py:70, random-init weights) and the latents end the observation rows
+    "camera_latents": dict(level="two_agent.xml", agents=["sender", "receiver"], cameras=True, encoder=True, envs=512,
+                           what="2-agent ant arena + both agent cameras (64x64x3 uint8, ray cast) + encoder latents (100 per "
+                                "agent, bf16 MFMA) in the observation per step, BASELINE config 5 feeding vision obs"),
 }
+# what the default run measures after the headline, ~50 steps each (bench line field `configs`): BASELINE.json configs[1],
+# [3] per GPU, [4] with and without the encoder.  (level, language channel, env copies)
+EXTRA_CONFIGS = [("config 2", "two_agent", False, 1024), ("config 4", "four_agent", False, 4096),
+                 ("config 5", "camera", False, 512), ("config 5 + encoder", "camera_latents", False, 512)]
+ENCODER_LATENT = 100
 
 
 def algorithmic_bytes_per_env_step(nq, nv, n_act_total, obs_total, n_agent, n_slot=0, s=8):
@@ -75,10 +85,31 @@ def phase_of(global_env, envs_per_gpu):
     return (np.asarray(global_env, dtype=np.int64) * EPISODE // max(envs_per_gpu, 1)) % EPISODE
 
 
-def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seconds=8.0, language=False):
+def cpu_share(limit=None):
+    """Worker processes for the CPU baseline: the cores this job may actually use -- the scheduler affinity, cut by the
+    cgroup's CPU quota where one is set -- and at most `limit` (default 16: a one-GPU box's share of its host; the other
+    cores of a 256-thread host belong to the other GPUs' jobs, and 256 workers there measured the neighbours' load:
+    1.44 M env-steps/s one day, 0.66 M the next, at an unchanged 50 k per core)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, limit or 16))
+
+
+def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seconds=8.0, language=False, workers=None):
     """The step on the host cores, on a bounded sample of the same workload: worker w steps GLOBAL env id w with the
     action stream the GPU feeds that copy (same Philox key and counter), episodes of 1024 steps from reset, for
-    `seconds` of wall time; once on one core, once with one process per core.  kind "reference": the box has the
+    `seconds` of wall time; once on one core, once with one process per core of this job's CPU share (cpu_share).  kind "reference": the box has the
     reference's own physics library (`mujoco`), run as the reference runs it (mj_step + numpy gather, solver set to PGS
     like the kernel).  kind "port": it has not (the case in this image) and the repo's fp64 restatement
     (oracle/ora_step.c) stands in."""
@@ -139,7 +170,7 @@ def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seco
         error, have_mujoco = repr(exc), False
         run_one(q, 0, seconds)
     n1, t1 = q.get()
-    cores = os.cpu_count() or 1
+    cores = cpu_share(workers)
     procs = [ctx.Process(target=run_one, args=(q, i, seconds)) for i in range(cores)]
     for p in procs:
         p.start()
@@ -153,7 +184,7 @@ def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seco
            "sample": f"{engine}; importlib.util.find_spec('mujoco') -> {'found' if found else 'None'}; {cores} processes x "
                      f"1 env copy x {seconds:.0f} s of {os.path.basename(level_file)}, worker w = global env id w on the GPU "
                      f"run's Philox action stream, episodes of {EPISODE} steps from reset, step + numpy obs gather",
-           "mujoco_found": found, "single_thread": n1 / t1}
+           "mujoco_found": found, "single_thread": n1 / t1, "host_threads": os.cpu_count()}
     if error:
         out["mujoco_error"] = error
     return out
@@ -162,14 +193,22 @@ def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seco
 class DeviceBatch:
     """The product path: ``MuJoCoRL`` over libmjrl_hip.so, tensors resident in HBM."""
 
-    def __init__(self, torch, dev, level_file, agents, n_env, plugins, args, stream, cameras=False):
+    def __init__(self, torch, dev, level_file, agents, n_env, plugins, args, stream, cameras=False, encoder=False):
         from mjrl_amd.mujoco_rl import MuJoCoRL
         self.torch, self.dev = torch, dev
-        self.env = MuJoCoRL({"xmlPath": level_file, "agents": agents, "numEnvs": n_env, "deviceId": dev.index,
-                             "skipFrames": 1, "maxSteps": EPISODE, "environmentDynamics": plugins,
-                             "nconmax": args.nconmax, "njmax": args.njmax, "agentCameras": cameras})
+        cfg = {"xmlPath": level_file, "agents": agents, "numEnvs": n_env, "deviceId": dev.index,
+               "skipFrames": 1, "maxSteps": EPISODE, "environmentDynamics": plugins,
+               "nconmax": args.nconmax, "njmax": args.njmax, "agentCameras": cameras}
+        if encoder:          # random-init weights of the reference's architecture (no checkpoint ships, no network)
+            rng = np.random.default_rng(0)
+            he = lambda *shape, fan: (rng.standard_normal(shape) * np.sqrt(2.0 / fan)).astype(np.float32)
+            cfg["cameraEncoder"] = {"relu": True, "weights": {
+                "w1": he(3, 3, 3, 32, fan=27), "b1": np.zeros(32, np.float32), "w2": he(3, 3, 32, 64, fan=288),
+                "b2": np.zeros(64, np.float32), "wd": he(16384, ENCODER_LATENT, fan=16384), "bd": np.zeros(ENCODER_LATENT, np.float32)}}
+        self.env = MuJoCoRL(cfg)
         self.rgb = None
-        if cameras:          # the images of every step land here (get_camera_data's content, kept in HBM)
+        if cameras and not encoder:   # the images of every step land here (get_camera_data's content, kept in HBM);
+                                      # with the encoder the step itself renders and encodes them (mjrl_set_camera_obs)
             self.rgb = torch.empty((n_env, self.env._handle.size("ncam"), 64, 64, 3), dtype=torch.uint8, device=dev)
         self.stream = stream
         self.env.set_stream(stream.cuda_stream)
@@ -261,11 +300,16 @@ def parse_args(argv=None):
     ap.add_argument("--njmax", type=int, default=None, help="constraint-row cap per env copy (default: the compiler's)")
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="env copies per GPU (default 4096; 512 for --level camera)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-workers", type=int, default=None,
+                    help="processes of the CPU baseline (default: this job's CPU share, at most 16)")
     ap.add_argument("--groups", type=int, default=1,
                     help="step the batch as this many independent groups on their own streams (1 = lockstep, the headline)")
     ap.add_argument("--double-buffer", action="store_true",
                     help="also measure the batch as two independent half-batches on two streams (reported beside the value)")
     ap.add_argument("--no-language", action="store_true", help="config 2: physics + gather only, no Language channel")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the BASELINE configs 2, 4, 5 that the default one-GPU run measures after the headline")
+    ap.add_argument("--extra-steps", type=int, default=50, help="timed steps of each of those configs")
     return ap.parse_args(argv)
 
 
@@ -281,6 +325,19 @@ def launch_ranks(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def host_tables(level_file, agents):
+    """What the CPU baseline needs of a level, built without touching a GPU: the packed model and every agent's ctrl
+    indices (mujoco_parent.py:274-314)."""
+    from mjrl_amd import blob as blob_mod, mjcf
+    from mjrl_amd.mujoco_parent import MuJoCoParent
+    tables = MuJoCoParent.tables_only(level_file)
+    index = {}
+    for a in agents:
+        tables.get_action_space_mujoco(a)
+        index[a] = list(tables.agents_action_index[a])
+    return blob_mod.pack(mjcf.compile_mjcf(level_file)), index
 
 
 def main():
@@ -299,6 +356,30 @@ def main():
         local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    entry.load_package()
+    from mjrl_amd import levels
+    from mjrl_amd.dynamics import Language
+
+    work = WORKLOADS[args.level]
+    agents, level_file = work["agents"], levels.level_path(work["level"])
+    n_agent = len(agents)
+    # the Language channel is a 2-agent dynamic (README.md:109-136)
+    language = n_agent == 2 and not args.no_language and not work.get("cameras")
+
+    # The CPU baseline runs FIRST, before this process makes its first GPU call: its workers are forked from a process
+    # without HIP state (round 2 forked them from one whose runtime was live).
+    cpu_line = None
+    if world == 1 and not args.no_cpu_baseline and not on_cpu:
+        packed, index = host_tables(level_file, agents)
+        n_phys0 = max(len(index[a]) for a in agents)
+        act_dim0 = n_phys0 + (1 if language else 0)
+        scatter = np.full((n_agent, act_dim0), -1, np.int64)
+        for k, a in enumerate(agents):
+            scatter[k, :len(index[a])] = index[a]
+        cpu_line = cpu_baseline(level_file, packed, scatter, n_agent, act_dim0, n_phys0, language=language,
+                                workers=args.cpu_workers)
+
     import torch
     dev = None
     if not on_cpu:
@@ -312,26 +393,17 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    entry.load_package()
-    from mjrl_amd import levels
-    from mjrl_amd.dynamics import Language
-
-    work = WORKLOADS[args.level]
-    agents, level_file = work["agents"], levels.level_path(work["level"])
-    if args.envs_per_gpu is None:
-        args.envs_per_gpu = work.get("envs", ENVS_PER_GPU)
-    cameras = bool(work.get("cameras"))
-    n_env, n_agent = args.envs_per_gpu, len(agents)
-    # the Language channel is a 2-agent dynamic (README.md:109-136)
-    plugins = [Language] if (n_agent == 2 and not args.no_language and not cameras) else []
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def timed_run(groups):
+    def timed_run(work, language, n_env, steps, warmup, preroll, groups):
         """The batch as `groups` env objects of n_env / groups copies, each on its own HIP stream (1: the whole batch
-        in lockstep on the current stream).  Returns (batches, wall seconds, ms per step by HIP events, stats)."""
+        in lockstep on the current stream).  Returns (batches, wall seconds, ms per step by HIP events, stats, n_phys)."""
+        agents, level_file = work["agents"], levels.level_path(work["level"])
+        n_agent = len(agents)
+        plugins = [Language] if language else []
+        cameras, encoder = bool(work.get("cameras")), bool(work.get("encoder"))
         per = n_env // groups
         batches, bufs, acts, masks = [], [], [], []
         for g in range(groups):
@@ -339,7 +411,7 @@ def main():
                 batch = RehearsalBatch(level_file, agents, per, bool(plugins))
             else:
                 stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
-                batch = DeviceBatch(torch, dev, level_file, agents, per, plugins, args, stream, cameras=cameras)
+                batch = DeviceBatch(torch, dev, level_file, agents, per, plugins, args, stream, cameras=cameras, encoder=encoder)
             n_phys = max(len(batch.agents_action_index[a]) for a in agents)
             act_dim = n_phys + len(plugins)
             first = rank * n_env + g * per
@@ -359,7 +431,7 @@ def main():
                 batch.set_step_reset_mask(m[i % EPISODE] if i else None)
                 batch.step_batched(a[i % ACT_RING], obs, rew, term, trunc)
 
-        lead = args.preroll + args.warmup
+        lead = preroll + warmup
         for i in range(lead):
             one_step(i)
         if not on_cpu:
@@ -372,7 +444,7 @@ def main():
         t0 = time.perf_counter()
         if not on_cpu:
             ev0.record(batches[0].stream)
-        for i in range(lead, lead + args.steps):
+        for i in range(lead, lead + steps):
             one_step(i)
         if not on_cpu:
             ev1.record(batches[0].stream)
@@ -380,7 +452,7 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         if not on_cpu and groups == 1:
-            kernel_ms = ev0.elapsed_time(ev1) / args.steps
+            kernel_ms = ev0.elapsed_time(ev1) / steps
         if world > 1:
             t = torch.tensor([wall], dtype=torch.float64, device="cpu" if rehearsal else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -393,10 +465,45 @@ def main():
         n_phys = max(len(batches[0].agents_action_index[a]) for a in agents)
         return batches, wall, kernel_ms, stats, n_phys
 
-    batches, wall, kernel_ms, stats, n_phys = timed_run(args.groups)
+    def roofline_of(work, level_name, batch, language, n_env, steps, wall, kernel_ms):
+        """The bench line's `roofline` object for one measured workload (algorithmic bytes per env-step x the
+        env-steps of a launch / the launch's duration by HIP events, against the HBM peak)."""
+        m, n_agent = batch.model, len(work["agents"])
+        n_phys = max(len(batch.agents_action_index[a]) for a in work["agents"])
+        act_dim = n_phys + (1 if language else 0)
+        bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * batch.obs_dim, n_agent,
+                                                   n_slot=1 if language else 0)
+        cameras = bool(work.get("cameras"))
+        if cameras:                             # + the pixels written per env-step (SURVEY 8d config 5)
+            bytes_per += m.ncam * 64 * 64 * 3
+        if kernel_ms is None:                 # several groups / no GPU: the step time is the wall time's
+            kernel_ms = wall / steps * 1e3
+        achieved = bytes_per * n_env / (kernel_ms * 1e-3) / 1e9
+        traffic, source = None, None
+        # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes of this same
+        # command (profiles/, newest round first); `traffic_source` says so in the line
+        for rnd in ("r03", "r02"):
+            pmc = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_{level_name}.json")
+            if os.path.exists(pmc) and n_env == work.get("envs", ENVS_PER_GPU) and not on_cpu and language == (level_name == "two_agent"):
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                source = f"profiles/{os.path.basename(pmc)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this run"
+                break
+        kernels = batch.kernel
+        if cameras:
+            kernels += " + mjrl_camera_frames_kernel + mjrl_render_kernel"
+        if work.get("encoder"):
+            kernels += " + mjrl_encoder_conv_kernel + mjrl_encoder_dense_kernel"
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": source, "kernel": kernels, "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_env_step": bytes_per}
+
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = work.get("envs", ENVS_PER_GPU)
+    n_env = args.envs_per_gpu
+    batches, wall, kernel_ms, stats, n_phys = timed_run(work, language, n_env, args.steps, args.warmup, args.preroll, args.groups)
     batch = batches[0]
     obs_dim = batch.obs_dim
-    act_dim = n_phys + len(plugins)
+    act_dim = n_phys + (1 if language else 0)
     # frames (pre-roll and warm-up included) in which a copy ran into its contact / row cap, i.e. dropped work: must be zero
     overflows = [sum(c) for c in zip(*(b.cap_overflows() for b in batches))]
     if any(overflows):
@@ -407,26 +514,15 @@ def main():
     # double-buffered sampler does: the policy works on one half while the other half steps).
     double_buffered = None
     if world == 1 and args.groups == 1 and args.double_buffer and not on_cpu:
-        b2, wall2, _, _, _ = timed_run(2)
+        b2, wall2, _, _, _ = timed_run(work, language, n_env, args.steps, args.warmup, args.preroll, 2)
         double_buffered = {"groups": 2, "value": n_env * args.steps / wall2, "unit": "env-steps/s",
                            "ms_per_step": wall2 / args.steps * 1e3}
         for b in b2:
             b.close()
 
+    line = None
     if rank == 0:
         m = batch.model
-        bytes_per = algorithmic_bytes_per_env_step(m.nq, m.nv, n_agent * act_dim, n_agent * obs_dim, n_agent,
-                                                   n_slot=len(plugins))
-        if cameras:                             # + the pixels written per env-step
-            bytes_per += m.ncam * 64 * 64 * 3
-        if kernel_ms is None:                 # several groups / no GPU: the step time is the wall time's
-            kernel_ms = wall / args.steps * 1e3
-        achieved = bytes_per * n_env / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
-        pmc = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{args.level}.json")
-        if os.path.exists(pmc) and n_env == work.get("envs", ENVS_PER_GPU) and not on_cpu:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
             "metric": "env-steps/sec", "value": n_env * world * args.steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -435,7 +531,7 @@ def main():
             "config": {"workload": f"{work['what']}, {n_env} env copies per GPU, skipFrames=1, PGS solver, episodes of "
                                    f"{EPISODE} steps with the copies' episode phases uniform over 0..{EPISODE - 1} (in-launch "
                                    f"reset of the copies whose episode is over); action scatter + physics step + per-agent "
-                                   f"obs gather{' + Language channel' if plugins else ''} fused in one launch",
+                                   f"obs gather{' + Language channel' if language else ''} fused in one launch",
                        "level": args.level, "envs_per_gpu": n_env, "agents": n_agent, "nq": m.nq, "nv": m.nv,
                        "obs_dim": obs_dim, "act_dim": act_dim, "nconmax": m.nconmax, "njmax": m.njmax,
                        "preroll_steps": args.preroll, "episode_steps": EPISODE,
@@ -444,22 +540,36 @@ def main():
                        "max_ncon": int(stats[:, 0].max()), "max_nefc": int(stats[:, 1].max()),
                        "max_solver_sweeps": int(stats[:, 2].max()),
                        "cap_overflow_frames": list(overflows), "groups": args.groups},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": batch.kernel + (" + mjrl_camera_frames_kernel + mjrl_render_kernel" if cameras else ""),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per},
+            "roofline": roofline_of(work, args.level, batch, language, n_env, args.steps, wall, kernel_ms),
         }
         if double_buffered:
             line["double_buffered"] = double_buffered
-        if world == 1 and not args.no_cpu_baseline and not on_cpu:
-            scatter = np.full((n_agent, act_dim), -1, np.int64)
-            for k, a in enumerate(agents):
-                idx = batch.agents_action_index[a]
-                scatter[k, :len(idx)] = idx
-            line["cpu_baseline"] = cpu_baseline(level_file, batch.blob, scatter, n_agent, act_dim, n_phys,
-                                                language=bool(plugins))
-        print(json.dumps(line), flush=True)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
     batch.close()
+
+    # The other BASELINE configs, measured by the same command after the headline (one GPU, default workload only): the
+    # driver runs nothing but the default command, so this is where their numbers come from.  ~50 timed steps each after
+    # their own pre-roll (every copy at its own point of its episode, as above); the headline `value` / `config` are
+    # untouched by them.
+    if world == 1 and not on_cpu and args.level == "two_agent" and not args.no_extra_configs and args.groups == 1:
+        extra = []
+        for name, level_name, lang, envs in EXTRA_CONFIGS:
+            w = WORKLOADS[level_name]
+            bs, wall_x, kms_x, stats_x, _ = timed_run(w, lang, envs, args.extra_steps, 5, args.preroll, 1)
+            b = bs[0]
+            over = list(b.cap_overflows())
+            extra.append({
+                "name": name, "workload": f"{w['what']}, {envs} env copies, skipFrames=1, no plugins, staggered episodes",
+                "level": level_name, "envs_per_gpu": envs, "steps": args.extra_steps,
+                "value": envs * args.extra_steps / wall_x, "unit": "env-steps/s", "ms_per_step": wall_x / args.extra_steps * 1e3,
+                "obs_dim": b.obs_dim, "mean_ncon": float(stats_x[:, 0].mean()), "mean_nefc": float(stats_x[:, 1].mean()),
+                "mean_solver_sweeps": float(stats_x[:, 2].mean()), "cap_overflow_frames": over,
+                "roofline": roofline_of(w, level_name, b, lang, envs, args.extra_steps, wall_x, kms_x)})
+            b.close()
+        line["configs"] = extra
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
