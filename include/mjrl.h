@@ -107,6 +107,21 @@ int mjrl_reset_device(mjrl_env* env, const uint8_t* d_mask, double* d_obs);
  * (typically the done flags of the previous step); NULL turns it off.  The reset observation is not produced: the
  * step returns the observation after the first step of the new episode. */
 int mjrl_set_step_reset_mask(mjrl_env* env, const uint8_t* d_mask);
+/* (round 3) A mask byte of 2 resets the copy WITHOUT stepping it: no physics frame runs for it in that step, its rows of
+ * the step's outputs hold the reset observation (what reset() returns, mujoco_rl.py:314; slots owned by fused dynamics and
+ * camera latents: 0 / the encoding of the reset state's image), reward 0, termination and truncation clear; its step
+ * counter is 0 afterwards.
+ *
+ * Autoreset kept on the device -- what a vector-env adapter (Gymnasium VectorEnv / SB3 VecEnv over
+ * MuJoCo_Gym/wrappers.py:12-82's single-agent shim) needs: every step records per copy whether the copy's episode ended in
+ * it (a termination or truncation flag of any agent), and the NEXT step resets the copies so flagged --
+ *   mode 1: without stepping them (a mask byte of 2): Gymnasium's next-step autoreset, the step after an episode's end
+ *           returns the first observation of the new episode;
+ *   mode 2: and then steps them (a mask byte of 1): `env.reset(); env.step(a)` of the reference's sampling loops;
+ *   mode 0: off.
+ * No mask travels between host and device, on any of the step entry points.  mjrl_reset of a copy clears its flag; an
+ * explicit step-reset mask byte wins over it. */
+int mjrl_set_autoreset(mjrl_env* env, int mode);
 
 /* One step() of every copy: scatter actions, skip_frames physics steps, gather observations.
  * Replaces apply_action + mj_step loop (mujoco_parent.py:316-336) and get_observations (:380-392),

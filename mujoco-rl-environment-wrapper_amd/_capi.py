@@ -20,7 +20,7 @@ SYMBOLS = [
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
     "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
-    "mjrl_step_truncated", "mjrl_host_buffers", "mjrl_step_pinned",
+    "mjrl_step_truncated", "mjrl_host_buffers", "mjrl_step_pinned", "mjrl_set_autoreset",
     "mjrl_reset_device", "mjrl_set_step_reset_mask", "mjrl_set_tag_tables", "mjrl_set_env_base", "mjrl_set_variants",
     "mjrl_encoder_load", "mjrl_encode_device", "mjrl_encode_host", "mjrl_set_camera_obs",
 ]
@@ -81,6 +81,7 @@ def load():
     L.mjrl_step_truncated.argtypes = [vp, ctypes.c_int]
     L.mjrl_host_buffers.argtypes = [vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 5
     L.mjrl_step_pinned.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.mjrl_set_autoreset.argtypes = [vp, ctypes.c_int]
     _lib = L
     return L
 
@@ -265,6 +266,11 @@ class Handle:
     def set_step_reset_mask(self, d_mask: int | None):
         """Every later step launch first resets the copies flagged in the device byte mask (None: off)."""
         self._check(self._lib.mjrl_set_step_reset_mask(self._h, ctypes.c_void_p(d_mask or 0)))
+
+    def set_autoreset(self, mode: int):
+        """0 off; 1: a copy whose episode ended is reset by the next step without being stepped (Gymnasium next-step
+        autoreset); 2: it is reset and stepped in that launch (the reference's ``env.reset(); env.step(a)``)."""
+        self._check(self._lib.mjrl_set_autoreset(self._h, int(mode)))
 
     def step_device(self, d_actions, act_dim, skip_frames, d_obs=None, d_reward=None, d_term=None, d_trunc=None):
         """All pointers are integer device addresses (e.g. ``tensor.data_ptr()``) or None."""

@@ -37,9 +37,10 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
                                   int* timestep, const unsigned char* mask, int n_env, double* store, int store_per_env,
                                   const double* warm0, const double* sens0, const int32_t* gather, int n_agent, int obs_dim,
                                   double* obs, int* variant, int* episode, int n_variant, unsigned long long variant_seed,
-                                  int env_base) {
+                                  int env_base, unsigned char* auto_mask) {
   int env = blockIdx.x;
   if (env >= n_env || (mask && !mask[env])) return;
+  if (auto_mask && threadIdx.x == 0) auto_mask[env] = 0;      // (a reset by hand settles a pending autoreset)
   // A new episode.  The episode count of a copy always moves (it is part of the key of every on-device random choice,
   // so that episodes differ from one another the way the reference's random.randint draws do); with level variants on,
   // the copy also gets a new variant (random.choice, mujoco_parent.py:352).
@@ -253,6 +254,8 @@ struct mjrl_env {
   int enc_latent = 0, enc_tiles = 0, enc_relu = 1, enc_cap = 0, n_cam_obs = 0;
   std::vector<int32_t> h_agent_cam;
   const unsigned char* step_reset_mask = nullptr;   // caller-owned device mask of the in-launch reset (mjrl_set_step_reset_mask)
+  unsigned char* auto_mask = nullptr;               // [n_env] "the copy's episode ended in its last step" (mjrl_set_autoreset)
+  int auto_mode = 0;
   // tables
   int n_agent = 0, obs_dim = 0, scatter_mode = 0, max_steps = 1024;
   std::vector<int32_t> h_gather;                 // [n_agent][obs_dim]
@@ -329,7 +332,7 @@ void mjrl_destroy(mjrl_env* e) {
   void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
-                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->inertia, e->overflow};
+                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->inertia, e->overflow, e->auto_mask};
   for (void* p : ptrs) if (p) hipFree(p);
   void* pinned[] = {e->p_act, e->p_obs, e->p_rew, e->p_term, e->p_trunc};
   for (void* p : pinned) if (p) hipHostFree(p);
@@ -343,7 +346,7 @@ static int launch_reset(mjrl_env* e, const unsigned char* d_mask, double* d_obs 
   hipLaunchKernelGGL(mjrl_reset_kernel, dim3(e->n_env), dim3(64), 0, e->stream, e->dm, e->qpos, e->qvel, e->ctrl, e->warm,
                      e->sens, e->timestep, d_mask, e->n_env, e->store, e->n_agent * e->n_slot, e->reset_warm, e->reset_sens,
                      e->d_gather, e->n_agent, e->obs_dim, d_obs, e->variant, e->episode, e->n_variant, e->variant_seed,
-                     e->env_base);
+                     e->env_base, e->auto_mask);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }
@@ -854,6 +857,9 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.variant = e->variant; a.episode = e->episode; a.n_variant = e->n_variant; a.variant_seed = e->variant_seed;
   a.reset_mask = forward_only ? nullptr : e->step_reset_mask;
   a.reset_warm = e->reset_warm;
+  a.reset_sens = e->reset_sens;
+  a.auto_mask = forward_only ? nullptr : e->auto_mask;
+  a.auto_mode = e->auto_mode;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
   a.agent_body = e->d_agent_body; a.agent_obs_len = e->d_obs_len; a.store = e->store;
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
@@ -910,6 +916,21 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     if (int rc = mjrl_render_device(e, enc::IMG, enc::IMG, e->enc_rgb)) return rc;
     if (int rc = launch_encoder(e, e->enc_rgb, e->n_env * e->hm.ncam, nullptr, d_obs, e->enc_obs_row)) return rc;
   }
+  return 0;
+}
+
+int mjrl_set_autoreset(mjrl_env* e, int mode) {
+  MJRL_ENTER(e);
+  if (mode < 0 || mode > 2) MJRL_FAIL(e, 4, "set_autoreset: mode %d (0 off, 1 reset without a step, 2 reset then step)", mode);
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  if (mode == 0) {
+    if (e->auto_mask) { hipFree(e->auto_mask); e->auto_mask = nullptr; }
+    e->auto_mode = 0;
+    return 0;
+  }
+  if (!e->auto_mask) MJRL_HIP(e, hipMalloc(&e->auto_mask, (size_t)e->n_env));
+  MJRL_HIP(e, hipMemset(e->auto_mask, 0, (size_t)e->n_env));
+  e->auto_mode = mode;
   return 0;
 }
 

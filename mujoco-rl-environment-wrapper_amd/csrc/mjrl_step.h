@@ -145,8 +145,18 @@ struct StepArgs {
   // its state rows -- qpos0, zero velocity and controls, the warm start mj_forward leaves at the reset state (reset_warm,
   // computed once per model at create), step counter 0, an empty data store -- i.e. `env.reset(); env.step(a)` of the
   // reference's sampling loops (fps_benchmark.py:33-38, mujoco_rl.py:291-331) in one launch.
+  // A byte of 2 is a reset WITHOUT a step: the copy goes to the reset image, no physics frame runs, the observation is
+  // the reset observation (what reset() returns, mujoco_rl.py:314), reward 0, flags clear, step counter 0 -- the step a
+  // Gymnasium vector env takes for a copy whose episode ended in the step before ("next-step" autoreset).
   const unsigned char* reset_mask;   // [n_env] device bytes, may be null
   int first_frame;                   // 1 in the first launch of a step (a flagged copy loads the reset image only there)
+  // Autoreset kept by the kernel itself (mjrl_set_autoreset): auto_mask[e] = the copy's episode ended in its last step
+  // (a termination or truncation flag of any agent), written by every step's last launch; a copy whose byte is set is
+  // reset by the next step -- auto_mode 1: without a step (Gymnasium next-step autoreset), 2: reset, then step
+  // (`env.reset(); env.step(a)` of the reference's sampling loops).  No host involvement, no mask to upload.
+  unsigned char* auto_mask;          // [n_env], may be null
+  int auto_mode;
+  const real* reset_sens;            // [nsensordata] sensor readings of the reset image
   // Runge-Kutta (<option integrator="RK4">, benchmarking/levels/Ant.xml:3): a physics frame is four launches, one forward
   // pass each; rk_stage 0..3 says which, rk [n_env][nq + 3 nv] keeps the frame's start state and the weighted sums of the
   // passes' derivatives between them (x0 qpos | x0 qvel | sum b_i qvel_i | sum b_i qacc_i)
@@ -2506,7 +2516,9 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
   // state in: the copy's rows (one element per lane and array, a second one of qpos when nq > 64), fetched whether or
   // not the copy is flagged for an in-launch reset -- the flag arrives with them
   const bool may_reset = a.reset_mask != nullptr && !a.forward_only;
-  const int r_mask = may_reset ? (int)a.reset_mask[env] : 0;
+  const bool may_auto = a.auto_mask != nullptr && !a.forward_only;
+  int r_mask = may_reset ? (int)a.reset_mask[env] : 0;
+  const int r_auto = may_auto ? (int)a.auto_mask[env] : 0;
   const int r_ts = a.forward_only ? 0 : a.timestep[env];
   const int r_ep = (a.episode && a.n_op > 0) ? a.episode[env] : 0;
   const real r_qpos0 = a.qpos[(size_t)env * m.nq + (L < m.nq ? L : 0)];
@@ -2541,7 +2553,10 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     if (a.n_agent > 0) { len_reg = a.agent_obs_len[L < a.n_agent ? L : 0]; body_reg = a.agent_body[L < a.n_agent ? L : 0]; }
   }
   // -- every load of the prologue is in flight; from here on their values are used --
-  const bool resetting = may_reset && wv::first_int(r_mask) != 0;
+  if (may_auto && r_mask == 0 && r_auto != 0) r_mask = a.auto_mode == 1 ? 2 : 1;      // (an explicit flag wins)
+  const int reset_kind = (may_reset || may_auto) ? wv::first_int(r_mask) : 0;
+  const bool resetting = reset_kind != 0;
+  const bool reset_only = reset_kind == 2;       // to the reset image, no physics frame (see StepArgs::reset_mask)
   const int ts = (a.forward_only || resetting) ? 0 : wv::first_int(r_ts);
   // the episode this step belongs to: an in-launch reset starts the next one
   const unsigned long long ep_key = (unsigned long long)(unsigned)(wv::first_int(r_ep) + (resetting ? 1 : 0)) << 32;
@@ -2556,10 +2571,11 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     if (L < m.nv) { S[l.qvel + L] = r_qvel; S[l.warm + L] = r_warm; }
     if (L < m.nu) S[l.ctrl + L] = r_ctrl;
   }
+  if (reset_only) MJ_FOR(i, m.nsensordata) S[l.sens + i] = a.reset_sens[i];     // (every launch of such a step: no frame computes them)
   stage_constants(m, l, S, L, TR);
   wv::sync();
   // scatter the physical part of every agent's action (mujoco_parent.py:323-332)
-  if (a.actions && a.scatter) {
+  if (a.actions && a.scatter && !reset_only) {
     if (act_in_lanes) {
       if (L < n_act_row && sc_reg >= 0) { if (a.scatter_mode == 0) S[l.ctrl + sc_reg] = act_reg; else S[l.qvel + sc_reg] = act_reg; }
     } else {
@@ -2585,7 +2601,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
   // instead of once at the top of the kernel for all stages: kept that long they do not fit the scalar registers, and
   // every use fetched its mask back from a spilled register with two v_readlane.
 #define MJ_L wv::opaque_lane(L)
-  if (a.skip_frames) {
+  if (a.skip_frames && !reset_only) {
     stage_kinematics(m, l, K, KK, S, MJ_L);
     MJ_STAMP(ST_KIN)
     stage_com_inertia(m, l, K, KK, CK, S, MJ_L);
@@ -2680,7 +2696,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     MJ_FOR(i, m.nu) a.ctrl[(size_t)env * m.nu + i] = S[l.ctrl + i];
   }
   if (a.forward_only != 2) MJ_FOR(i, m.nv) a.warm[(size_t)env * m.nv + i] = S[l.warm + i];
-  if (m.integrator == 0 || a.rk_stage == 0) {
+  if (m.integrator == 0 || a.rk_stage == 0 || reset_only) {
     MJ_FOR(i, m.nsensordata) a.sensordata[(size_t)env * m.nsensordata + i] = S[l.sens + i];
   } else if (!a.more_frames) {        // the last pass of a Runge-Kutta frame: the observation gather reads the first pass's sensors
     MJ_FOR(i, m.nsensordata) S[l.sens + i] = a.sensordata[(size_t)env * m.nsensordata + i];
@@ -2692,7 +2708,9 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     MJ_FOR(it, a.n_agent * a.obs_dim) {
       int code = it < 64 ? EK.gcode[0] : (it < 128 ? EK.gcode[1] : -3);
       if (code == -3) code = a.gather[it];
-      if (code == -2) continue;        // slot owned by a fused dynamics op (written below by lane 0)
+      // slot owned by a fused dynamics op (written below) or by the camera encoder; a reset without a step runs no op:
+      // the slot reads 0 like in the reset observation of the array path (camera latents are written behind the step)
+      if (code == -2 && !reset_only) continue;
       real v = 0;
       if (code >= 0) {
         int kind = code >> 24, idx = code & 0xFFFFFF;
@@ -2704,9 +2722,9 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
   MJ_STAMP_ONLY(ST_STORE)
   if (a.stats && a.skip_frames && L < 4) {
     const int* I = (const int*)(S + l.ints);
-    a.stats[4 * (size_t)env + L] = I[L == 0 ? I_NCON : (L == 1 ? I_NEFC : (L == 2 ? I_NITER : I_WARN))];
+    a.stats[4 * (size_t)env + L] = reset_only ? 0 : I[L == 0 ? I_NCON : (L == 1 ? I_NEFC : (L == 2 ? I_NITER : I_WARN))];
   }
-  if (a.overflow && !a.forward_only && a.skip_frames && L == 0) {
+  if (a.overflow && !a.forward_only && a.skip_frames && !reset_only && L == 0) {
     const int warn = ((const int*)(S + l.ints))[I_WARN];
     if (warn & 1) wv::atomic_add(a.overflow + 0, 1ull);
     if (warn & 2) wv::atomic_add(a.overflow + 1, 1ull);
@@ -2716,7 +2734,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
 #define MJ_FILE_WORK                                                                                         \
   if (a.lpt_count_out && L == 0) {                                                                           \
     const int* Iw = (const int*)(S + l.ints);                                                                \
-    unsigned work = (unsigned)(Iw[I_NEFC] * Iw[I_NITER]);                                                    \
+    unsigned work = reset_only ? 0u : (unsigned)(Iw[I_NEFC] * Iw[I_NITER]);                                  \
     int wb = work ? 32 - __builtin_clz(work) : 0;           /* bit length */                                 \
     if (wb > LPT_BUCKETS - 1) wb = LPT_BUCKETS - 1;                                                          \
     wv::atomic_add_noret(a.lpt_count_out + wb, 1);                                                           \
@@ -2734,9 +2752,36 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     MJ_TIMELINE
     return;
   }
+  if (reset_only) {
+    // the step of a copy that is only being reset: reward 0, flags clear, an empty data store, step counter 0, a new
+    // episode -- what reset() leaves (mujoco_rl.py:291-331); the observation above is the reset observation
+    if (L < a.n_agent) {
+      if (a.reward) a.reward[(size_t)env * a.n_agent + L] = 0.0;
+      if (a.term) a.term[(size_t)env * a.n_agent + L] = 0;
+      if (a.trunc) a.trunc[(size_t)env * a.n_agent + L] = 0;
+    }
+    if (a.store) MJ_FOR(k, a.n_agent * a.n_slot) a.store[(size_t)env * a.n_agent * a.n_slot + k] = __builtin_nan("");
+    if (L == 0) {
+      a.timestep[env] = 0;
+      if (a.auto_mask) a.auto_mask[env] = 0;
+      if (a.episode) {
+        const int ep = a.episode[env] + 1;
+        a.episode[env] = ep;
+        if (a.variant)
+          a.variant[env] = pick_of(mix64(a.variant_seed, (unsigned long long)(a.env_base + env), 0ull, (unsigned long long)ep, 2), a.n_variant);
+      }
+    }
+    MJ_STAMP(ST_TAIL)
+    if constexpr (DIAG) if (stamps && L < N_STAMPS) wv::atomic_add(a.stamps + L, stamps->mine);
+    MJ_FILE_WORK
+    MJ_TIMELINE
+    return;
+  }
   // truncation is evaluated before the counter moves (mujoco_rl.py:279,288)
+  const bool truncated = ts >= a.max_steps;
+  bool ended = truncated;                     // the copy's episode ended in this step (StepArgs::auto_mask)
   MJ_FOR(ag, a.n_agent) {
-    if (a.trunc) a.trunc[(size_t)env * a.n_agent + ag] = ts >= a.max_steps;
+    if (a.trunc) a.trunc[(size_t)env * a.n_agent + ag] = truncated;
   }
   // Rewards start at 0, terminations at false (mujoco_rl.py:262-263); the fused ops then run like the plugin loop.
   // With the program staged in LDS (or no program) LANE ag IS AGENT ag: the reward and the flag are two registers, every
@@ -2844,6 +2889,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
       if (a.reward) a.reward[(size_t)env * a.n_agent + ag] = rew;
       if (a.term) a.term[(size_t)env * a.n_agent + ag] = term;
     }
+    if (a.auto_mask) ended = ended || wv::ballot(on && term) != 0ull;
   } else if (L == 0) {
     // rewards start at 0, terminations at false (mujoco_rl.py:262-263); the fused ops then run like the plugin loop
     real rew[MAX_AGENT];
@@ -2938,9 +2984,12 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     for (int ag = 0; ag < a.n_agent; ag++) {
       if (a.reward) a.reward[(size_t)env * a.n_agent + ag] = rew[ag];
       if (a.term) a.term[(size_t)env * a.n_agent + ag] = term[ag];
+      ended = ended || term[ag];
     }
+    if (a.auto_mask) a.auto_mask[env] = ended;        // (lane 0 alone ran the program: it writes the flag itself)
   }
   wv::sync();
+  if (a.auto_mask && L == 0 && (a.n_op == 0 || ops_staged)) a.auto_mask[env] = ended;
   if (ops_staged && a.store && L < n_store_row) a.store[(size_t)env * n_store_row + L] = S[l.bias + t_store + L];
   if (L == 0) a.timestep[env] = ts + 1;
   if (resetting && a.episode && L == 0) {          // a new episode (and a new level variant), as mjrl_reset counts / chooses it

@@ -311,7 +311,7 @@ def test_wrappers():
         GymnasiumWrapper(MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS}), "sender")
     single.close()
     vec = BatchedVectorEnv(MuJoCoRL({"xmlPath": levels.level_path("single_agent.xml"), "agents": ["sender"],
-                                     "numEnvs": 7, "maxSteps": 5}))
+                                     "numEnvs": 7, "maxSteps": 5}), autoreset="same_step")      # (the SB3 convention)
     obs, _ = vec.reset()
     assert obs.shape == (7, 30)
     first = obs.copy()

@@ -482,34 +482,7 @@ def test_per_copy_level_variants(tmp_path):
     other.close()
 
 
-# --------------------------------------------------------------------------- vector-env adapter against the oracle (8f rank 1)
-def test_batched_vector_env_follows_the_oracle_through_autoresets():
-    from mjrl_amd.wrappers import BatchedVectorEnv
-    n_env, horizon = 5, 6
-    vec = BatchedVectorEnv(MuJoCoRL({"xmlPath": levels.level_path("single_agent.xml"), "agents": ["sender"],
-                                     "numEnvs": n_env, "maxSteps": horizon}))
-    obs, _ = vec.reset()
-    env = vec.environment
-    oras = [OracleEnv(env._blob) for _ in range(n_env)]
-    first = np.stack([np.concatenate([o.sensordata[[0]], o.qpos, o.qvel]) for o in oras])
-    assert np.allclose(obs, first, atol=1e-12)
-    rng = np.random.default_rng(6)
-    idx = env.agents_action_index["sender"]
-    for step in range(1, 3 * horizon + 3):
-        act = rng.uniform(-1, 1, (n_env, 8))
-        obs, rew, term, trunc, info = vec.step(act)
-        for e, o in enumerate(oras):
-            o.ctrl[idx] = act[e]
-            o.step()
-        expect = np.stack([np.concatenate([o.sensordata[[0]], o.qpos, o.qvel]) for o in oras])
-        if step % (horizon + 1) == 0:           # call max_steps + 1 truncates (mujoco_rl.py:412): autoreset
-            assert trunc.all() and np.allclose(info["final_observation"], expect, atol=1e-9)
-            for o in oras:
-                o.reset()
-            assert np.allclose(obs, first, atol=1e-12)
-        else:
-            assert not trunc.any() and np.allclose(obs, expect, atol=1e-9)
-    vec.close()
+# (the vector-env adapter against the oracle through autoresets: tests/test_gpu_parity_r3.py, round 3 moved it onto the fast path)
 
 
 # --------------------------------------------------------------------------- box-box contacts

@@ -191,3 +191,98 @@ def test_diagnostic_launches_give_the_production_bits():
     tl = b.step_timeline()
     assert (tl[:, 1] > tl[:, 0]).all() and sorted(tl[:, 2].tolist()) == list(range(32))
     a.close(); b.close()
+
+
+# --------------------------------------------------------------------------- vector-env adapter on the fast path (8f rank 1)
+def _oracle_obs(o):
+    return np.concatenate([o.sensordata[[0]], o.qpos, o.qvel])
+
+
+@pytest.mark.parametrize("mode", ["next_step", "reset_then_step", "same_step"])
+@pytest.mark.parametrize("path", ["numpy", "torch"])
+def test_batched_vector_env_follows_the_oracle_through_autoresets(mode, path):
+    """SURVEY 8f rank 1 (MuJoCo_Gym/wrappers.py:12-82 as a vector env): ``BatchedVectorEnv`` over ``mjrl_step_pinned``
+    (numpy in / out) and ``mjrl_step_device`` (torch in / out), the autoreset kept by the kernel (mjrl_set_autoreset).  Every
+    copy follows its own CPU oracle through three episodes; the three autoreset conventions return what their
+    definitions say at the episode boundaries (call max_steps + 1 truncates, mujoco_rl.py:412)."""
+    import torch
+    from mjrl_amd.wrappers import BatchedVectorEnv
+    n_env, horizon = 5, 6
+    vec = BatchedVectorEnv(MuJoCoRL({"xmlPath": levels.level_path("single_agent.xml"), "agents": ["sender"],
+                                     "numEnvs": n_env, "maxSteps": horizon}), autoreset=mode)
+    assert vec.observation_space.shape == (n_env, 30) and vec.action_space.shape == (n_env, 8)
+    obs, _ = vec.reset()
+    env = vec.environment
+    oras = [OracleEnv(env._blob) for _ in range(n_env)]
+    first = np.stack([_oracle_obs(o) for o in oras])
+    assert np.allclose(obs, first, atol=1e-12)
+    rng = np.random.default_rng(6)
+    idx = env.agents_action_index["sender"]
+    host = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+    t_in_episode, pending = 0, False           # oracle-side bookkeeping of the convention under test
+    for step in range(1, 3 * horizon + 8):
+        act = rng.uniform(-1, 1, (n_env, 8))
+        out = vec.step(torch.from_numpy(act).cuda() if path == "torch" else act)
+        obs, rew, term, trunc, info = host(out[0]), host(out[1]), host(out[2]), host(out[3]), out[4]
+        assert not term.any() and not rew.any()
+        if pending and mode == "next_step":
+            # the copies are reset instead of stepped: the reset observation, flags clear, the action ignored
+            for o in oras:
+                o.reset()
+            assert np.allclose(obs, first, atol=1e-12) and not trunc.any()
+            pending, t_in_episode = False, 0
+            continue
+        if pending and mode == "reset_then_step":
+            for o in oras:
+                o.reset()
+            pending, t_in_episode = False, 0
+        for e, o in enumerate(oras):
+            o.ctrl[idx] = act[e]
+            o.step()
+        expect = np.stack([_oracle_obs(o) for o in oras])
+        t_in_episode += 1
+        if t_in_episode == horizon + 1:          # the truncated call
+            assert trunc.all()
+            if mode == "same_step":
+                assert np.allclose(host(info["final_observation"]), expect, atol=1e-9) and host(info["_final_observation"]).all()
+                assert np.allclose(obs, first, atol=1e-12)
+                for o in oras:
+                    o.reset()
+                t_in_episode = 0
+            else:
+                assert np.allclose(obs, expect, atol=1e-9)
+                pending = True
+        else:
+            assert not trunc.any() and np.allclose(obs, expect, atol=1e-9), (step, t_in_episode)
+    vec.close()
+
+
+def test_vector_env_autoreset_is_per_copy_and_runs_the_fused_channel():
+    """Copies that end their episodes at different steps are reset one by one (next-step convention) while the others
+    keep stepping, on the 2-agent level with the fused Language channel driven through the adapter: the ended copy's
+    row is the reset observation with the channel's slot at 0, its data store is empty, and it matches a fresh oracle
+    from there on."""
+    from mjrl_amd.dynamics import Language
+    from mjrl_amd.wrappers import BatchedVectorEnv
+    n_env = 6
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": n_env, "maxSteps": 5,
+                    "environmentDynamics": [Language]})
+    vec = BatchedVectorEnv(env, agent="sender")
+    vec.reset()
+    # stagger the copies: copy e starts e steps into its episode
+    env._handle.set_field("timestep", np.arange(n_env, dtype=np.int32))
+    rng = np.random.default_rng(0)
+    ended_at = {}
+    for step in range(12):
+        act = rng.uniform(-1, 1, (n_env, 9)); act[:, 8] = 2.5
+        obs, rew, term, trunc, _ = vec.step(act)
+        obs, trunc = obs.copy(), trunc.copy()
+        for e in range(n_env):
+            if e in ended_at and ended_at[e] == step - 1:
+                assert not trunc[e] and np.array_equal(obs[e, 1:31], env._compiled.qpos0) and obs[e, 59] == 0.0
+            if trunc[e]:
+                ended_at[e] = step
+    assert len(ended_at) == n_env and len(set(ended_at.values())) > 1
+    ts = env._handle.get_field("timestep")
+    assert len(set(ts.tolist())) > 1                     # the copies are still at different points of their episodes
+    vec.close()
