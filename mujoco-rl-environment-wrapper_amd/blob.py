@@ -18,13 +18,13 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 15
+VERSION = 16
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
                "ndesc", "nchild", "maxdofdepth", "pair_kmax", "maxtreedof", "has_accel", "nitemmax", "rowmap", "nfactor", "npass",
                "ntab", "maxkdepth", "nchunk", "ntp", "nchunk_plane", "nchunk_box", "nchunk_boxbox",
-               "reserved_size"]        # (an even number of size fields keeps the float64 sections 8-byte aligned)
+               "nlight"]               # (an even number of size fields keeps the float64 sections 8-byte aligned)
 OPT_FIELDS = ["timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "impratio", "meaninertia",
               "reserved"]
 
@@ -42,6 +42,12 @@ F64_FIELDS = [
     ("geom_solmix", "ngeom"), ("geom_rbound", "ngeom"), ("geom_rgba", "ngeom*4"),
     ("site_pos", "nsite*3"), ("site_quat", "nsite*4"), ("site_size", "nsite*3"),
     ("cam_pos", "ncam*3"), ("cam_quat", "ncam*4"), ("cam_fovy", "ncam"),
+    # rendering only (layout 16): material properties per geom (specular, shininess, emission), the scene's lights and
+    # the headlight (active | ambient 3 | diffuse 3 | specular 3)
+    ("geom_matprop", "ngeom*3"),
+    ("light_pos", "nlight*3"), ("light_dir", "nlight*3"), ("light_attenuation", "nlight*3"), ("light_cutoff", "nlight"),
+    ("light_exponent", "nlight"), ("light_ambient", "nlight*3"), ("light_diffuse", "nlight*3"), ("light_specular", "nlight*3"),
+    ("headlight", "10"),
     ("act_gear", "nu"), ("act_ctrlrange", "nu*2"),
     ("sensor_cutoff", "nsensor"),
     ("pair_margin", "npair"), ("pair_bound", "npair"), ("pair_gap", "npair"), ("pair_mu", "npair"), ("tp_reach", "ntp"),
@@ -66,6 +72,7 @@ I32_FIELDS = [
     ("factor_sched", "nfactor"), ("row_dof", "64"), ("solve_b", "1024"), ("solve_f", "1024"), ("dof_lane", "nv"),
     ("lds_tab", "ntab"), ("pair_word", "npair"), ("pair_reach", "npair"), ("dof_descmask", "nv*2"),
     ("body_kparent", "nbody"), ("body_kdepth", "nbody"), ("chunk_info", "nchunk"), ("tp_root", "ntp*2"),
+    ("light_bodyid", "nlight"), ("light_directional", "nlight"),
 ]
 
 
@@ -73,7 +80,6 @@ def _sizes(model) -> dict:
     s = {k: int(getattr(model, k)) for k in SIZE_FIELDS if hasattr(model, k) and not k.startswith("reserved")
          and k != "maxdepth"}
     s["maxdepth"] = int(model.body_depth.max()) if model.nbody else 0
-    s["reserved_size"] = 0
     assert len(SIZE_FIELDS) % 2 == 0
     # narrow-phase work items one candidate pair can need (box-box 16, plane-box 8, capsule-capsule 4, capsule ends 2);
     # 16 also tells the kernels that the level has box-box pairs at all (the routine is compiled out of a specialised
@@ -136,6 +142,7 @@ def same_physics(blob_a: bytes, blob_b: bytes) -> bool:
     if len(blob_a) != len(blob_b):
         return False
     lo, hi = section_range(blob_a, "geom_rgba")
+    assert [f for f, _ in F64_FIELDS][[f for f, _ in F64_FIELDS].index("geom_rgba") - 1] == "geom_rbound"
     if blob_a[:lo] != blob_b[:lo] or blob_a[hi:] != blob_b[hi:]:
         return False
     ca = np.frombuffer(blob_a[lo:hi], np.float64).reshape(-1, 4)

@@ -75,11 +75,23 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
 // right, +y up, vertical field of view fovy, rows stored bottom-up (glReadPixels order), uint8 RGB.
 //
 // Two kernels.  mjrl_camera_frames_kernel, one wave per env copy: body and geom frames from the current qpos (the step
-// kernel's kinematics), written as a scene row  [geom pos 3G | geom matrix 9G | camera pos 3C | camera matrix 9C]  to HBM.
+// kernel's kinematics), written as a scene row  [geom pos 3G | geom matrix 9G | camera pos 3C | camera matrix 9C |
+// light pos 3N | light dir 3N]  to HBM.
 // mjrl_render_kernel, grid (n_env, ncam * tiles): a wave renders a group of 8x8 pixel blocks of one camera of one copy
 // from that row.  (Round 1 let every render wave redo the copy's kinematics behind the 20 KB step image: 16 tiles x 2
 // cameras repeated it 32 times per copy and the image held a CU to 7 waves.)
-inline __host__ __device__ int scene_doubles(const DevModel& m) { return 12 * m.ngeom + 12 * m.ncam; }
+inline __host__ __device__ int scene_doubles(const DevModel& m) { return 12 * m.ngeom + 12 * m.ncam + 6 * m.nlight; }
+// x^y for x in [0, 1], y >= 0 as exp2(y log2 x) on the transcendental unit (v_log_f32, v_exp_f32): three instructions
+// where the library's powf -- also behind __powf -- is 170; a tenth of a colour level at worst after the 255 scaling
+__device__ __forceinline__ float fast_pow(float x, float y) {
+  return y > 0.0f ? __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)) : 1.0f;
+}
+#ifndef MJRL_RENDER_VARIANT
+#define MJRL_RENDER_VARIANT 0        // (experiments: 1 = round 2's shading, 2 = byte stores)
+#endif
+// one light of the ray kernel in LDS (floats): camera-relative position 3 | direction 3 | attenuation 3 | cos(cutoff) |
+// exponent | ambient 3 | diffuse 3 | specular 3 | directional
+enum { LIGHT_FLOATS = 21 };
 
 __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, const double* qpos, int n_env, double* scene) {
   extern __shared__ double lds[];
@@ -114,6 +126,12 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
     M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
     for (int k = 0; k < 9; k++) out[12 * m.ngeom + 3 * m.ncam + 9 * cam + k] = cm.m[k];
   }
+  for (int li = L; li < m.nlight; li += 64) {        // the level's lights ride on their bodies
+    const int body = m.light_bodyid[li];
+    const Quat bq = ldq(S + l.xquat + 4 * body);
+    st3(out + 12 * m.ngeom + 12 * m.ncam + 3 * li, ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.light_pos + 3 * li)));
+    st3(out + 12 * m.ngeom + 12 * m.ncam + 3 * m.nlight + 3 * li, rot(bq, ld3(m.light_dir + 3 * li)));
+  }
 }
 
 // (Single precision: the kernel is bound by vector-instruction issue -- 93 M VALU instructions per 512 x 2 cameras,
@@ -130,17 +148,57 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   float* GP = ldsf;
   float* GM = ldsf + 3 * m.ngeom;
   float* GS = ldsf + 12 * m.ngeom;
+  float* MP = ldsf + 15 * m.ngeom;            // material properties: specular, 128 x shininess, emission
+  float* GC = ldsf + 18 * m.ngeom;            // the copy's geom colours (its level variant's)
+  float* LT = ldsf + 21 * m.ngeom;            // light table: entry 0 the headlight, then the level's lights
   const double* row = scene + (size_t)env * scene_doubles(m);
   for (int i = L; i < 12 * m.ngeom; i += 64) ldsf[i] = (float)row[i];
-  for (int i = L; i < 3 * m.ngeom; i += 64) GS[i] = (float)m.geom_size[i];
+  for (int i = L; i < 3 * m.ngeom; i += 64) {
+    GS[i] = (float)m.geom_size[i];
+    MP[i] = (float)m.geom_matprop[i] * (i % 3 == 1 ? 128.0f : 1.0f);
+  }
   // the camera, and every geom's position relative to it (the subtraction in double: positions are metres from the
   // arena's origin, differences are what the rays see)
   const double cpx = row[12 * m.ngeom + 3 * cam], cpy = row[12 * m.ngeom + 3 * cam + 1], cpz = row[12 * m.ngeom + 3 * cam + 2];
-  float cm[9];
-  for (int k = 0; k < 9; k++) cm[k] = (float)row[12 * m.ngeom + 3 * m.ncam + 9 * cam + k];
+  // (the camera matrix lives in LDS, behind the light table: nine wave-uniform floats would otherwise sit in nine vector
+  // registers for the whole kernel -- there is no scalar float unit to keep them in -- and cost a wave per SIMD)
+  float* cm = LT + LIGHT_FLOATS * (m.nlight + 1);
+  if (L < 9) cm[L] = (float)row[12 * m.ngeom + 3 * m.ncam + 9 * cam + L];
   wv::sync();
   for (int g = L; g < m.ngeom; g += 64) {       // camera-relative positions
     GP[3 * g] = (float)(row[3 * g] - cpx); GP[3 * g + 1] = (float)(row[3 * g + 1] - cpy); GP[3 * g + 2] = (float)(row[3 * g + 2] - cpz);
+  }
+  // the copy's colours: its level variant's (mjrl_set_variants), else the model's
+  const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
+  auto rgba_of = [&](int g, int k) { return (float)(rgba_tab ? rgba_tab[4 * g + k] : (double)m.geom_rgba[4 * g + k]); };
+  for (int i = L; i < 3 * m.ngeom; i += 64) GC[i] = rgba_of(i / 3, i % 3);
+  if (L == 0) {
+    // the headlight (visual/headlight) as entry 0: directional, shining along the viewing direction (L = V = the
+    // camera's +z axis); an inactive one contributes nothing
+    float* T = LT;
+    const float on = m.headlight[0] != 0 ? 1.0f : 0.0f;
+    T[0] = T[1] = T[2] = 0.0f;
+    T[3] = -cm[2]; T[4] = -cm[5]; T[5] = -cm[8];
+    T[6] = 1.0f; T[7] = T[8] = 0.0f; T[9] = -2.0f; T[10] = 0.0f;
+    for (int k = 0; k < 9; k++) T[11 + k] = on * (float)m.headlight[1 + k];
+    T[20] = 1.0f;
+  }
+  for (int li = L; li < m.nlight; li += 64) {   // the level's lights, camera-relative
+    float* T = LT + LIGHT_FLOATS * (li + 1);
+    const double* lp = row + 12 * m.ngeom + 12 * m.ncam + 3 * li;
+    const double* ld = row + 12 * m.ngeom + 12 * m.ncam + 3 * m.nlight + 3 * li;
+    T[0] = (float)(lp[0] - cpx); T[1] = (float)(lp[1] - cpy); T[2] = (float)(lp[2] - cpz);
+    for (int k = 0; k < 3; k++) {
+      T[3 + k] = (float)ld[k];
+      T[6 + k] = (float)m.light_attenuation[3 * li + k];
+      T[11 + k] = (float)m.light_ambient[3 * li + k];
+      T[14 + k] = (float)m.light_diffuse[3 * li + k];
+      T[17 + k] = (float)m.light_specular[3 * li + k];
+    }
+    // (cutoff >= 180: no cone -- a cosine no (-L . dir) can fall below)
+    T[9] = m.light_cutoff[li] < 180.0 ? (float)cos(m.light_cutoff[li] * 3.14159265358979323846 / 180.0) : -2.0f;
+    T[10] = (float)m.light_exponent[li];
+    T[20] = m.light_directional[li] ? 1.0f : 0.0f;
   }
   wv::sync();
   const F3 origin = f3(0, 0, 0);
@@ -155,9 +213,6 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   auto pixel_ray = [&](float px, float py) {        // px, py in pixel units, pixel centres at +0.5
     return normalizedf(mulf(cm, f3((px * inv_w - 1.0f) * t * aspect, (py * inv_h - 1.0f) * t, -1.0f)));
   };
-  // the copy's colours: its level variant's (mjrl_set_variants), else the model's
-  const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
-  auto rgba_of = [&](int g, int k) { return (float)(rgba_tab ? rgba_tab[4 * g + k] : (double)m.geom_rgba[4 * g + k]); };
   const bool my_geom = L < m.ngeom && rgba_of(L < m.ngeom ? L : 0, 3) != 0;
   const int my_type = my_geom ? m.geom_type[L] : -1;
   const float my_rb = my_geom ? (float)m.geom_rbound[L] * (1.0f + 1e-5f) + 1e-5f : 0.0f;     // (rounded up)
@@ -201,17 +256,71 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
     }
     unsigned char out[3] = {0, 0, 0};
     if (hit >= 0) {
-      const F3 n = geom_normalf(m.geom_type[hit], ldf3(GP + 3 * hit), GM + 9 * hit, ldf3(GS + 3 * hit), vec * best);
-      const float shade = 0.4f + 0.6f * fmaxf(-dotf(n, vec), 0.0f);
-      for (int k = 0; k < 3; k++)
-        out[k] = (unsigned char)(255.0f * fminf(fmaxf(rgba_of(hit, k), 0.0f), 1.0f) * shade + 0.5f);
+      // OpenGL's fixed-function lighting equation with the parameters MuJoCo documents (oracle/ora_step.c ora_shade, the
+      // same arithmetic in double): emission + per light att * spot * (ambient + max(n.L, 0) diffuse + (n.H)^shininess
+      // specular), the geom's rgba as ambient and diffuse material colour, clamped once at the end
+      const F3 P = vec * best;
+      const F3 n = geom_normalf(m.geom_type[hit], ldf3(GP + 3 * hit), GM + 9 * hit, ldf3(GS + 3 * hit), P);
+      const float spec_m = MP[3 * hit], shin = MP[3 * hit + 1], emis = MP[3 * hit + 2];
+      const F3 mat = ldf3(GC + 3 * hit);
+      const F3 V = f3(-LT[3], -LT[4], -LT[5]);               // towards the viewer (at infinity): the camera's +z axis
+      float col[3] = {emis * mat.x, emis * mat.y, emis * mat.z};
+#if MJRL_RENDER_VARIANT == 1
+      { const float shade = 0.4f + 0.6f * fmaxf(-dotf(n, vec), 0.0f); col[0] = mat.x * shade; col[1] = mat.y * shade; col[2] = mat.z * shade; }
+      for (int li = 0; li < 0; li++) {
+#else
+#pragma unroll 1
+      for (int li = 0; li <= m.nlight; li++) {
+#endif
+        const float* T = LT + LIGHT_FLOATS * li;
+        const F3 dir = ldf3(T + 3);
+        F3 Ld = dir * -1.0f;
+        float scale = 1.0f;
+        if (T[20] == 0.0f) {
+          Ld = ldf3(T) - P;
+          const float d2 = dotf(Ld, Ld);
+          if (d2 < 1e-30f) continue;
+          const float inv = rsqrtf(d2), dist = d2 * inv;
+          Ld = Ld * inv;
+          scale = 1.0f / (T[6] + T[7] * dist + T[8] * d2);
+          const float c = -dotf(Ld, dir);
+          if (T[9] > -1.5f) scale = c < T[9] ? 0.0f : scale * fast_pow(fmaxf(c, 0.0f), T[10]);
+        }
+        float nl = dotf(n, Ld), sp = 0.0f;
+        if (nl > 0.0f) {
+          const F3 H = Ld + V;
+          const float hh = dotf(H, H), nh = hh > 1e-30f ? dotf(n, H) * rsqrtf(hh) : 0.0f;
+          sp = nh > 0.0f ? fast_pow(nh, shin) * spec_m : 0.0f;
+        } else {
+          nl = 0.0f;
+        }
+        col[0] += scale * (T[11] * mat.x + nl * T[14] * mat.x + sp * T[17]);
+        col[1] += scale * (T[12] * mat.y + nl * T[15] * mat.y + sp * T[18]);
+        col[2] += scale * (T[13] * mat.z + nl * T[16] * mat.z + sp * T[19]);
+      }
+      for (int k = 0; k < 3; k++) out[k] = (unsigned char)(255.0f * fminf(fmaxf(col[k], 0.0f), 1.0f) + 0.5f);
     }
-    if (inside) { img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2]; }
+    // A block's 8 rows of 8 pixels are 8 x 24 bytes: written as 48 dwords, 6 per row, each put together from two
+    // neighbouring lanes' pixels (round 2 stored 3 single bytes per lane: 192 byte stores per block, and four times the
+    // pixels' bytes in HBM write traffic, profiles/r02_pmc_render_fp64.txt).  Needs dword-aligned rows, i.e. a width
+    // that is a multiple of 4, and a block wholly inside the image; anything else keeps the byte stores.
+    const bool whole = MJRL_RENDER_VARIANT != 2 && (width & 3) == 0 && r0 + 8 <= height && c0 + 8 <= width;
+    if (whole) {
+      const unsigned packed = (unsigned)out[0] | ((unsigned)out[1] << 8) | ((unsigned)out[2] << 16);
+      const int prow = L / 6, j = L - 6 * prow;             // lanes 0..47: dword j of the block's pixel row prow
+      const int b = 4 * j, pa = b / 3, o = b - 3 * pa;       // its first byte belongs to pixel pa of that row, byte o
+      const int src = (prow & 7) * 8 + pa;
+      const unsigned lo = (unsigned)wv::shfl((int)packed, src), hi = (unsigned)wv::shfl((int)packed, (src + 1) & 63);
+      const unsigned long long q = (unsigned long long)lo | ((unsigned long long)hi << 24);
+      if (L < 48) *(unsigned*)(img + (size_t)(r0 + prow) * width * 3 + 3 * c0 + 4 * j) = (unsigned)(q >> (8 * o));
+    } else if (inside) {
+      img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2];
+    }
   }
 }
 
 // the ray kernel's LDS: geom positions, matrices and sizes
-inline size_t render_lds_bytes(const DevModel& m) { return 15 * (size_t)m.ngeom * sizeof(float); }
+inline size_t render_lds_bytes(const DevModel& m) { return (21 * (size_t)m.ngeom + LIGHT_FLOATS * ((size_t)m.nlight + 1) + 9) * sizeof(float); }
 
 std::string g_create_error;
 

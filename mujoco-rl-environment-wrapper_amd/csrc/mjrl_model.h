@@ -57,8 +57,8 @@ __device__ __forceinline__ void mjrl_model_from_base(DevModel* m, const char MJR
                 ngeom = DevModel::ngeom, nsite = DevModel::nsite, ncam = DevModel::ncam, nsensor = DevModel::nsensor,
                 npair = DevModel::npair, nM = DevModel::nM, ndesc = DevModel::ndesc, nchild = DevModel::nchild,
                 ntree = DevModel::ntree, nfactor = DevModel::nfactor, ntab = DevModel::ntab, nchunk = DevModel::nchunk,
-                ntp = DevModel::ntp;
-  (void)nchunk; (void)ntp;
+                ntp = DevModel::ntp, nlight = DevModel::nlight;
+  (void)nchunk; (void)ntp; (void)nlight;
   (void)nfactor; (void)ntab; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
   (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
 #define X(name, count) m->name = (const double MJRL_GLOBAL*)(b + off); off += 8 * (size_t)(count);
@@ -91,8 +91,8 @@ static inline int mjrl_model_from_blob(DevModel* m, const void* host_blob, size_
   const char* b = (const char*)base;
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom, nsite = m->nsite,
       ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nM = m->nM, ndesc = m->ndesc, nchild = m->nchild,
-      ntree = m->ntree, nfactor = m->nfactor, ntab = m->ntab, nchunk = m->nchunk, ntp = m->ntp;
-  (void)nchunk; (void)ntp;
+      ntree = m->ntree, nfactor = m->nfactor, ntab = m->ntab, nchunk = m->nchunk, ntp = m->ntp, nlight = m->nlight;
+  (void)nchunk; (void)ntp; (void)nlight;
   (void)nfactor; (void)ntab; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor;
   (void)npair; (void)nM; (void)ndesc; (void)nchild; (void)ntree;
 #define X(name, count) m->name = (const double MJRL_GLOBAL*)(b + off); off += 8 * (size_t)(count);

@@ -152,11 +152,15 @@ def ant() -> str:
     ET.SubElement(default, "joint", armature="1", damping="1", limited="true")
     ET.SubElement(default, "geom", conaffinity="0", condim="3", density="5.0", friction="1 0.5 0.5", margin="0.01",
                   rgba="0.8 0.6 0.4 1")
+    # (the floor's material, Ant.xml:15: its specular / shininess enter the fixed-function shading; its checker texture
+    # and reflectance are outside the ray caster's image model)
+    asset = ET.SubElement(root, "asset")
+    ET.SubElement(asset, "material", name="MatPlane", reflectance="0.5", shininess="1", specular="1")
     world = ET.SubElement(root, "worldbody")
     ET.SubElement(world, "light", cutoff="100", diffuse="1 1 1", dir="-0 0 -1.3", directional="true", exponent="1",
                   pos="0 0 1.3", specular=".1 .1 .1")
-    ET.SubElement(world, "geom", conaffinity="1", condim="3", name="floor", pos="0 0 0", rgba="0.8 0.9 0.8 1",
-                  size="40 40 40", type="plane")
+    ET.SubElement(world, "geom", conaffinity="1", condim="3", material="MatPlane", name="floor", pos="0 0 0",
+                  rgba="0.8 0.9 0.8 1", size="40 40 40", type="plane")
     body = ET.SubElement(world, "body", name="torso", pos="0 0 0.75")
     ET.SubElement(body, "camera", name="track", mode="trackcom", pos="0 -3 0.3", xyaxes="1 0 0 0 0 1")
     ET.SubElement(body, "geom", name="torso_geom", pos="0 0 0", size="0.25", type="sphere")

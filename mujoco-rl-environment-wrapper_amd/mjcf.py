@@ -198,6 +198,25 @@ class _Compiler:
         self.eulerseq = comp.get("eulerseq", "xyz")
         self.defaults = _Defaults(self.root)
         self.bodies, self.joints, self.geoms, self.sites, self.cams = [], [], [], [], []
+        self.lights = []
+        # <asset><material>: the part of a material the fixed-function shading uses (colour, specular, shininess,
+        # emission; XML reference, asset/material).  Textures and reflectance are parsed and ignored.
+        self.materials = {}
+        asset = self.root.find("asset")
+        if asset is not None:
+            for el in asset:
+                if el.tag == "material":
+                    a = self.defaults.apply(el, None)
+                    self.materials[a.get("name", "")] = dict(
+                        rgba=_vec(a.get("rgba"), 4, [1.0, 1.0, 1.0, 1.0]), specular=float(a.get("specular", 0.5)),
+                        shininess=float(a.get("shininess", 0.5)), emission=float(a.get("emission", 0.0)))
+        # <visual><headlight>: XML reference defaults ambient 0.1, diffuse 0.4, specular 0.5, active 1
+        self.headlight = dict(active=1.0, ambient=np.full(3, 0.1), diffuse=np.full(3, 0.4), specular=np.full(3, 0.5))
+        visual = self.root.find("visual")
+        if visual is not None and visual.find("headlight") is not None:
+            a = visual.find("headlight").attrib
+            self.headlight = dict(active=float(a.get("active", 1)), ambient=_vec(a.get("ambient"), 3, [0.1] * 3),
+                                  diffuse=_vec(a.get("diffuse"), 3, [0.4] * 3), specular=_vec(a.get("specular"), 3, [0.5] * 3))
 
     # -- orientation attributes -------------------------------------------------
     def _angle(self, a):
@@ -256,6 +275,22 @@ class _Compiler:
                 self.cams.append(dict(name=a.get("name", ""), body=body_id,
                                       pos=_vec(a.get("pos"), 3, [0, 0, 0]), quat=self.orientation(a),
                                       fovy=float(a.get("fovy", 45.0))))
+            elif child.tag == "light":
+                # XML reference, body/light: directional false, active true, pos 0 0 0, dir 0 0 -1, attenuation 1 0 0,
+                # cutoff 45, exponent 10, ambient 0 0 0, diffuse 0.7 0.7 0.7, specular 0.3 0.3 0.3 (castshadow: ignored)
+                a = self.defaults.apply(child, childclass)
+                if a.get("active", "true") == "false":
+                    continue
+                d = _vec(a.get("dir"), 3, [0, 0, -1])
+                n = np.linalg.norm(d)
+                self.lights.append(dict(name=a.get("name", ""), body=body_id, pos=_vec(a.get("pos"), 3, [0, 0, 0]),
+                                        dir=d / n if n > MINVAL else np.array([0.0, 0, -1]),
+                                        directional=int(a.get("directional", "false") == "true"),
+                                        attenuation=_vec(a.get("attenuation"), 3, [1, 0, 0]),
+                                        cutoff=float(a.get("cutoff", 45.0)), exponent=float(a.get("exponent", 10.0)),
+                                        ambient=_vec(a.get("ambient"), 3, [0, 0, 0]),
+                                        diffuse=_vec(a.get("diffuse"), 3, [0.7, 0.7, 0.7]),
+                                        specular=_vec(a.get("specular"), 3, [0.3, 0.3, 0.3])))
         for child in elem:
             if child.tag == "body":
                 a = child.attrib
@@ -315,6 +350,12 @@ class _Compiler:
                  solmix=float(a.get("solmix", 1.0)),
                  rgba=_vec(a.get("rgba"), 4, [0.5, 0.5, 0.5, 1.0]),
                  mass=float(a["mass"]) if "mass" in a else None)
+        # visual material (XML reference, geom/material and geom/rgba): without a material the renderer's defaults
+        # (specular 0.5, shininess 0.5, no emission); with one, its properties -- and its colour unless the geom sets rgba
+        mat = self.materials.get(a.get("material", ""))
+        g["matprop"] = np.array([mat["specular"], mat["shininess"], mat["emission"]] if mat else [0.5, 0.5, 0.0])
+        if mat and "rgba" not in a:
+            g["rgba"] = mat["rgba"].copy()
         self.bodies[body_id]["geoms"].append(len(self.geoms))
         self.geoms.append(g)
 
@@ -565,6 +606,7 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     A["geom_solmix"] = np.array([g["solmix"] for g in c.geoms], np.float64)
     A["geom_rbound"] = np.array([_geom_rbound(g) for g in c.geoms], np.float64)
     A["geom_rgba"] = np.array([g["rgba"] for g in c.geoms], np.float64).reshape(ngeom, 4)
+    A["geom_matprop"] = np.array([g["matprop"] for g in c.geoms], np.float64).reshape(ngeom, 3)
 
     # ---- body inertial frames from geoms
     body_mass, body_ipos = np.zeros(nbody), np.zeros((nbody, 3))
@@ -609,6 +651,16 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     A["cam_pos"] = np.array([s["pos"] for s in c.cams], np.float64).reshape(nc, 3)
     A["cam_quat"] = np.array([s["quat"] for s in c.cams], np.float64).reshape(nc, 4)
     A["cam_fovy"] = np.array([s["fovy"] for s in c.cams], np.float64)
+    # ---- lights (rendering only): the scene's <light> elements and the headlight of <visual>
+    nl = m.nlight = len(c.lights)
+    A["light_bodyid"] = np.array([s["body"] for s in c.lights], np.int32)
+    A["light_directional"] = np.array([s["directional"] for s in c.lights], np.int32)
+    for key, width in (("pos", 3), ("dir", 3), ("attenuation", 3), ("ambient", 3), ("diffuse", 3), ("specular", 3)):
+        A["light_" + key] = np.array([s[key] for s in c.lights], np.float64).reshape(nl, width)
+    A["light_cutoff"] = np.array([s["cutoff"] for s in c.lights], np.float64)
+    A["light_exponent"] = np.array([s["exponent"] for s in c.lights], np.float64)
+    h = c.headlight
+    A["headlight"] = np.concatenate([[h["active"]], h["ambient"], h["diffuse"], h["specular"]]).astype(np.float64)
 
     m.names = dict(body=[b["name"] for b in c.bodies], joint=[j["name"] for j in c.joints],
                    geom=[g["name"] for g in c.geoms], site=[s["name"] for s in c.sites],

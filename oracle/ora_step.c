@@ -91,8 +91,8 @@ ora_model* ora_model_create(const void* blob, size_t nbytes) {
 #undef X
   p += 8 * ORA_NOPTS;
   int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt, ngeom = m->ngeom, nsite = m->nsite, nM = m->nM, ndesc = m->ndesc, nchild = m->nchild, ntree = m->ntree,
-      ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nfactor = m->nfactor, ntab = m->ntab, nchunk = m->nchunk, ntp = m->ntp;
-  (void)nfactor; (void)ntab; (void)nchunk; (void)ntp;
+      ncam = m->ncam, nsensor = m->nsensor, npair = m->npair, nfactor = m->nfactor, ntab = m->ntab, nchunk = m->nchunk, ntp = m->ntp, nlight = m->nlight;
+  (void)nfactor; (void)ntab; (void)nchunk; (void)ntp; (void)nlight;
   (void)nM; (void)ndesc; (void)nchild; (void)ntree; (void)nq; (void)nv; (void)nu; (void)nbody; (void)njnt; (void)ngeom; (void)nsite; (void)ncam; (void)nsensor; (void)npair;
 #define X(name, count) m->name = (const double*)p; p += 8 * (size_t)(count);
   ORA_F64_FIELDS(X)
@@ -892,11 +892,80 @@ void ora_reset(const ora_model* m, ora_data* d) {
 
 /* ------------------------------------------------------------------ camera (config 5)
  * Fixed body-mounted camera as a ray caster: the reference renders it with OpenGL (mujoco_parent.py:518-538,
- * mjv_updateScene + mjr_render + mjr_readPixels); no renderer is available here, so the image model is this
- * repo's own and pixel parity with the reference is UNPINNED.  Conventions kept from the reference: the camera
- * looks along -z of its frame with +x right and +y up, vertical field of view fovy, uint8 RGB, rows stored
- * bottom-up as glReadPixels returns them, shape (W, H, 3).  Shading: geom rgba (clamped to [0,1]) times
- * (0.4 + 0.6 * max(0, n . -ray)) (a headlight), background black. */
+ * mjv_updateScene + mjr_render + mjr_readPixels); no renderer is available here, so pixel parity with the reference
+ * is UNPINNED.  Conventions kept from the reference: the camera looks along -z of its frame with +x right and +y up,
+ * vertical field of view fovy, uint8 RGB, rows stored bottom-up as glReadPixels returns them, shape (W, H, 3).
+ *
+ * Shading (round 3): the OpenGL fixed-function lighting equation that MuJoCo's renderer drives, with the parameters
+ * MuJoCo documents (XML reference: visual/headlight -- ambient 0.1, diffuse 0.4, specular 0.5, active; body/light --
+ * directional false, pos 0 0 0, dir 0 0 -1, attenuation 1 0 0, cutoff 45, exponent 10, ambient 0, diffuse 0.7,
+ * specular 0.3; asset/material -- specular 0.5, shininess 0.5, emission 0, which are also what a geom without a
+ * material is drawn with).  Per colour channel, with the geom's rgba as ambient and diffuse material colour:
+ *   c = emission * rgba
+ *     + sum over lights  att * spot * ( amb_l * rgba + max(n.L, 0) * diff_l * rgba
+ *                                       + [n.L > 0] * max(n.H, 0)^(128 * shininess) * spec_l * specular )
+ * clamped to [0, 1] once, at the end (rgba itself is NOT clamped: the levels' "255 255 255" floor saturates as it does
+ * in OpenGL).  Lights: the headlight -- directional, shining along the camera's viewing direction (L = the camera's
+ * +z axis), att = spot = 1 -- and every <light> of the level: L = -dir for a directional one; else L points from the
+ * surface point to the light, att = 1 / (k0 + k1 d + k2 d^2), and for cutoff < 180 the OpenGL spot factor
+ * (-L . dir)^exponent inside the cone, 0 outside.  H = normalize(L + V) with V = the camera's +z axis (OpenGL's default
+ * viewer at infinity), the scene's global ambient is 0.
+ * What is NOT reproduced: shadows (MuJoCo draws them for lights with castshadow), textures and
+ * reflectance (the checker floor of Ant.xml), the skybox, anti-aliasing, fog / haze, transparency blending; OpenGL
+ * evaluates the equation per vertex of the tessellated geoms and interpolates, this evaluates it per pixel; the viewer
+ * model (local / at infinity) and the zero global ambient are read off OpenGL's defaults, not off MuJoCo's source. */
+static void ora_shade(const ora_model* m, const ora_data* d, const double* cm, int hit, const double* p, const double* n,
+                      unsigned char* px) {
+  const double* rgba = m->geom_rgba + 4 * hit;
+  const double spec_m = m->geom_matprop[3 * hit], shin = 128.0 * m->geom_matprop[3 * hit + 1], emis = m->geom_matprop[3 * hit + 2];
+  const double V[3] = {cm[2], cm[5], cm[8]};        /* the camera's +z axis: towards the viewer */
+  double col[3] = {emis * rgba[0], emis * rgba[1], emis * rgba[2]};
+  for (int li = -1; li < m->nlight; li++) {
+    double L[3], scale = 1.0;
+    const double *amb, *dif, *spc;
+    if (li < 0) {
+      if (m->headlight[0] == 0) continue;
+      L[0] = V[0]; L[1] = V[1]; L[2] = V[2];
+      amb = m->headlight + 1; dif = m->headlight + 4; spc = m->headlight + 7;
+    } else {
+      const int b = m->light_bodyid[li];
+      double pos[3], dir[3];
+      m3_mulv(pos, d->xmat + 9 * b, m->light_pos + 3 * li);
+      v3_add(pos, pos, d->xpos + 3 * b);
+      m3_mulv(dir, d->xmat + 9 * b, m->light_dir + 3 * li);
+      amb = m->light_ambient + 3 * li; dif = m->light_diffuse + 3 * li; spc = m->light_specular + 3 * li;
+      if (m->light_directional[li]) {
+        L[0] = -dir[0]; L[1] = -dir[1]; L[2] = -dir[2];
+      } else {
+        v3_sub(L, pos, p);
+        double dist = sqrt(v3_dot(L, L));
+        if (dist < ORA_MINVAL) continue;
+        L[0] /= dist; L[1] /= dist; L[2] /= dist;
+        const double* k = m->light_attenuation + 3 * li;
+        scale = 1.0 / (k[0] + k[1] * dist + k[2] * dist * dist);
+        if (m->light_cutoff[li] < 180.0) {
+          double c = -v3_dot(L, dir);
+          scale = c < cos(m->light_cutoff[li] * ORA_PI / 180.0) ? 0.0 : scale * pow(c > 0 ? c : 0, m->light_exponent[li]);
+        }
+      }
+    }
+    double nl = v3_dot(n, L), sp = 0;
+    if (nl > 0) {
+      double H[3] = {L[0] + V[0], L[1] + V[1], L[2] + V[2]};
+      double hn = sqrt(v3_dot(H, H));
+      double nh = hn > ORA_MINVAL ? v3_dot(n, H) / hn : 0;
+      sp = nh > 0 ? pow(nh, shin) : 0;
+    } else {
+      nl = 0;
+    }
+    for (int k = 0; k < 3; k++) col[k] += scale * (amb[k] * rgba[k] + nl * dif[k] * rgba[k] + sp * spc[k] * spec_m);
+  }
+  for (int k = 0; k < 3; k++) {
+    double c = col[k] > 1 ? 1 : (col[k] < 0 ? 0 : col[k]);
+    px[k] = (unsigned char)(255.0 * c + 0.5);
+  }
+}
+
 void ora_render(const ora_model* m, ora_data* d, int cam, int width, int height, unsigned char* out) {
   ora_kinematics(m, d);
   const double* cp = d->cam_xpos + 3 * cam;
@@ -920,15 +989,7 @@ void ora_render(const ora_model* m, ora_data* d, int cam, int width, int height,
       double p[3], n[3];
       v3_addscl(p, cp, vec, best);
       ora_geom_normal(m->geom_type[hit], d->geom_xpos + 3 * hit, d->geom_xmat + 9 * hit, m->geom_size + 3 * hit, p, n);
-      double lambert = -v3_dot(n, vec);
-      if (lambert < 0) lambert = 0;
-      double shade = 0.4 + 0.6 * lambert;
-      for (int k = 0; k < 3; k++) {
-        double col = m->geom_rgba[4 * hit + k];
-        if (col > 1) col = 1;
-        if (col < 0) col = 0;
-        px[k] = (unsigned char)(255.0 * col * shade + 0.5);
-      }
+      ora_shade(m, d, cm, hit, p, n, px);
     }
 }
 

@@ -286,3 +286,30 @@ def test_vector_env_autoreset_is_per_copy_and_runs_the_fused_channel():
     ts = env._handle.get_field("timestep")
     assert len(set(ts.tolist())) > 1                     # the copies are still at different points of their episodes
     vec.close()
+
+
+# --------------------------------------------------------------------------- camera shading (row a14)
+def test_render_kernel_shades_like_the_oracle(tmp_path):
+    """The ray kernel evaluates the fixed-function lighting equation in single precision, the oracle in double
+    (tests/test_render_shading.py pins the oracle to the documented equation): on the spot-light scene, with a material
+    and with a directional light, no pixel differs by more than one level, and almost none differs at all; on the
+    2-agent level the images carry the light's footprint (the floor is darker far from the light)."""
+    from tests.test_render_shading import SCENE
+    cases = [dict(light='<light diffuse=".5 .5 .5" pos="0 0 3" dir="0 0 -1"/>', visual="", material=""),
+             dict(light='<light diffuse=".5 .5 .5" pos="0 0 3" dir="0 0 -1"/>', visual="", material='material="shiny"'),
+             dict(light='<light directional="true" dir="1 0 -1" diffuse=".6 .6 .6"/>',
+                  visual='<visual><headlight ambient=".2 .2 .2"/></visual>', material="")]
+    for k, case in enumerate(cases):
+        path = tmp_path / f"scene{k}.xml"
+        path.write_text(SCENE.format(**case))
+        packed = blob.pack(mjcf.compile_mjcf(str(path)))
+        h = _capi.Handle(packed, 3)
+        h.reset()
+        ora = OracleEnv(packed)
+        for size in (65, 64):
+            got = h.render(size, size).astype(int)
+            ref = ora.render(0, size, size).reshape(size, size, 3).astype(int)
+            assert np.abs(got[1, 0] - ref).max() <= 1, (k, size)
+            assert (np.abs(got[1, 0] - ref).max(axis=-1) > 0).mean() < 0.01, (k, size)
+            assert k == 2 or len(np.unique(ref.reshape(-1, 3), axis=0)) > 20    # a graded image (the directional case is flat)
+        h.close(); ora.close()

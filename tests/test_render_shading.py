@@ -1,0 +1,106 @@
+"""The camera image model's shading: OpenGL's fixed-function lighting equation with the parameters
+MuJoCo documents (XML reference: visual/headlight, body/light, asset/material), as the oracle's ray caster evaluates it
+(oracle/ora_step.c ``ora_shade``).  Known answers recomputed here from the documented equation in numpy: a floor under
+the level's spot light seen from straight above -- on the light's axis, inside its cone, outside its cone -- a material's
+specular / shininess / emission, a directional light, an inactive headlight, and the XML defaults of the shipped levels.
+(Pixel parity with the reference's OpenGL output stays unpinned: no renderer here.  GPU kernel == oracle: test_gpu_*.)"""
+import numpy as np
+import pytest
+
+from mjrl_amd import blob, levels, mjcf
+from oracle.oracle import OracleEnv
+
+SCENE = """<mujoco>
+  {visual}
+  <asset><material name="shiny" specular="1" shininess="0.25" emission="0.1"/></asset>
+  <worldbody>
+    {light}
+    <geom type="plane" size="20 20 1" rgba="0.2 0.3 0.4 1" {material}/>
+    <camera name="down" pos="0 0 10"/>
+    <body pos="15 15 1"><freejoint/><geom type="sphere" size="0.1"/></body>
+  </worldbody>
+</mujoco>"""
+
+
+def render(tmp_path, light='<light diffuse=".5 .5 .5" pos="0 0 3" dir="0 0 -1"/>', visual="", material="", size=65):
+    path = tmp_path / "scene.xml"
+    path.write_text(SCENE.format(light=light, visual=visual, material=material))
+    model = mjcf.compile_mjcf(str(path))
+    ora = OracleEnv(blob.pack(model))
+    img = ora.render(0, size, size).reshape(size, size, 3).astype(int)      # rows bottom-up, camera +x right
+    ora.close()
+    return model, img
+
+
+def floor_x(col, size=65, height=10.0, fovy=45.0):
+    """World x of the floor point the pixel of column ``col`` (middle row) sees from a camera looking straight down."""
+    return (2.0 * (col + 0.5) / size - 1.0) * np.tan(0.5 * np.radians(fovy)) * height
+
+
+def expected(x, rgba, head=(0.1, 0.4, 0.5), light=(0.0, 0.5, 0.3), spec_m=0.5, shin=0.5, emis=0.0, cutoff=45.0, exponent=10.0,
+             light_pos=(0.0, 0.0, 3.0)):
+    """The documented equation at floor point (x, 0, 0), normal and viewer direction +z, one spot light pointing down."""
+    rgba = np.asarray(rgba, float)
+    n = V = np.array([0.0, 0, 1])
+    col = emis * rgba
+    col = col + head[0] * rgba + head[1] * rgba * 1.0 + head[2] * spec_m * 1.0        # headlight: L = H = V = n
+    L = np.asarray(light_pos) - np.array([x, 0, 0])
+    L = L / np.linalg.norm(L)
+    c = L[2]                                                                          # -L . dir with dir = (0, 0, -1)
+    spot = 0.0 if c < np.cos(np.radians(cutoff)) else c ** exponent
+    H = (L + V) / np.linalg.norm(L + V)
+    col = col + spot * (light[0] * rgba + max(n @ L, 0) * light[1] * rgba + max(n @ H, 0) ** (128 * shin) * light[2] * spec_m)
+    return np.floor(255.0 * np.clip(col, 0, 1) + 0.5).astype(int)
+
+
+def test_floor_under_the_levels_spot_light(tmp_path):
+    model, img = render(tmp_path)
+    assert model.nlight == 1 and np.allclose(model.light_diffuse, 0.5) and np.allclose(model.light_specular, 0.3)
+    assert np.allclose(model.headlight, [1, .1, .1, .1, .4, .4, .4, .5, .5, .5]) and model.light_cutoff[0] == 45
+    rgba = (0.2, 0.3, 0.4)
+    mid = 32
+    # on the light's axis: everything at full strength: rgba (0.1 + 0.4 + 0.5) + 0.25 + 0.15
+    assert np.array_equal(img[mid, mid], expected(0.0, rgba)) and np.array_equal(img[mid, mid], [153, 179, 204])
+    for col in (40, 48, 52, 60, 64):                      # inside the 45 degree cone (radius 3 on the floor) and outside it
+        x = floor_x(col)
+        assert np.abs(img[mid, col] - expected(x, rgba)).max() <= 1, (col, x, img[mid, col], expected(x, rgba))
+    outside = expected(floor_x(64), rgba)
+    assert floor_x(64) > 3.0 and np.array_equal(outside, [89, 102, 115])      # the headlight alone: 0.5 rgba + 0.25
+    assert np.array_equal(img[mid, 0], img[mid, 64]) and np.array_equal(img[0, mid], img[mid, 64])      # symmetric
+
+
+def test_material_and_headlight_attributes(tmp_path):
+    rgba = (0.2, 0.3, 0.4)
+    model, img = render(tmp_path, material='material="shiny"')
+    assert np.allclose(model.geom_matprop[0], [1.0, 0.25, 0.1])
+    for col in (32, 44, 64):
+        want = expected(floor_x(col), rgba, spec_m=1.0, shin=0.25, emis=0.1)
+        assert np.abs(img[32, col] - want).max() <= 1
+    model, img = render(tmp_path, visual='<visual><headlight active="0"/></visual>')
+    assert model.headlight[0] == 0
+    assert np.array_equal(img[32, 64], [0, 0, 0])                     # outside the cone and no headlight: black
+    assert np.array_equal(img[32, 32], expected(0.0, rgba, head=(0, 0, 0)))
+    model, img = render(tmp_path, visual='<visual><headlight ambient=".3 .3 .3" diffuse="0 0 0" specular="0 0 0"/></visual>')
+    assert np.array_equal(img[32, 64], expected(floor_x(64), rgba, head=(0.3, 0, 0)))
+
+
+def test_directional_light_has_neither_cone_nor_falloff(tmp_path):
+    rgba = np.array([0.2, 0.3, 0.4])
+    light = '<light directional="true" dir="1 0 -1" diffuse=".6 .6 .6" specular="0 0 0" attenuation="0 0 5"/>'
+    model, img = render(tmp_path, light=light)
+    assert model.light_directional[0] == 1
+    nl = 1 / np.sqrt(2)                                                # L = -dir = (-1, 0, 1) / sqrt 2 everywhere
+    want = np.floor(255 * np.clip(0.5 * rgba + 0.25 + nl * 0.6 * rgba, 0, 1) + 0.5).astype(int)
+    assert all(np.abs(img[32, col] - want).max() <= 1 for col in (0, 32, 64))
+
+
+def test_shipped_levels_carry_their_light_and_the_default_headlight():
+    for name in ("two_agent.xml", "single_agent.xml", "four_agent.xml", "sensor_touch.xml"):
+        m = mjcf.compile_mjcf(levels.level_path(name))
+        assert m.nlight == 1 and m.light_bodyid[0] == 0 and np.allclose(m.light_pos, [[0, 0, 3]])
+        assert np.allclose(m.light_dir, [[0, 0, -1]]) and np.allclose(m.light_diffuse, 0.5) and m.light_directional[0] == 0
+        assert np.allclose(m.geom_matprop, np.tile([0.5, 0.5, 0.0], (m.ngeom, 1)))
+    ant = mjcf.compile_mjcf(levels.level_path("ant.xml"))
+    assert ant.light_directional[0] == 1 and ant.light_cutoff[0] == 100 and np.allclose(ant.light_specular, 0.1)
+    assert np.allclose(ant.geom_matprop[0], [1.0, 1.0, 0.0]) and np.allclose(ant.geom_rgba[0], [0.8, 0.9, 0.8, 1])
+    assert np.allclose(ant.light_dir[0], [0, 0, -1])                   # "-0 0 -1.3" normalised
