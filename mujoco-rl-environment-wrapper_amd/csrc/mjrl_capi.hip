@@ -358,6 +358,8 @@ struct mjrl_env {
   void *enc_w1 = nullptr, *enc_w2 = nullptr, *enc_wd = nullptr;
   float *enc_b1 = nullptr, *enc_b2 = nullptr, *enc_bd = nullptr;
   unsigned short* enc_a2 = nullptr;        // [enc_cap][16384] conv output (bf16)
+  float* enc_part = nullptr;               // [DENSE_KSPLIT][enc_cap][16 enc_tiles] partial tiles of the dense layer
+  int enc_part_tiles = 0;
   unsigned char* enc_rgb = nullptr;        // [n_env][ncam][64][64][3] frames of the camera observation
   int* enc_obs_row = nullptr;              // [n_env * ncam] first latent slot of the image in the flat observation tensor, -1: none
   int enc_latent = 0, enc_tiles = 0, enc_relu = 1, enc_cap = 0, n_cam_obs = 0;
@@ -438,7 +440,7 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_part, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->inertia, e->overflow, e->auto_mask};
@@ -773,13 +775,21 @@ int mjrl_encoder_load(mjrl_env* e, int latent_dim, int relu_latent, const float*
   if (e->n_cam_obs && latent_dim != e->enc_latent) MJRL_FAIL(e, 1, "encoder_load: camera observations are laid out for latent_dim %d", e->enc_latent);
   const int tiles = (latent_dim + 15) / 16;
   auto lane_k = [](int lane, int j) { return 8 * (lane >> 4) + j; };
-  // conv1: B[k][n], k = (ky * 3 + kx) * 3 + c padded to 32, scaled by 1/255 (the pixels enter as integers 0..255)
+  // conv1: W[n][k] scaled by 1/255 (the pixels enter as integers 0..255), K reordered so that a lane's eight k-values are
+  // eight contiguous bytes of the image (mjrl_encoder.h): k = 8 ky + j is byte j = 3 kx + c of the 9-byte run of image row
+  // ky, k = 24 + ky the run's ninth byte (kx = 2, c = 2); 27..31 are padding
+  auto conv1_source = [](int k) {            // -> index (ky * 3 + kx) * 3 + c of the Keras kernel, -1 for padding
+    if (k < 24) { const int ky = k / 8, j = k % 8; return (ky * 3 + j / 3) * 3 + j % 3; }
+    if (k < 27) return ((k - 24) * 3 + 2) * 3 + 2;
+    return -1;
+  };
   std::vector<unsigned short> p1((size_t)2 * 64 * 8), p2((size_t)9 * 4 * 64 * 8), pd((size_t)(enc::FLAT / 32) * tiles * 64 * 8);
   for (int nt = 0; nt < 2; nt++)
     for (int lane = 0; lane < 64; lane++)
       for (int j = 0; j < 8; j++) {
         const int k = lane_k(lane, j), n = 16 * nt + (lane & 15);
-        p1[((size_t)nt * 64 + lane) * 8 + j] = host_bf16(k < 27 ? w1[k * 32 + n] / 255.0f : 0.0f);
+        const int src = conv1_source(k);
+        p1[((size_t)nt * 64 + lane) * 8 + j] = host_bf16(src >= 0 ? w1[src * 32 + n] / 255.0f : 0.0f);
       }
   for (int tap = 0; tap < 9; tap++)
     for (int nt = 0; nt < 4; nt++)
@@ -792,7 +802,8 @@ int mjrl_encoder_load(mjrl_env* e, int latent_dim, int relu_latent, const float*
     for (int nt = 0; nt < tiles; nt++)
       for (int lane = 0; lane < 64; lane++)
         for (int j = 0; j < 8; j++) {
-          const int k = 32 * kk + lane_k(lane, j), n = 16 * nt + (lane & 15);
+          // (element k of the activation vector as the conv kernel lays it out is Keras' flattened index a2_source(k))
+          const int k = enc::a2_source(32 * kk + lane_k(lane, j)), n = 16 * nt + (lane & 15);
           pd[(((size_t)kk * tiles + nt) * 64 + lane) * 8 + j] = n < latent_dim ? host_bf16(wd[(size_t)k * latent_dim + n]) : 0;
         }
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
@@ -810,7 +821,7 @@ int mjrl_encoder_load(mjrl_env* e, int latent_dim, int relu_latent, const float*
   if (int rc = up((void**)&e->enc_b2, b2, sizeof(float) * 64)) return rc;
   if (int rc = up((void**)&e->enc_bd, bd, sizeof(float) * latent_dim)) return rc;
   e->enc_latent = latent_dim; e->enc_tiles = tiles; e->enc_relu = relu_latent ? 1 : 0;
-  const int conv_lds = enc::IMG * enc::IMG * 3 + enc::H1 * enc::H1 * enc::C1 * 2;
+  const int conv_lds = enc::IMG_LDS + enc::H1 * enc::H1 * enc::C1 * 2;
   MJRL_HIP(e, hipFuncSetAttribute((const void*)enc::mjrl_encoder_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds));
   return 0;
 }
@@ -819,19 +830,42 @@ int mjrl_encoder_load(mjrl_env* e, int latent_dim, int relu_latent, const float*
 static int launch_encoder(mjrl_env* e, const uint8_t* d_rgb, int n_img, float* d_latent, double* d_obs, const int* d_obs_row) {
   if (!e->enc_wd) MJRL_FAIL(e, 3, "encode: no encoder weights loaded (mjrl_encoder_load)");
   if (n_img <= 0) return 0;
-  if (n_img > e->enc_cap) {
+  const int groups = (e->enc_tiles + enc::DENSE_MAXT - 1) / enc::DENSE_MAXT, mtiles = (n_img + 31) / 32;
+  if (n_img > e->enc_cap || e->enc_part_tiles != e->enc_tiles) {
     MJRL_HIP(e, hipStreamSynchronize(e->stream));
-    if (e->enc_a2) { hipFree(e->enc_a2); e->enc_a2 = nullptr; }
+    for (void** p : {(void**)&e->enc_a2, (void**)&e->enc_part})
+      if (*p) { hipFree(*p); *p = nullptr; }
+    e->enc_cap = 0;
     MJRL_HIP(e, hipMalloc(&e->enc_a2, sizeof(unsigned short) * (size_t)n_img * enc::FLAT));
+    // the dense layer's partial tiles [image][K split][column]
+    MJRL_HIP(e, hipMalloc(&e->enc_part, sizeof(float) * (size_t)enc::DENSE_KSPLIT * n_img * e->enc_tiles * 16));
     e->enc_cap = n_img;
+    e->enc_part_tiles = e->enc_tiles;
   }
-  const int conv_lds = enc::IMG * enc::IMG * 3 + enc::H1 * enc::H1 * enc::C1 * 2;
-  hipLaunchKernelGGL(enc::mjrl_encoder_conv_kernel, dim3(n_img), dim3(256), conv_lds, e->stream, d_rgb, n_img,
+  const int conv_lds = enc::IMG_LDS + enc::H1 * enc::H1 * enc::C1 * 2;
+  hipLaunchKernelGGL(enc::mjrl_encoder_conv_kernel, dim3(n_img), dim3(enc::CONV_THREADS), conv_lds, e->stream, d_rgb, n_img,
                      (const enc::frag_ab*)e->enc_w1, e->enc_b1, (const enc::frag_ab*)e->enc_w2, e->enc_b2, e->enc_a2);
   MJRL_HIP(e, hipGetLastError());
-  hipLaunchKernelGGL(enc::mjrl_encoder_dense_kernel, dim3((n_img + 15) / 16, (e->enc_tiles + enc::DENSE_TILES - 1) / enc::DENSE_TILES), dim3(64 * enc::DENSE_WAVES), 0, e->stream, e->enc_a2, n_img,
-                     (const enc::frag_ab*)e->enc_wd, e->enc_bd, e->enc_latent, e->enc_tiles, e->enc_relu, d_latent, d_obs,
-                     d_obs_row, e->obs_dim);
+  for (int g = 0; g < groups; g++) {
+    const int nt0 = g * enc::DENSE_MAXT, nt = std::min((int)enc::DENSE_MAXT, e->enc_tiles - nt0);
+    // (the partial buffer is laid out for THIS call's image count)
+#define MJRL_DENSE(NT)                                                                                                       \
+    hipLaunchKernelGGL(enc::mjrl_encoder_dense_kernel<NT>, dim3(mtiles, enc::DENSE_KSPLIT), dim3(64 * enc::DENSE_WAVES), 0,    \
+                       e->stream, e->enc_a2, n_img, (const enc::frag_ab*)e->enc_wd, e->enc_tiles, nt0, e->enc_part)
+    switch (nt) {
+      case 1: MJRL_DENSE(1); break;
+      case 2: MJRL_DENSE(2); break;
+      case 3: MJRL_DENSE(3); break;
+      case 4: MJRL_DENSE(4); break;
+      case 5: MJRL_DENSE(5); break;
+      case 6: MJRL_DENSE(6); break;
+      default: MJRL_DENSE(7); break;
+    }
+#undef MJRL_DENSE
+    MJRL_HIP(e, hipGetLastError());
+  }
+  hipLaunchKernelGGL(enc::mjrl_encoder_dense_finish_kernel, dim3((n_img * e->enc_latent + 255) / 256), dim3(256), 0, e->stream,
+                     e->enc_part, n_img, e->enc_latent, e->enc_tiles, e->enc_bd, e->enc_relu, d_latent, d_obs, d_obs_row);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }

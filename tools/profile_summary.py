@@ -1,23 +1,27 @@
-"""Turn the rocprofv3 output of tools/profile_run.sh (gpurun_out/prof_r02_<level>) into the committed summaries:
-profiles/r02_kernel_stats_<level>.csv (the --stats table of the exact driver command), profiles/r02_timed_window_<level>.json
+"""Turn the rocprofv3 output of tools/profile_run.sh (gpurun_out/prof_<round>_<level>) into the committed summaries:
+profiles/<round>_kernel_stats_<level>.csv (the --stats table of the exact driver command), profiles/<round>_timed_window_<level>.json
 (the step kernel's launches of the TIMED region, taken from the kernel trace: the last `steps` launches -- pre-roll and
-warm-up launches come before them) and profiles/r02_hbm_traffic_<level>.json (HBM bytes per launch from the FETCH_SIZE /
+warm-up launches come before them) and profiles/<round>_hbm_traffic_<level>.json (HBM bytes per launch from the FETCH_SIZE /
 WRITE_SIZE passes, corrected with the calibration copy as /opt/skills/guides/MI355X_MICROARCH.md prescribes).
 Usage: profile_summary.py [level] [steps]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 level = sys.argv[1] if len(sys.argv) > 1 else "two_agent"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-src = os.path.join(ROOT, "gpurun_out", f"prof_r02_{level}")
-dst = os.path.join(ROOT, "profiles")
+ROUND = os.environ.get("ROUND", "r03")
+src = os.path.join(ROOT, "gpurun_out", f"prof_{ROUND}_{level}")
+dst = os.environ.get("PROFILE_OUT", os.path.join(ROOT, "profiles"))
+os.makedirs(dst, exist_ok=True)
 STEP = "mjrl_step_kernel"          # matches the generic kernel and the specialised one (mjrl_step_kernel_spec)
-COMMAND = f"python3 bench.py --gpus 1 --steps {steps} --warmup 5 --level {level}"
+COMMAND = f"python3 bench.py --gpus 1 --steps {steps} --warmup 5" + ("" if level == "two_agent" else f" --level {level}")
 
 bench_line = None
 for line in open(os.path.join(src, "stats.log")):
     if line.startswith("{"):
         bench_line = json.loads(line)
 envs = bench_line["config"]["envs_per_gpu"]
+lead = bench_line["config"]["preroll_steps"] + bench_line["warmup"]     # untimed launches in front of the timed ones
+SPEC = "mjrl_step_kernel_spec"     # the headline's launches (the one generic launch per handle is the reset image's)
 algo = bench_line["roofline"]["algorithmic_bytes_per_env_step"]
 
 
@@ -38,17 +42,20 @@ def counter(run, name, kernel, last=None):
     if not vals:
         raise SystemExit(f"no {name} samples for {kernel} under {run}")
     if last:
-        vals = vals[-last:]
+        # the timed launches by position: the default command goes on to measure the other configs after them
+        vals = vals[lead:lead + last] if len(vals) >= lead + last else vals[-last:]
     return sum(vals) / len(vals), len(vals)
 
 
 stats = [newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))]
-shutil.copy(stats[0], os.path.join(dst, f"r02_kernel_stats_{level}.csv"))
-row = [r for r in csv.DictReader(open(stats[0])) if STEP in r["Name"]][0]
+shutil.copy(stats[0], os.path.join(dst, f"{ROUND}_kernel_stats_{level}.csv"))
+row = [r for r in csv.DictReader(open(stats[0])) if SPEC in r["Name"]][0]
 trace = newest(os.path.join(src, "stats", "*", "*kernel_trace.csv"))
-launches = [r for r in csv.DictReader(open(trace)) if STEP in r["Kernel_Name"]]
+launches = [r for r in csv.DictReader(open(trace)) if SPEC in r["Kernel_Name"]]
 launches.sort(key=lambda r: int(r["Start_Timestamp"]))
-dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in launches]
+all_dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in launches]
+launches = launches[:lead + steps]          # the headline's: what follows belongs to the `configs` array of the line
+dur = all_dur[:lead + steps]
 timed = dur[-steps:]
 window = {
     "command": f"rocprofv3 --kernel-trace --stats -- {COMMAND}   [tools/profile_run.sh, tools/profile_summary.py]",
@@ -65,11 +72,11 @@ window = {
     "note": "pre-roll (1024) and warm-up launches precede the timed ones in the trace; the first ~170 pre-roll launches run "
             "with every copy still airborne and are lighter, so the all-launch average sits slightly below the timed one",
 }
-json.dump(window, open(os.path.join(dst, f"r02_timed_window_{level}.json"), "w"), indent=1)
+json.dump(window, open(os.path.join(dst, f"{ROUND}_timed_window_{level}.json"), "w"), indent=1)
 print(json.dumps(window, indent=1))
 
-fetch_kb, n = counter("pmc_FETCH_SIZE", "FETCH_SIZE", STEP, last=steps)
-write_kb, _ = counter("pmc_WRITE_SIZE", "WRITE_SIZE", STEP, last=steps)
+fetch_kb, n = counter("pmc_FETCH_SIZE", "FETCH_SIZE", SPEC, last=steps)
+write_kb, _ = counter("pmc_WRITE_SIZE", "WRITE_SIZE", SPEC, last=steps)
 cal_fetch, _ = counter("calib_FETCH_SIZE", "FETCH_SIZE", "copy")
 cal_write, _ = counter("calib_WRITE_SIZE", "WRITE_SIZE", "copy")
 CAL_BYTES = 512 << 20
@@ -86,5 +93,5 @@ out = {
     "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": envs * algo,
     "ratio_to_algorithmic": hbm / (envs * algo),
 }
-json.dump(out, open(os.path.join(dst, f"r02_hbm_traffic_{level}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{ROUND}_hbm_traffic_{level}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
