@@ -29,7 +29,7 @@ enum { CON_DIST = 0, CON_POS = 1, CON_FRAME = 4, CON_INCL = 13, CON_MU = 14, CON
 // per-row record in LDS (doubles); ROW_F doubles as the constraint position until the row is built
 enum { ROW_R = 0, ROW_B = 1, ROW_F = 2, ROW_ARII = 3, ROW_STRIDE = 4 };
 // integer header of the int region
-enum { I_NCON = 0, I_NEFC = 1, I_NLIM = 2, I_NITER = 3, I_WARN = 4, I_NITEM = 5, I_HEAD = 8 };
+enum { I_NCON = 0, I_NEFC = 1, I_NLIM = 2, I_NITER = 3, I_WARN = 4, I_NITEM = 5, I_COST = 6, I_HEAD = 8 };
 enum { MAX_DOF_DEPTH = 8 };
 // A constraint row is stored in JW doubles, in one of two forms.
 // Tree-local (models in the tree-row lane map, rows inside one kinematic tree -- all rows of the solver's parallel
@@ -1596,6 +1596,184 @@ __device__ __forceinline__ real tall_bcast(real lo, real hi) {
   else return wv::bcast16<K - 16>(hi);
 }
 
+// The register solver for 17..32 rows in a tree of a model with MORE than two trees (the 4-agent arena: an ant pressed
+// onto the floor; some 25 copies of every launch of 4096, and with the schedule sweep the longest waves of nearly every
+// launch -- 170 us against a mean of 68).  All four rows of 16 lanes are taken by trees here, so a lane owns TWO rows of
+// its tree: lane k of the tree's 16 keeps rows k and k + 16 -- their forces, their rows of AR = B D^-1 B' + diag(R)
+// (2 x 32 registers pairs) and their residuals.  A row step is the 16-row solver's (stage_pgs): max on the negated
+// residual of the row's slot, one DPP broadcast inside the tree's row of 16, one fused multiply-add per slot; the same
+// late stop test, the same guard, the same sweep count.  It needs some 330 vector registers: such a model's LDS image
+// holds a CU to one wave per SIMD anyway (4 copies of 38 KB), so the registers are there.
+#ifndef MJRL_TALL_INLINE
+#if defined(MJRL_SPEC) || !defined(__HIPCC__)
+#define MJRL_TALL_INLINE inline __attribute__((always_inline))
+#else
+#define MJRL_TALL_INLINE __attribute__((noinline))      // (generic GPU kernel: a register allocation of its own)
+#endif
+#endif
+struct TallOut { real u; int iter; };
+#define MJ_ROWS32(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+                     X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+__device__ MJRL_TALL_INLINE TallOut pgs_tall_registers(real* S, const int* I, int L, int cnt_in, int base_in, int tmax_in,
+                                                       bool dof, int o_rowid, int o_row, int o_J, int o_Dinv, int iterations_in,
+                                                       int adr0, int ntree, real tolerance, real scale, int iter_in) {
+  int iter = wv::first_int(iter_in);
+  const int tmax = wv::first_int(tmax_in), iterations = wv::first_int(iterations_in);
+  const int cnt_my = cnt_in, base_my = base_in;
+  const int kme = L & 15;
+  const bool has0 = kme < cnt_my, has1 = kme + 16 < cnt_my;
+  const int row0 = has0 ? I[o_rowid + base_my + kme] : 0, row1 = has1 ? I[o_rowid + base_my + kme + 16] : 0;
+  real* Rm0 = S + o_row + ROW_STRIDE * row0;
+  real* Rm1 = S + o_row + ROW_STRIDE * row1;
+  real f0 = has0 ? Rm0[ROW_F] : 0.0, f1 = has1 ? Rm1[ROW_F] : 0.0;
+  const real b0 = has0 ? Rm0[ROW_B] : 0.0, b1 = has1 ? Rm1[ROW_B] : 0.0;
+  const real R0 = has0 ? Rm0[ROW_R] : 0.0, R1 = has1 ? Rm1[ROW_R] : 0.0;
+  const real aii0 = has0 ? Rm0[ROW_ARII] : 1.0, aii1 = has1 ? Rm1[ROW_ARII] : 1.0;
+  const real ainv0 = 1.0 / aii0, ainv1 = 1.0 / aii1;
+  real W0[16], W1[16], A0[32], A1[32];
+#pragma unroll
+  for (int d = 0; d < 16; d++) {
+    const real di = S[o_Dinv + adr0 + d];                                        // (slots past the tree's dofs hold 0 in J)
+    W0[d] = has0 ? S[o_J + JW * row0 + d] * di : 0.0;
+    W1[d] = has1 ? S[o_J + JW * row1 + d] * di : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 32; k++) { A0[k] = 0; A1[k] = 0; }
+  // rows of AR: the tree's KK-th row against the lane's two rows (its id over DPP from the lane that owns it)
+#define MJ_ASTEP(KK)                                                                  \
+    if (KK >= tmax) break;                                                            \
+    {                                                                                 \
+      const int rk = KK < 16 ? wv::bcast16i<(KK & 15)>(row0) : wv::bcast16i<(KK & 15)>(row1); \
+      const real* Bk = S + o_J + JW * rk;                                             \
+      real p0 = 0, p1 = 0, p2 = 0, p3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;            \
+      _Pragma("unroll")                                                               \
+      for (int d = 0; d < 16; d += 4) {                                               \
+        const real e0 = Bk[d], e1 = Bk[d + 1], e2 = Bk[d + 2], e3 = Bk[d + 3];        \
+        p0 += W0[d] * e0; p1 += W0[d + 1] * e1; p2 += W0[d + 2] * e2; p3 += W0[d + 3] * e3; \
+        q0 += W1[d] * e0; q1 += W1[d + 1] * e1; q2 += W1[d + 2] * e2; q3 += W1[d + 3] * e3; \
+      }                                                                               \
+      real acc0 = (p0 + p1) + (p2 + p3), acc1 = (q0 + q1) + (q2 + q3);                \
+      if (KK >= cnt_my) { acc0 = 0; acc1 = 0; }                                       \
+      if (KK == kme) acc0 += R0;                                                      \
+      if (KK == kme + 16) acc1 += R1;                                                 \
+      A0[KK] = acc0; A1[KK] = acc1;                                                   \
+    }
+  do { MJ_ROWS32(MJ_ASTEP) } while (0);
+#undef MJ_ASTEP
+  real r0 = b0, r1 = b1;
+#define MJ_RINIT(KK) if (KK >= tmax) break; { const real fk = tall_bcast<KK>(f0, f1); r0 += A0[KK] * fk; r1 += A1[KK] * fk; }
+  do { MJ_ROWS32(MJ_RINIT) } while (0);
+#undef MJ_RINIT
+  {      // warm start: keep last step's forces only if they beat f = 0; cost(f) = 1/2 f'(r + b)
+    const real cost = wv::rows_sum(wv::sum16(0.5 * f0 * (r0 + b0) + 0.5 * f1 * (r1 + b1)), ntree);
+    const bool cold = cost > 0;
+    f0 = cold ? 0.0 : f0; f1 = cold ? 0.0 : f1;
+    r0 = cold ? b0 : r0; r1 = cold ? b1 : r1;
+  }
+  real s0 = r0 * ainv0, s1 = r1 * ainv1;             // scaled residuals (stage_pgs)
+#pragma unroll
+  for (int k = 0; k < 32; k++) { A0[k] *= ainv0; A1[k] *= ainv1; }
+  const real haii0 = 0.5 * aii0, haii1 = 0.5 * aii1;
+  real f0_start = f0, f1_start = f1, s0_start = s0, s1_start = s1;
+  real f0_prev = f0, f1_prev = f1, s0_prev = s0, s1_prev = s1;
+  real c0_prev = 0, c1_prev = 0;
+  bool pending = false, guarded = false;
+  while (iter < iterations) {
+    const int kme_s = wv::opaque_lane(kme), tmax_s = wv::opaque_uniform(tmax);
+    f0_start = f0; f1_start = f1; s0_start = s0; s1_start = s1;
+    real ns0 = -s0, ns1 = -s1, nss0 = ns0, nss1 = ns1;
+    const real nf0 = -f0, nf1 = -f1;
+    // the stop test of the sweep before, decided in the shadow of this sweep's first two row steps (stage_pgs); one row
+    // whose own cost decrease exceeds the threshold by more than the other rows could take back (64 x 1e-10) decides
+    unsigned long long refused = 0ull, deciding = 1ull;
+    if (pending) {
+      refused = wv::ballot(c0_prev > 1e-10 || c1_prev > 1e-10);
+      deciding = wv::ballot((fmax(-c0_prev, -c1_prev) - 1e-8) * scale >= tolerance);
+    }
+#define MJ_FSTEP(KK)                                                                  \
+      {                                                                               \
+        const real db = wv::bcast16<(KK & 15)>(KK < 16 ? fmax(ns0, nf0) : fmax(ns1, nf1)); \
+        if (kme_s == (KK & 15)) { if (KK < 16) nss0 = ns0; else nss1 = ns1; }         \
+        ns0 = __builtin_fma(-A0[KK], db, ns0);                                        \
+        ns1 = __builtin_fma(-A1[KK], db, ns1);                                        \
+      }
+    MJ_FSTEP(0) MJ_FSTEP(1)
+    if (pending && (refused != 0ull || deciding == 0ull)) {
+      const real improvement = wv::rows_sum(wv::sum16(-c0_prev - c1_prev), ntree);
+      if (refused != 0ull || wv::ballot(improvement * scale < tolerance)) {
+        if (refused != 0ull) { f0 = f0_prev; f1 = f1_prev; s0 = s0_prev; s1 = s1_prev; iter--; guarded = true; }
+        else { s0 = s0_start; s1 = s1_start; }
+        pending = false;
+        break;
+      }
+    }
+    MJ_FSTEP(2) MJ_FSTEP(3) MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7) MJ_FSTEP(8) MJ_FSTEP(9)
+    MJ_FSTEP(10) MJ_FSTEP(11) MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15) MJ_FSTEP(16)
+    do {
+      if (17 >= tmax_s) break;
+      MJ_FSTEP(17) MJ_FSTEP(18) MJ_FSTEP(19)
+      if (20 >= tmax_s) break;
+      MJ_FSTEP(20) MJ_FSTEP(21) MJ_FSTEP(22) MJ_FSTEP(23)
+      if (24 >= tmax_s) break;
+      MJ_FSTEP(24) MJ_FSTEP(25) MJ_FSTEP(26) MJ_FSTEP(27)
+      if (28 >= tmax_s) break;
+      MJ_FSTEP(28) MJ_FSTEP(29) MJ_FSTEP(30) MJ_FSTEP(31)
+    } while (0);
+#undef MJ_FSTEP
+    s0 = -ns0; s1 = -ns1;
+    const real ss0 = -nss0, ss1 = -nss1;
+    f0 = fmax(f0_start - ss0, 0.0); f1 = fmax(f1_start - ss1, 0.0);
+    const real d0 = f0 - f0_start, d1 = f1 - f1_start;
+    c0_prev = d0 * d0 * haii0 + d0 * (ss0 * aii0);
+    c1_prev = d1 * d1 * haii1 + d1 * (ss1 * aii1);
+    f0_prev = f0_start; f1_prev = f1_start; s0_prev = s0_start; s1_prev = s1_start;
+    pending = true;
+    iter++;
+  }
+  if (pending && wv::ballot(c0_prev > 1e-10 || c1_prev > 1e-10)) {      // the sweep cap was reached and the last sweep has a refused step
+    f0 = f0_prev; f1 = f1_prev; s0 = s0_prev; s1 = s1_prev; iter--; guarded = true;
+  }
+  while (guarded && iter < iterations) {
+    real imp = 0;
+    const int kme_g = wv::opaque_lane(kme);
+#define MJ_GSTEP(KK)                                                                  \
+    if (KK < tmax) {                                                                  \
+      const real fo = KK < 16 ? f0 : f1, so = KK < 16 ? s0 : s1;                      \
+      const real ao = KK < 16 ? aii0 : aii1, ho = KK < 16 ? haii0 : haii1;            \
+      real fn = fmax(fo - so, 0.0);                                                   \
+      real delta = fn - fo;                                                           \
+      real change = delta * delta * ho + delta * (so * ao);                           \
+      const bool act = kme_g == (KK & 15) && (KK < 16 ? has0 : has1) && !(change > 1e-10); \
+      if (!act) { delta = 0; change = 0; fn = fo; }                                   \
+      if (KK < 16) f0 = fn; else f1 = fn;                                             \
+      imp -= change;                                                                  \
+      const real db = wv::bcast16<(KK & 15)>(delta);                                  \
+      s0 += A0[KK] * db;                                                              \
+      s1 += A1[KK] * db;                                                              \
+    }
+    MJ_ROWS32(MJ_GSTEP)
+#undef MJ_GSTEP
+    iter++;
+    if (wv::rows_sum(wv::sum16(imp), ntree) * scale < tolerance) break;
+  }
+  if (has0) Rm0[ROW_F] = f0;
+  if (has1) Rm1[ROW_F] = f1;
+  real u = 0;       // u = B' f for the lane's dof
+#define MJ_USTEP(KK)                                                                  \
+    if (KK >= tmax) break;                                                            \
+    {                                                                                 \
+      const real fk = tall_bcast<KK>(f0, f1);                                         \
+      const int rk = KK < 16 ? wv::bcast16i<(KK & 15)>(row0) : wv::bcast16i<(KK & 15)>(row1); \
+      if (dof && KK < cnt_my) u += S[o_J + JW * rk + kme] * fk;                       \
+    }
+  do { MJ_ROWS32(MJ_USTEP) } while (0);
+#undef MJ_USTEP
+  TallOut out;
+  out.u = u; out.iter = iter;
+  return out;
+}
+#undef MJ_ROWS32
+
 // The sweep of a copy on a row schedule (pgs_coupled_schedule: every tree's list of rows, coupling rows at the same
 // position of both their trees' lists) of at most 16 positions, with everything but the arithmetic out of the loop:
 // the lane's coefficient in the row at every position in 16 registers, the rows' records (R, b, AR_ii, its reciprocal,
@@ -1753,7 +1931,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   real dinv = dof ? S[l.Dinv + mydof] : 0.0;
   real u = 0;
   if (nefc == 0) {
-    if (L == 0) I[I_NITER] = 0;
+    if (L == 0) { I[I_NITER] = 0; I[I_COST] = 1; }
     if (L < m.nv) { S[l.qfc + L] = 0; S[l.qacc + L] = S[l.qaccs + L]; }
     wv::sync();
     return;
@@ -1787,7 +1965,11 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   wv::sync();
   MJ_SUBSTAMP(ST_PGS_LISTS)
   const bool wide = m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree <= 2;
-  const bool in_registers = (m.rowmap && !cross && tmax <= 16) || wide;
+  const bool tall = m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree > 2 && m.ntree <= 4;     // pgs_tall_registers
+  const bool in_registers = (m.rowmap && !cross && tmax <= 16) || wide || tall;
+  // what a sweep of this copy costs relative to one of the 16-row register solver (for the longest-first dispatch: rows x
+  // sweeps of a copy on the wide, schedule or serial path stand for three to four times the wave time)
+  if (L == 0) I[I_COST] = (in_registers && !wide && !tall) ? 1 : (tall ? 2 : 4);
   if (!in_registers) {
     // warm start: keep the forces implied by last step's acceleration only if they beat f = 0
     if (dof)
@@ -1813,6 +1995,12 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     const WideOut wo = pgs_wide_registers(S, I, L, cnt_w, base_w, tmax, dof, l.i_rowid, l.row, l.J, l.Dinv, m.iterations, wadr0,
                                           m.tolerance, scale, iter);
     u = wo.u; iter = wv::first_int(wo.iter);
+    wv::sync();
+  } else if (tall) {
+    const int tadr0 = mytree < m.ntree ? m.tree_dofadr[mytree] : 0;
+    const TallOut to = pgs_tall_registers(S, I, L, mytree < m.ntree ? cnt_my : 0, base_my, tmax, dof, l.i_rowid, l.row, l.J, l.Dinv,
+                                          m.iterations, tadr0, m.ntree, m.tolerance, scale, iter);
+    u = to.u; iter = wv::first_int(to.iter);
     wv::sync();
   } else if (in_registers) {
     // Residual form, all in registers: with at most 16 rows per tree, lane k of a tree's 16 lanes owns the tree's
@@ -2734,7 +2922,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
 #define MJ_FILE_WORK                                                                                         \
   if (a.lpt_count_out && L == 0) {                                                                           \
     const int* Iw = (const int*)(S + l.ints);                                                                \
-    unsigned work = reset_only ? 0u : (unsigned)(Iw[I_NEFC] * Iw[I_NITER]);                                  \
+    unsigned work = reset_only ? 0u : (unsigned)(Iw[I_NEFC] * Iw[I_NITER] * Iw[I_COST]);                     \
     int wb = work ? 32 - __builtin_clz(work) : 0;           /* bit length */                                 \
     if (wb > LPT_BUCKETS - 1) wb = LPT_BUCKETS - 1;                                                          \
     wv::atomic_add_noret(a.lpt_count_out + wb, 1);                                                           \
