@@ -1965,7 +1965,11 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   wv::sync();
   MJ_SUBSTAMP(ST_PGS_LISTS)
   const bool wide = m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree <= 2;
+#ifdef MJRL_NO_TALL       // (experiments: the schedule sweep for these copies, as before round 3)
+  const bool tall = false;
+#else
   const bool tall = m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree > 2 && m.ntree <= 4;     // pgs_tall_registers
+#endif
   const bool in_registers = (m.rowmap && !cross && tmax <= 16) || wide || tall;
   // what a sweep of this copy costs relative to one of the 16-row register solver (for the longest-first dispatch: rows x
   // sweeps of a copy on the wide, schedule or serial path stand for three to four times the wave time)
