@@ -1,5 +1,5 @@
 """Agent-scoped key/value store with buffered writes -- semantics of the reference's
-MuJoCo_Gym/data_store.py:1-113 (pinned by Testing/data_store_test.py, mirrored in tests/test_data_store.py).
+MuJoCo_Gym/data_store.py:1-113 (pinned by Testing/data_store_test.py; its seven cases and a reference-generated trace are checked in tests/test_golden_host.py).
 
 Behaviour that callers can observe and that is kept on purpose:
 * writes go to a per-agent buffer and become readable after ``commit()``;
