@@ -224,35 +224,46 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
     for (int k = 0; k < 4; k++)
       cosmin = fminf(cosmin, dotf(axis, pixel_ray(c0 + ((k & 1) ? 7.5f : 0.5f), r0 + ((k & 2) ? 7.5f : 0.5f))));
     const float cos_t = cosmin * (1.0f - 1e-5f) - 1e-6f, sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.0f));
-    bool cand = my_geom;
-    if (my_geom && my_type != GEOM_PLANE) {
-      const float along = dotf(my_rel, axis), perp = sqrtf(fmaxf(dotf(my_rel, my_rel) - along * along, 0.0f));
-      // (perp cos - along sin is a lower bound of the centre's distance to the cone, negative inside it)
-      cand = !(along + my_rb < 0.0f) && perp * cos_t - along * sin_t <= my_rb + 1e-5f * (1.0f + perp);
-    }
-    unsigned long long todo = wv::ballot(cand);
     const int r = r0 + (L >> 3), c = c0 + (L & 7);
     const bool inside = r < height && c < width;
     const int pix = r * width + c;
     const F3 vec = pixel_ray(c + 0.5f, r + 0.5f);
     float best = -1;
     int hit = -1;
-    while (todo) {
-      const int g = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      // (geom g's type, bounding radius and position come from lane g's registers: no memory latency per candidate)
-      int gt = wv::lane_int(my_type, g);
-      const F3 rel = f3(__int_as_float(wv::lane_int(__float_as_int(my_rel.x), g)), __int_as_float(wv::lane_int(__float_as_int(my_rel.y), g)),
-                        __int_as_float(wv::lane_int(__float_as_int(my_rel.z), g)));
-      if (!inside) gt = -1;
-      else if (gt != GEOM_PLANE) {
-        const float rb = __int_as_float(wv::lane_int(__float_as_int(my_rb), g));
-        const float along = dotf(rel, vec), d2 = dotf(rel, rel) - along * along;
-        if (d2 > rb * rb + 1e-5f * (1.0f + dotf(rel, rel)) || along + rb < 0.0f) gt = -1;
+    // the geoms in chunks of 64, lane g of a chunk standing for geom base + g (one chunk unless the level has more than
+    // 64 geoms; the first chunk's records live in registers for the whole kernel, a later chunk's are fetched per block)
+    auto visit = [&](int base, bool geom_on, int type_v, float rb_v, F3 rel_v) {
+      bool cand = geom_on;
+      if (geom_on && type_v != GEOM_PLANE) {
+        const float along = dotf(rel_v, axis), perp = sqrtf(fmaxf(dotf(rel_v, rel_v) - along * along, 0.0f));
+        // (perp cos - along sin is a lower bound of the centre's distance to the cone, negative inside it)
+        cand = !(along + rb_v < 0.0f) && perp * cos_t - along * sin_t <= rb_v + 1e-5f * (1.0f + perp);
       }
-      if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
-      const float x = ray_geomf(gt, rel, GM + 9 * g, ldf3(GS + 3 * g), origin, vec);
-      if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
+      unsigned long long todo = wv::ballot(cand);
+      while (todo) {
+        const int g = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        // (geom g's type, bounding radius and position come from lane g's registers: no memory latency per candidate)
+        int gt = wv::lane_int(type_v, g);
+        const F3 rel = f3(__int_as_float(wv::lane_int(__float_as_int(rel_v.x), g)), __int_as_float(wv::lane_int(__float_as_int(rel_v.y), g)),
+                          __int_as_float(wv::lane_int(__float_as_int(rel_v.z), g)));
+        if (!inside) gt = -1;
+        else if (gt != GEOM_PLANE) {
+          const float rb = __int_as_float(wv::lane_int(__float_as_int(rb_v), g));
+          const float along = dotf(rel, vec), d2 = dotf(rel, rel) - along * along;
+          if (d2 > rb * rb + 1e-5f * (1.0f + dotf(rel, rel)) || along + rb < 0.0f) gt = -1;
+        }
+        if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
+        const float x = ray_geomf(gt, rel, GM + 9 * (base + g), ldf3(GS + 3 * (base + g)), origin, vec);
+        if (x >= 0 && (best < 0 || x < best)) { best = x; hit = base + g; }
+      }
+    };
+    visit(0, my_geom, my_type, my_rb, my_rel);
+    for (int base = 64; base < m.ngeom; base += 64) {
+      const int g = base + L;
+      const bool on = g < m.ngeom && rgba_of(g < m.ngeom ? g : 0, 3) != 0;
+      visit(base, on, on ? m.geom_type[g] : -1, on ? (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f : 0.0f,
+            on ? ldf3(GP + 3 * g) : origin);
     }
     unsigned char out[3] = {0, 0, 0};
     if (hit >= 0) {
@@ -475,8 +486,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   int rc = mjrl_model_from_blob(&e->hm, e->h_blob.data(), nbytes, e->h_blob.data());
   if (rc) return fail(2, "mjrl_create: model blob rejected (magic/version/size), code " + std::to_string(rc));
   const DevModel& m = e->hm;
-  if (m.nv < 1 || m.nv > 64 || m.nbody > 64 || m.njnt > 64 || m.ngeom > 64)
-    return fail(3, "mjrl_create: the model must fit one wavefront (1 <= nv <= 64; nbody, njnt, ngeom <= 64)");
+  if (m.nv < 1 || m.nv > 64 || m.nbody > 64 || m.njnt > 64 || m.ngeom > 128)
+    return fail(3, "mjrl_create: the model must fit one wavefront (1 <= nv <= 64; nbody, njnt <= 64; ngeom <= 128)");
   if (m.maxdofdepth + 1 > mj::MAX_DOF_DEPTH) return fail(3, "mjrl_create: kinematic chains deeper than 8 dofs are not supported");
   if (m.nconmax > 64 || m.nconmax < 1) return fail(3, "mjrl_create: nconmax must be in 1..64");
   if (m.njmax > 511 || m.njmax < 1) return fail(3, "mjrl_create: njmax must be in 1..511");

@@ -10,7 +10,10 @@
 // Lane mappings change from stage to stage (lane = body, joint, dof, geom, narrow-phase work item,
 // constraint row); stages exchange data through LDS and are separated by wv::sync().  Per-lane model
 // constants (the lane's body / dof record) are read from HBM once per launch into registers (LaneK).
-// The model must fit one wave: nbody, njnt, nv, ngeom <= 64 (checked by mjrl_create).
+// The model must fit one wave: nbody, njnt, nv <= 64; ngeom <= 128 (checked by mjrl_create).  Geoms past the 64th --
+// arenas with more scenery; the model compiler folds jointless bodies into the world when there are too many bodies --
+// take a second pass in the three places where a lane stands for a geom (geom frames, rangefinder targets, the ray
+// kernel's candidates); a level with at most 64 geoms compiles to the code it had.
 #ifndef MJRL_STEP_H
 #define MJRL_STEP_H
 
@@ -793,6 +796,12 @@ __device__ inline void stage_geoms(const DevModel& m, const Lay& l, const GeomK&
     Quat quat = qmul(bq, G.quat);
     st3(S + l.gpos + 3 * L, pos);
     stq(S + l.gquat + 4 * L, quat);
+  }
+  for (int g = 64 + L; g < m.ngeom; g += 64) {      // (geoms past the 64th: their records straight from the model)
+    V3 pos; Quat quat;
+    geom_frame(m, l, S, g, pos, quat);
+    st3(S + l.gpos + 3 * g, pos);
+    stq(S + l.gquat + 4 * g, quat);
   }
   // the geom sizes go next to the work items of the collision stage (scratch area of `u`, free since the composite
   // inertias were consumed)
@@ -2423,6 +2432,20 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
           }
           real x = ray_geom(gt, rg_pos, rg_mat, rg_size, sp, vec);
           if (x >= 0) best = x;
+        }
+        for (int g = 64 + L; g < m.ngeom; g += 64) {      // (targets past the 64th geom: the same tests, records from the model)
+          if (m.geom_rgba[4 * g + 3] == 0 || m.geom_bodyid[g] == body) continue;
+          V3 gp; Quat gq;
+          geom_frame(m, l, S, g, gp, gq);
+          int gt = m.geom_type[g];
+          const real rb = m.geom_rbound[g];
+          if (gt != GEOM_PLANE) {
+            V3 rel = gp - sp;
+            real t = dot(rel, vec), d2 = dot(rel, rel) - t * t;
+            if (d2 > rb * rb * (1.0 + 1e-9) + 1e-12 || t + rb < -1e-9) gt = -1;
+          }
+          real x = ray_geom(gt, gp, qmat(gq), ld3(m.geom_size + 3 * g), sp, vec);
+          if (x >= 0 && x < best) best = x;
         }
         best = wv::min_pos(best);
         real out = best > 1e299 ? -1.0 : best;

@@ -300,6 +300,70 @@ class _Compiler:
                                         jnts=[], geoms=[]))
                 self._body_children(child, new_id, a.get("childclass", childclass))
 
+    def fuse_static(self):
+        """Fold every body that cannot move -- no joint on it or on any ancestor -- into the world body: its geoms, sites,
+        cameras and lights become the world's, at their composed poses.  What MuJoCo's ``<compiler fusestatic>`` does; here
+        it is applied only when a level has more bodies than a wavefront has lanes (the arena's walls and boxes are one
+        body each).  Physics is unchanged -- a static body has no dofs, and contacts against it are contacts against the
+        world --, geom ids are unchanged, body ids shrink.  Returns {name: record} of the folded bodies so that host
+        queries by body name (``get_data``, ``distance``, tags) still answer: position = the body's inertial position."""
+        nb = len(self.bodies)
+        static = [False] * nb
+        static[0] = True
+        for b in range(1, nb):
+            static[b] = static[self.bodies[b]["parent"]] and not self.bodies[b]["jnts"]
+        # world pose of every static body (parents come first)
+        wpos, wquat = [np.zeros(3)] * nb, [np.array([1.0, 0, 0, 0])] * nb
+        for b in range(1, nb):
+            if static[b]:
+                p = self.bodies[b]["parent"]
+                wpos[b] = wpos[p] + quat_to_mat(wquat[p]) @ self.bodies[b]["pos"]
+                wquat[b] = quat_mul(wquat[p], self.bodies[b]["quat"])
+        folded = {}
+        for b in range(1, nb):
+            if not static[b]:
+                continue
+            body = self.bodies[b]
+            rot = quat_to_mat(wquat[b])
+            for kind in (self.geoms, self.sites, self.cams, self.lights):
+                for item in kind:
+                    if item["body"] == b:
+                        item["pos"] = wpos[b] + rot @ item["pos"]
+                        if "quat" in item:
+                            item["quat"] = quat_mul(wquat[b], item["quat"])
+                        if "dir" in item:
+                            item["dir"] = rot @ item["dir"]
+                        item["body"] = 0
+            self.bodies[0]["geoms"] += body["geoms"]
+            if body["name"]:
+                # (inertial position: the mass-weighted centre of its geoms, now in world coordinates)
+                parts = [(_geom_mass_inertia(self.geoms[g])[0], self.geoms[g]["pos"]) for g in body["geoms"]]
+                total = sum(mass for mass, _ in parts)
+                xipos = sum(mass * pos for mass, pos in parts) / total if total > 0 else wpos[b].copy()
+                folded[body["name"]] = dict(pos=wpos[b].copy(), quat=wquat[b].copy(), geoms=list(body["geoms"]),
+                                            xipos=np.asarray(xipos, np.float64), mass=float(total))
+        self.bodies[0]["geoms"].sort()
+        # moving bodies whose parent was folded hang off the world at their composed pose
+        for b in range(1, nb):
+            p = self.bodies[b]["parent"]
+            if not static[b] and p != 0 and static[p]:
+                self.bodies[b]["pos"] = wpos[p] + quat_to_mat(wquat[p]) @ self.bodies[b]["pos"]
+                self.bodies[b]["quat"] = quat_mul(wquat[p], self.bodies[b]["quat"])
+                self.bodies[b]["parent"] = 0
+        # renumber
+        new_id, kept = {}, []
+        for b in range(nb):
+            if b == 0 or not static[b]:
+                new_id[b] = len(kept)
+                kept.append(self.bodies[b])
+        for body in kept:
+            body["parent"] = new_id[body["parent"]]
+        for kind in (self.geoms, self.sites, self.cams, self.lights, self.joints):
+            for item in kind:
+                item["body"] = new_id[item["body"]]
+        self.bodies = kept
+        return folded
+
     def _add_joint(self, elem, body_id, childclass):
         if elem.tag == "freejoint":
             a = dict(elem.attrib)
@@ -406,20 +470,30 @@ SUPPORTED_PAIRS = {
 }
 
 
+MAX_LANE_BODIES = 64      # a wavefront's lanes: bodies, joints and dofs of a level must fit (geoms: two passes, 128)
+
+
 def compile_mjcf(xml_path: str, nconmax: int | None = None, njmax: int | None = None, lane_map: bool = True,
-                 broad_cull: bool = True) -> Model:
+                 broad_cull: bool = True, fuse_static: bool | None = None) -> Model:
     with open(xml_path, "r") as fh:
         text = fh.read()
-    return compile_mjcf_string(text, xml_path=xml_path, nconmax=nconmax, njmax=njmax, lane_map=lane_map, broad_cull=broad_cull)
+    return compile_mjcf_string(text, xml_path=xml_path, nconmax=nconmax, njmax=njmax, lane_map=lane_map, broad_cull=broad_cull,
+                               fuse_static=fuse_static)
 
 
 def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None, lane_map: bool = True,
-                        broad_cull: bool = True) -> Model:
+                        broad_cull: bool = True, fuse_static: bool | None = None) -> Model:
     """``lane_map=False`` withholds the tree-row lane map even from a model that qualifies for it (a model with more
-    than four trees or more than 16 dofs in a tree never gets it): the kernels then take their general paths."""
+    than four trees or more than 16 dofs in a tree never gets it): the kernels then take their general paths.
+    ``fuse_static``: fold the bodies that cannot move into the world (``_Compiler.fuse_static``); ``None`` = only when
+    the level has more than 64 bodies, so that every level that fits keeps MuJoCo's body ids."""
     c = _Compiler(text)
     c.walk()
+    folded = {}
+    if fuse_static or (fuse_static is None and len(c.bodies) > MAX_LANE_BODIES):
+        folded = c.fuse_static()
     m = Model(xml_path=xml_path)
+    m.folded_bodies = folded
     A = m.arrays
     opt = c.root.find("option")
     opt = opt.attrib if opt is not None else {}

@@ -89,6 +89,15 @@ class DataView:
         return _Named(id=view.id, name=name, data=self._squeeze(data))
 
     def body(self, name):
+        folded = getattr(self._p._compiled, "folded_bodies", {})
+        if name in folded:
+            # a static body the model compiler folded into the world (levels with more bodies than a wavefront has lanes,
+            # mjcf.fuse_static): it does not move, its frame is a constant of the model
+            rec, n = folded[name], self._p.n_env
+            rows = lambda v: self._squeeze(np.tile(np.asarray(v, np.float64), (n, 1)))
+            xipos = self._p._folded_xipos(name)
+            return _Named(id=-1, name=name, xpos=rows(rec["pos"]), xipos=rows(xipos), xquat=rows(rec["quat"]),
+                          xmat=rows(mjcf.quat_to_mat(rec["quat"]).reshape(9)))
         b = self._p._compiled.name2id("body", name)
         q = self._p._handle.query
         xquat = q("xquat")[:, b]
@@ -408,9 +417,22 @@ class MuJoCoParent:
         return self._squeeze(self._obs_cache[:, k, :self._obs_len[agent]].copy())
 
     # ------------------------------------------------------------------ plugin query helpers
+    def _folded_xipos(self, name):
+        """Inertial position of a static body the model compiler folded into the world (a constant of the model)."""
+        return self._compiled.folded_bodies[name]["xipos"]
+
+    def _folded_mass(self, name):
+        return self._compiled.folded_bodies[name]["mass"]
+
     def get_data(self, name: str) -> dict:
         """Body (xipos, mass, euler zyx deg) or geom record (mujoco_parent.py:394-426)."""
         names = self._compiled.names
+        if name in getattr(self._compiled, "folded_bodies", {}):
+            body = self.data.body(name)
+            xmat = np.asarray(body.xmat).reshape(-1, 9)
+            euler = np.stack([mat2euler_scipy(x) for x in xmat])
+            return {"position": body.xipos, "mass": np.array([self._folded_mass(name)]), "orientation": self._squeeze(euler),
+                    "id": body.id, "name": name, "type": "body"}
         if name in names["body"]:
             body = self.data.body(name)
             xmat = np.asarray(body.xmat).reshape(-1, 9)
@@ -431,7 +453,7 @@ class MuJoCoParent:
         (mujoco_parent.py:428-449)."""
         def coordinates(obj):
             if isinstance(obj, str):
-                if obj in self._compiled.names["body"]:
+                if obj in self._compiled.names["body"] or obj in getattr(self._compiled, "folded_bodies", {}):
                     return np.asarray(self.data.body(obj).xipos)
                 return np.asarray(self.data.geom(obj).xpos)
             return np.asarray(obj, dtype=np.float64)

@@ -400,7 +400,11 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
         names = self._compiled.names
         refs = []
         for name in self.tagged_names(tag):
-            if name in names["body"]:
+            folded = getattr(self._compiled, "folded_bodies", {})
+            if name in folded and folded[name]["geoms"]:
+                # a static body folded into the world: its (single, centred) geom stands for it -- geom xpos = body xipos
+                refs.append((1, folded[name]["geoms"][0]))
+            elif name in names["body"]:
                 refs.append((0, names["body"].index(name)))
             elif name in names["geom"]:
                 refs.append((1, names["geom"].index(name)))

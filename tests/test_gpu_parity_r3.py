@@ -313,3 +313,48 @@ def test_render_kernel_shades_like_the_oracle(tmp_path):
             assert (np.abs(got[1, 0] - ref).max(axis=-1) > 0).mean() < 0.01, (k, size)
             assert k == 2 or len(np.unique(ref.reshape(-1, 3), axis=0)) > 20    # a graded image (the directional case is flat)
         h.close(); ora.close()
+
+
+# --------------------------------------------------------------------------- levels with more bodies / geoms than lanes
+def test_arena_with_73_geoms_on_the_device(tmp_path):
+    """74 bodies, 73 geoms: the compiler folds the static bodies into the world (53 bodies left), the kernels take geoms
+    64..72 in a second pass.  Both kernel builds follow the oracle (contacts, rows, sweeps, state, rangefinder readings),
+    the cameras see the late geoms like the oracle's ray caster does, and a folded body still answers by name."""
+    from tests.test_big_levels import big_level_text
+    path = tmp_path / "big_arena.xml"
+    path.write_text(big_level_text())
+    model = mjcf.compile_mjcf(str(path))
+    assert (model.nbody, model.ngeom) == (53, 73)
+    packed = blob.pack(model)
+    for specialize in (True, False):
+        h = _capi.Handle(packed, 3, specialize=specialize)
+        h.reset()
+        oras = [OracleEnv(packed) for _ in range(3)]
+        rng = np.random.default_rng(2)
+        for step in range(150):
+            ctrl = rng.uniform(-1, 1, (3, model.nu))
+            h.set_field("ctrl", ctrl)
+            h.step_device(None, 0, 1)
+            for e, o in enumerate(oras):
+                o.ctrl[:] = ctrl[e]
+                o.step()
+            if step % 25 == 24:
+                stats = h.get_field("solver_stats")
+                for e, o in enumerate(oras):
+                    assert (stats[e, 0], stats[e, 1], stats[e, 2]) == (o.ncon, o.nefc, o.niter), (specialize, step, e)
+        q = h.get_field("qpos")
+        for e, o in enumerate(oras):
+            assert np.allclose(q[e], o.qpos, rtol=0, atol=1e-9)
+            assert np.allclose(h.get_field("sensordata")[e], o.sensordata, atol=1e-7)
+        assert max(o.ncon for o in oras) > 0
+        got = h.render(64, 64).astype(int)
+        for cam in (0, 3):
+            ref = oras[1].render(cam, 64, 64).reshape(64, 64, 3).astype(int)
+            assert np.abs(got[1, cam] - ref).max() <= 255 and (np.abs(got[1, cam] - ref).max(axis=-1) > 0).mean() < 0.01
+        h.close()
+    env = MuJoCoRL({"xmlPath": str(path), "agents": ["sender", "receiver", "agent_3", "agent_4"], "numEnvs": 2})
+    env.reset()
+    rec = env.get_data("pillar_3")
+    assert rec["type"] == "body" and np.allclose(rec["position"], [[-8 + 1.3 * 3, 3.5, 0.3]] * 2)
+    assert np.allclose(env.distance("pillar_3", "pillar_4"), np.linalg.norm([1.3, 7.0, 0.0]))
+    env.close()
