@@ -36,6 +36,10 @@ def lib():
                                ctypes.c_int, ctypes.c_int, P, P, ctypes.c_int, ctypes.c_int, P, P, P, P, P, P]
         L.emu_set_step_reset.argtypes = [ctypes.c_int, P]
         L.emu_set_step_reset.restype = None
+        L.emu_set_reset_sens.argtypes = [P]
+        L.emu_set_reset_sens.restype = None
+        L.emu_set_autoreset.argtypes = [P, ctypes.c_int, P]
+        L.emu_set_autoreset.restype = None
         L.emu_set_tags.argtypes = [P, P, P, ctypes.c_int]
         L.emu_set_tags.restype = None
         L.emu_set_lpt.argtypes = [P, P, ctypes.c_int]
@@ -148,7 +152,8 @@ class EmuEnv:
         return lib().emu_lds_offset(self.blob, len(self.blob), name.encode())
 
     def step(self, nsteps=1, skip_frames=1, dbg_stage=0, forward_only=False, actions=None, scatter=None, n_agent=0,
-             scatter_mode=0, gather=None, obs=None, program=None, max_steps=1 << 30, reset_warm=None):
+             scatter_mode=0, gather=None, obs=None, program=None, max_steps=1 << 30, reset_warm=None, reset_kind=1,
+             reset_sens=None, autoreset=None):
         """``program``: dict(prog_i, prog_f, n_slot, agent_body, agent_obs_len, store, reward, term, trunc) for the
         fused plugin ops.  ``reset_warm``: the first frame starts from the reset image (in-launch reset) with this warm
         start."""
@@ -159,9 +164,21 @@ class EmuEnv:
             ref = np.array([(k << 16) | i for t in tags for k, i in t] or [0], np.int32)
             self._tags = (adr, num, ref)
             lib().emu_set_tags(_p(adr), _p(num), _p(ref), int(program.get("env_base", 0)))
+        # (reset_kind 2: the flagged copy is reset without being stepped; autoreset = (flag byte array[1], mode, episode
+        # array[1]): the step keeps the flag itself, mjrl_set_autoreset; both need the reset image's sensor readings)
+        if reset_sens is not None:
+            self._reset_sens = np.ascontiguousarray(reset_sens, dtype=np.float64)
+            lib().emu_set_reset_sens(_p(self._reset_sens))
         if reset_warm is not None:
             self._reset_warm = np.ascontiguousarray(reset_warm, dtype=np.float64)
-            lib().emu_set_step_reset(1, _p(self._reset_warm))
+            lib().emu_set_step_reset(int(reset_kind), _p(self._reset_warm))
+        if autoreset is not None:
+            flag, mode, episode = autoreset
+            self._reset_warm = np.ascontiguousarray(self._reset_warm if reset_warm is None else reset_warm, dtype=np.float64)
+            lib().emu_set_step_reset(0, _p(self._reset_warm))
+            lib().emu_set_autoreset(_p(flag), int(mode), _p(episode))
+        else:
+            lib().emu_set_autoreset(None, 0, None)
         act_dim = 0 if actions is None else actions.shape[-1]
         obs_dim = 0 if gather is None else gather.shape[-1]
         rc = lib().emu_step(self.blob, len(self.blob), _p(self.qpos), _p(self.qvel), _p(self.ctrl), _p(self.warm),

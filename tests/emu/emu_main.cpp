@@ -146,9 +146,16 @@ int emu_lds_offset(const void* blob, size_t nbytes, const char* region) {
 
 // in-launch reset of the next emu_step call's first frame (mjrl_set_step_reset_mask): flag != 0 and the reset image's
 // warm start; cleared by the call
+// (flag 2: a reset without a step; reset_sens: the reset image's sensor readings, needed by that kind)
 static unsigned char g_reset_flag = 0;
-static const double* g_reset_warm = nullptr;
-void emu_set_step_reset(int flag, const double* reset_warm) { g_reset_flag = flag ? 1 : 0; g_reset_warm = reset_warm; }
+static const double *g_reset_warm = nullptr, *g_reset_sens = nullptr;
+void emu_set_step_reset(int flag, const double* reset_warm) { g_reset_flag = (unsigned char)(flag < 0 ? 0 : flag); g_reset_warm = reset_warm; }
+void emu_set_reset_sens(const double* reset_sens) { g_reset_sens = reset_sens; }
+// autoreset kept by the step itself (mjrl_set_autoreset): the copy's flag byte (read and written by every step) and the mode
+static unsigned char* g_auto_mask = nullptr;
+static int g_auto_mode = 0;
+static int* g_episode = nullptr;
+void emu_set_autoreset(unsigned char* mask_byte, int mode, int* episode) { g_auto_mask = mask_byte; g_auto_mode = mode; g_episode = episode; }
 
 // object-tag tables and the global id of the copy for the following emu_step calls (mjrl_set_tag_tables / mjrl_set_env_base)
 static const int32_t *g_tag_adr = nullptr, *g_tag_num = nullptr, *g_tag_ref = nullptr;
@@ -213,7 +220,9 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
       if (f > 0) b.scatter = nullptr;
       b.first_frame = f == 0;
       if (b.more_frames) { b.dbg = nullptr; b.frames = nullptr; }
-      if (s == 0 && g_reset_flag) { b.reset_mask = &g_reset_flag; b.reset_warm = g_reset_warm; }
+      b.reset_warm = g_reset_warm; b.reset_sens = g_reset_sens;
+      if (s == 0 && g_reset_flag) b.reset_mask = &g_reset_flag;
+      if (!forward_only) { b.auto_mask = g_auto_mask; b.auto_mode = g_auto_mode; b.episode = g_episode; }
       if (emu::run_wave(m, b, lds.data())) return 2;
     }
   }

@@ -379,8 +379,8 @@ def test_coupling_rows_in_several_tree_pairs_at_once():
 
 
 def test_more_than_sixteen_rows_per_tree_in_a_four_tree_model():
-    """17..32 rows in a tree of the 4-agent level: no idle lanes to spread a tree over, so the copy takes the
-    LDS-resident sweep with all four trees side by side.  One agent is lowered onto the floor with bent legs (four
+    """17..32 rows in a tree of the 4-agent level: no idle lanes to spread a tree over, so a lane owns two rows of its
+    tree (pgs_tall_registers, round 3; before: the sweep on the aligned schedule).  One agent is lowered onto the floor with bent legs (four
     foot contacts plus active joint limits) while the others fall; sweep counts and trajectories must be the
     oracle's."""
     model, ora, emu = pair("four_agent.xml")
@@ -668,3 +668,48 @@ def test_in_launch_reset_with_several_frames_per_step():
         assert np.array_equal(getattr(emu, name), getattr(fresh, name)), name
     assert np.array_equal(obs, obs2) and np.array_equal(store, store2)
     assert obs[0, 59] == 0 and obs[1, 59] == 2         # a fresh episode: the sender has heard nothing yet
+
+
+def test_reset_without_a_step_and_the_autoreset_kept_by_the_step():
+    """Round 3: a reset-mask byte of 2 resets a copy without stepping it (its outputs are the reset observation), and
+    with mjrl_set_autoreset the step itself records that a copy's episode ended and resets it in the next step -- mode 1
+    without a step (Gymnasium's next-step convention), mode 2 reset-then-step.  Device source on the CPU emulation
+    against the oracle, one and two frames per step."""
+    model = mjcf.compile_mjcf(levels.level_path("single_agent.xml"))
+    packed = blob.pack(model)
+    gather = np.array([[0] + [(1 << 24) | i for i in range(model.nq)] + [(2 << 24) | i for i in range(model.nv)]], np.int32)
+    scatter = np.arange(model.nu, dtype=np.int32).reshape(1, -1)
+    look = lambda o: np.concatenate([o.sensordata[:1], o.qpos, o.qvel])
+    for frames in (1, 2):
+        for mode in (1, 2):
+            ora, emu = OracleEnv(packed), EmuEnv(model, packed)
+            emu.step(forward_only=True)
+            reset_warm, reset_sens = emu.warm.copy(), emu.sens.copy()
+            first = look(ora)
+            flag, episode = np.zeros(1, np.uint8), np.zeros(1, np.int32)
+            obs = np.zeros((1, gather.shape[1]))
+            program = None
+            rng = np.random.default_rng(frames + 10 * mode)
+            horizon, t = 3, 0
+            for step in range(12):
+                act = rng.uniform(-1, 1, (1, model.nu))
+                pending = bool(flag[0])
+                trunc = np.zeros((1,), np.uint8)
+                prog = dict(prog_i=np.zeros((1, 8), np.int32), prog_f=np.zeros((1, 4)), n_op=0, n_slot=0, agent_body=np.zeros(1, np.int32),
+                            agent_obs_len=np.array([gather.shape[1]], np.int32), store=np.zeros(1), reward=np.zeros(1),
+                            term=np.zeros(1, np.uint8), trunc=trunc)
+                emu.step(skip_frames=frames, actions=act, scatter=scatter, n_agent=1, gather=gather, obs=obs, max_steps=horizon,
+                         program=prog, reset_warm=reset_warm, reset_sens=reset_sens, autoreset=(flag, mode, episode))
+                if pending:
+                    ora.reset()
+                    t = 0
+                    if mode == 1:                      # reset, not stepped: the reset observation, no flags, action ignored
+                        assert np.allclose(obs[0], first, atol=1e-12) and not trunc[0] and not flag[0] and emu.timestep[0] == 0
+                        continue
+                ora.ctrl[:] = act[0]
+                for _ in range(frames):
+                    ora.step()
+                t += 1
+                assert np.allclose(obs[0], look(ora), atol=1e-9), (frames, mode, step)
+                assert bool(trunc[0]) == (t == horizon + 1) and bool(flag[0]) == bool(trunc[0])
+            assert episode[0] >= 2

@@ -65,6 +65,38 @@ term, trunc = np.zeros((2, 2), np.uint8), np.zeros((2, 2), np.uint8)
 for t in range(6):
     batch.set_step_reset_mask(np.array([t == 3, t == 4], np.uint8))
     batch.step_batched(rng.uniform(-1, 1, (2, 2, 9)), obs, rew, term, trunc)
+# a reset without a step (mask byte 2) and the autoreset kept by the step itself, two frames per step
+model = mjcf.compile_mjcf(levels.level_path("single_agent.xml"))
+env = EmuEnv(model, blob.pack(model))
+env.step(forward_only=True)
+warm0, sens0 = env.warm.copy(), env.sens.copy()
+gather = np.array([[0] + [(1 << 24) | i for i in range(model.nq)] + [(2 << 24) | i for i in range(model.nv)]], np.int32)
+scatter = np.arange(model.nu, dtype=np.int32).reshape(1, -1)
+flag, episode, row = np.zeros(1, np.uint8), np.zeros(1, np.int32), np.zeros((1, gather.shape[1]))
+for mode in (1, 2):
+    for t in range(9):
+        prog = dict(prog_i=np.zeros((1, 8), np.int32), prog_f=np.zeros((1, 4)), n_op=0, n_slot=0, agent_body=np.zeros(1, np.int32),
+                    agent_obs_len=np.array([gather.shape[1]], np.int32), store=np.zeros(1), reward=np.zeros(1),
+                    term=np.zeros(1, np.uint8), trunc=np.zeros(1, np.uint8))
+        env.step(skip_frames=2, actions=rng.uniform(-1, 1, (1, model.nu)), scatter=scatter, n_agent=1, gather=gather, obs=row,
+                 max_steps=2, program=prog, reset_warm=warm0, reset_sens=sens0, autoreset=(flag, mode, episode))
+    env.step(actions=rng.uniform(-1, 1, (1, model.nu)), scatter=scatter, n_agent=1, gather=gather, obs=row, reset_warm=warm0,
+             reset_kind=2, reset_sens=sens0)
+assert episode[0] >= 4 and np.isfinite(row).all()
+# an arena with more geoms than lanes (second pass over geoms 64..72; static bodies folded into the world)
+from tests.test_big_levels import big_level_text
+model = mjcf.compile_mjcf_string(big_level_text())
+env = EmuEnv(model, blob.pack(model))
+for j in range(model.njnt):
+    if model.jnt_type[j] == mjcf.JNT_FREE:
+        env.qpos[model.jnt_qposadr[j] + 2] = 0.14
+env.step(forward_only=True)
+most = 0
+for t in range(60):
+    env.ctrl[:model.nu] = rng.uniform(-1, 1, model.nu)
+    img = env.step()
+    most = max(most, img.nefc)
+assert np.isfinite(env.qpos).all() and most > 16
 print("sanitized run ok")
 """
 

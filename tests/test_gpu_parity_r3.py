@@ -358,3 +358,43 @@ def test_arena_with_73_geoms_on_the_device(tmp_path):
     assert rec["type"] == "body" and np.allclose(rec["position"], [[-8 + 1.3 * 3, 3.5, 0.3]] * 2)
     assert np.allclose(env.distance("pillar_3", "pillar_4"), np.linalg.norm([1.3, 7.0, 0.0]))
     env.close()
+
+
+def test_autoreset_with_several_frames_per_step_and_runge_kutta():
+    """A reset-without-step has to hold through every launch of a step: two physics frames per step on the 2-agent level
+    (two launches) and the Runge-Kutta level (`ant.xml`: four launches per frame, eight per step).  Next-step autoreset
+    through the adapter, every copy against its oracle."""
+    from mjrl_amd.wrappers import BatchedVectorEnv
+    for level, agents, agent, nobs in (("single_agent.xml", ["sender"], "sender", 30), ("ant.xml", ["torso"], "torso", 29)):
+        horizon = 4
+        env = MuJoCoRL({"xmlPath": levels.level_path(level), "agents": agents, "numEnvs": 3, "maxSteps": horizon, "skipFrames": 2})
+        vec = BatchedVectorEnv(env, agent=agent)
+        obs, _ = vec.reset()
+        assert obs.shape == (3, nobs)
+        oras = [OracleEnv(env._blob) for _ in range(3)]
+        first = obs.copy()
+        idx = env.agents_action_index[agent]
+        nsens = env._compiled.nsensordata
+        look = lambda o: np.concatenate([o.sensordata[:nsens], o.qpos, o.qvel])
+        rng = np.random.default_rng(8)
+        t, pending = 0, False
+        for step in range(14):
+            act = rng.uniform(-1, 1, (3, len(idx)))
+            obs, rew, term, trunc, _ = vec.step(act)
+            if pending:
+                assert np.allclose(obs, first, atol=1e-12) and not trunc.any(), (level, step)
+                for o in oras:
+                    o.reset()
+                pending, t = False, 0
+                continue
+            for e, o in enumerate(oras):
+                o.ctrl[idx] = act[e]
+                o.step(); o.step()
+            t += 1
+            assert np.allclose(obs, np.stack([look(o) for o in oras]), atol=1e-9), (level, step)
+            if t == horizon + 1:
+                assert trunc.all()
+                pending = True
+            else:
+                assert not trunc.any()
+        vec.close()
