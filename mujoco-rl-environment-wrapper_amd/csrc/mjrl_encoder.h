@@ -243,17 +243,28 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void mjrl_encoder_dense_kernel(
   for (int u = 0; u < 2; u++)
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[u][t] = frag_cd{0, 0, 0, 0};
-#pragma unroll MJRL_DENSE_UNROLL
-  for (int kk = kk0; kk < kk0 + STEPS; kk++) {
-    frag_ab a[2], b[NT];
+  // The fragments of DENSE_BLOCK k-steps are fetched together, ahead of the multiplications that use them: left to the
+  // compiler, every k-step's nine loads were issued right before its MFMAs and the wave sat out a trip to L2 / HBM per
+  // step with four waves per CU to cover it (SQ_WAIT_ANY 88 % of the wave cycles): 14.8 -> 13.5 us.  (The scheduling
+  // fence keeps the loads of a block from being sunk back to their uses.)
+  constexpr int DENSE_BLOCK = MJRL_DENSE_UNROLL;
+  static_assert(STEPS % DENSE_BLOCK == 0, "k-steps per wave must be a multiple of the prefetch block");
+  for (int kb = kk0; kb < kk0 + STEPS; kb += DENSE_BLOCK) {
+    frag_ab a[DENSE_BLOCK][2], b[DENSE_BLOCK][NT];
 #pragma unroll
-    for (int u = 0; u < 2; u++) a[u] = arow[u][kk * 4];
+    for (int i = 0; i < DENSE_BLOCK; i++) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) b[t] = bcol[((size_t)kk * n_tile + t) * 64];
+      for (int u = 0; u < 2; u++) a[i][u] = arow[u][(kb + i) * 4];
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+      for (int t = 0; t < NT; t++) b[i][t] = bcol[((size_t)(kb + i) * n_tile + t) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < NT; t++) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[t], acc[u][t], 0, 0, 0);
+    for (int i = 0; i < DENSE_BLOCK; i++)
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][u], b[i][t], acc[u][t], 0, 0, 0);
   }
   // C layout: column (latent) = lane & 15, rows (images) = 4 (lane >> 4) + r
 #pragma unroll
