@@ -527,7 +527,8 @@ def main():
             "metric": "env-steps/sec", "value": n_env * world * args.steps / wall, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic" if not on_cpu else "REHEARSAL on the CPU emulation of the device source -- not a measurement",
+            "data": ("REHEARSAL on the CPU emulation of the device source -- not a measurement" if on_cpu else
+                     "REHEARSAL: every rank on device 0, gloo in place of RCCL -- not a measurement" if rehearsal else "synthetic"),
             "config": {"workload": f"{work['what']}, {n_env} env copies per GPU, skipFrames=1, PGS solver, episodes of "
                                    f"{EPISODE} steps with the copies' episode phases uniform over 0..{EPISODE - 1} (in-launch "
                                    f"reset of the copies whose episode is over); action scatter + physics step + per-agent "
