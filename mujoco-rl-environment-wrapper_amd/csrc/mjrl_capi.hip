@@ -25,7 +25,10 @@ __global__ __launch_bounds__(64) void mjrl_step_kernel(const DevModel* __restric
 // mjrl_step_debug / _profile / _timeline / _truncated and the LDS read-back of mjrl_query.  Same arithmetic, same bits.
 __global__ __launch_bounds__(64) void mjrl_step_kernel_diag(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
-  mj::env_step_t<true>(*mp, *mj::kernarg_step_args(8), lds);
+  // (the diagnostic build checks what the production build assumes: the arguments sit 8 bytes into the kernarg segment)
+  const mj::StepArgs* k = mj::kernarg_step_args(8);
+  if (k->qpos != a.qpos || k->n_env != a.n_env || k->lpt_words != a.lpt_words) __builtin_trap();
+  mj::env_step_t<true>(*mp, *k, lds);
 }
 
 // Masked reset of the HBM state: mj_resetData + mj_forward (mujoco_parent.py:349-350) for the selected copies.  Every

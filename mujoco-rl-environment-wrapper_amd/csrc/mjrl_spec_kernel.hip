@@ -35,6 +35,11 @@ extern "C" __global__ __launch_bounds__(64) MJRL_SPEC_OCCUPANCY void mjrl_step_k
   extern __shared__ double lds[];
   DevModel m;
   mjrl_model_from_base(&m, (const char MJRL_GLOBAL*)image);
-  // (`a` is read where the dispatch packet left it, field by field at its point of use: mj::kernarg_step_args)
-  mj::env_step_t<MJRL_SPEC_DIAG>(m, *mj::kernarg_step_args(8), lds);
+  // (`a` is read where the dispatch packet left it, field by field at its point of use: mj::kernarg_step_args; the
+  // diagnostic build checks the offset that assumes)
+  const mj::StepArgs* k = mj::kernarg_step_args(8);
+#ifdef MJRL_DIAG
+  if (k->qpos != a.qpos || k->n_env != a.n_env || k->lpt_words != a.lpt_words) __builtin_trap();
+#endif
+  mj::env_step_t<MJRL_SPEC_DIAG>(m, *k, lds);
 }
