@@ -352,7 +352,6 @@ struct mjrl_env {
   int n_env = 0, device = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
-  double* inertia = nullptr;       // [n_env][nM] scratch: the sparse inertia matrix between the CRB stage and the integrator
   unsigned long long* overflow = nullptr;   // [2] sticky cap-overflow counters (mjrl_cap_overflows)
   double* scene = nullptr;         // [n_env][12 ngeom + 12 ncam] geom and camera frames of the camera kernels
   double* rk = nullptr;            // [n_env][nq + 3 nv] Runge-Kutta scratch (models with <option integrator="RK4">)
@@ -457,7 +456,7 @@ void mjrl_destroy(mjrl_env* e) {
   void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_part, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
-                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->inertia, e->overflow, e->auto_mask};
+                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->overflow, e->auto_mask};
   for (void* p : ptrs) if (p) hipFree(p);
   void* pinned[] = {e->p_act, e->p_obs, e->p_rew, e->p_term, e->p_trunc};
   for (void* p : pinned) if (p) hipHostFree(p);
@@ -519,7 +518,6 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   CK(hipMalloc(&e->qvel, sizeof(double) * n_env * m.nv));
   CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
   CK(hipMalloc(&e->warm, sizeof(double) * n_env * m.nv));
-  CK(hipMalloc(&e->inertia, sizeof(double) * (size_t)n_env * (m.nM > 0 ? m.nM : 1)));
   if (m.integrator == 1) CK(hipMalloc(&e->rk, sizeof(double) * (size_t)n_env * (m.nq + 3 * m.nv)));
   CK(hipMalloc(&e->stats, sizeof(int) * 4 * (size_t)n_env));
   CK(hipMemset(e->stats, 0, sizeof(int) * 4 * (size_t)n_env));
@@ -991,7 +989,6 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   if (d_obs && !e->d_gather) MJRL_FAIL(e, 3, "step: observations requested but no gather table is set");
   mj::StepArgs a{};
   a.qpos = e->qpos; a.qvel = e->qvel; a.ctrl = e->ctrl; a.warm = e->warm; a.sensordata = e->sens;
-  a.inertia = e->inertia;
   a.overflow = e->overflow;
   a.stats = e->stats;
   a.timestep = e->timestep;

@@ -73,7 +73,7 @@ __host__ __device__ inline void make_layout(const DevModel& m, Lay& l) {
   REG(xpos, 3 * m.nbody) REG(xquat, 4 * m.nbody) REG(com, 3 * (m.ntree + 1))
   REG(cdof, 6 * m.nv)
   if (m.has_accel) { REG(cvel, 6 * m.nbody) REG(cdofdot, 6 * m.nv) REG(cacc, 6 * m.nbody) }
-  REG(LD, m.nM) REG(Dinv, m.nv)        // (the unfactorised inertia matrix lives in HBM: StepArgs::inertia)
+  REG(LD, m.nM) REG(Dinv, m.nv)        // (the unfactorised inertia matrix waits for the integrator in registers: MKeep)
   REG(bias, m.nv) REG(smooth, m.nv) REG(qaccs, m.nv) REG(qfc, m.nv)
   l.x = l.bias;      // solver / integrator temporary: the bias forces are dead once qfrc_smooth exists
   l.qacc = l.warm;   // the solver leaves the new acceleration in both; the old warm start is last read by the row build
@@ -120,11 +120,6 @@ struct Stamps {
 struct StepArgs {
   // state in HBM, [n_env][n] row-major
   real *qpos, *qvel, *ctrl, *warm, *sensordata;
-  // Per-copy scratch in HBM [n_env][nM]: the sparse inertia matrix M.  The CRB stage writes it (and its copy to be
-  // factorised, in LDS); only the integrator reads it again, a whole step later, for M + h*diag(damping).  Kept out
-  // of LDS it costs 2.6 KB of HBM traffic per copy and step and buys residency (the LDS image decides how many
-  // copies a CU holds, and the step rate follows that number almost linearly).
-  real* inertia;
   int* timestep;
   // action scatter (mujoco_parent.py:323-332): action slot -> ctrl index (mode 0) or qvel index (mode 1)
   const real* actions;       // [n_env][n_agent][act_dim], may be null (no scatter)
@@ -567,7 +562,24 @@ __device__ inline void stage_com_inertia(const DevModel& m, const Lay& l, const 
   wv::sync();
 }
 
-__device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L, real* Mg) {
+// The unfactorised inertia matrix between the CRB stage and the integrator (M + h*diag(damping) is factorised there, a
+// whole step of work later): element 64 k + L of the dof_Madr layout in lane L.  nM <= nv * MAX_DOF_DEPTH <= 512, i.e.
+// at most 8 doubles per lane -- 3 for the 2-agent level, where the matrix used to make a round trip through a per-copy
+// row in HBM (2.6 KB of traffic per copy and step, half of what the kernel moved).
+enum { M_KEEP = 8 };
+struct MKeep { real v[M_KEEP]; };
+// (both inlined by force: through a call the eight values would be an object on the stack)
+__device__ __forceinline__ void mkeep_take(const DevModel& m, const Lay& l, const real* S, int L, MKeep& Mk) {
+#pragma unroll
+  for (int k = 0; k < M_KEEP; k++) Mk.v[k] = (64 * k < m.nM) ? S[l.LD + (64 * k + L < m.nM ? 64 * k + L : 0)] : 0.0;
+  wv::sync();          // (the factorisation that follows works in place)
+}
+__device__ __forceinline__ void mkeep_put(const DevModel& m, const Lay& l, real* S, int L, const MKeep& Mk) {
+#pragma unroll
+  for (int k = 0; k < M_KEEP; k++)
+    if (64 * k < m.nM && 64 * k + L < m.nM) S[l.LD + 64 * k + L] = Mk.v[k];
+}
+__device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
   const Tab T = make_tab(m, l, S);
   // composite inertia of every body that carries dofs: sum of cinert over its subtree (an id range)
   if (L > 0 && L < m.nbody && K.b_dofnum > 0) {
@@ -589,7 +601,6 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
       for (int k = 0; k < 6; k++) cj[k] = S[l.cdof + 6 * j + k];
       real v = dot6(cj, buf);
       if (t == 0) v = K.d_armature + v;
-      Mg[K.d_Madr + t] = v;
       S[l.LD + K.d_Madr + t] = v;
     }
   }
@@ -2503,22 +2514,17 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
 }
 
 // ------------------------------------------------------------------ integrator
-// What the integrator and the observation gather read from HBM / the model, fetched before the sensor stage: the
-// lane's row of the inertia matrix (written by the CRB stage a whole step of work ago), the first schedule words of the
-// second factorisation, the lane's joint record, and the first two gather codes of the lane.
+// What the integrator and the observation gather read from HBM / the model, fetched before the sensor stage: the first
+// schedule words of the second factorisation, the lane's joint record, and the first two gather codes of the lane.
 struct EulerK {
-  real mg[MAX_DOF_DEPTH];
   FactorRing ring;
   int qa, da, jtype;
   int gcode[2];
 };
-__device__ __forceinline__ void load_euler_constants(const DevModel& m, const StepArgs& a, const LaneK& K, int L, const real* Mg,
-                                                     bool integrate, EulerK& E) {
-#pragma unroll
-  for (int t = 0; t < MAX_DOF_DEPTH; t++)     // (entries past the lane's row repeat its diagonal and are not used)
-    E.mg[t] = integrate ? Mg[K.d_Madr + (t <= K.d_depth ? t : 0)] : 0.0;
-  if (integrate) factor_prefetch(m, L, E.ring);
-  else { for (int u = 0; u < FACTOR_AHEAD; u++) { E.ring.q[u] = 0u; E.ring.q1[u] = 0u; } E.ring.adr0 = E.ring.num = E.ring.adr1 = E.ring.num1 = 0; }
+__device__ __forceinline__ void load_euler_constants(const DevModel& m, const StepArgs& a, int L, EulerK& E) {
+  // (fetched whether or not this launch integrates: filled in one branch and zeroed in the other, the ring became an
+  // object on the stack addressed through a per-branch offset)
+  factor_prefetch(m, L, E.ring);
   const int j = L < m.njnt ? L : 0;
   E.qa = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
   E.da = m.njnt > 0 ? m.jnt_dofadr[j] : 0;
@@ -2528,16 +2534,16 @@ __device__ __forceinline__ void load_euler_constants(const DevModel& m, const St
   for (int u = 0; u < 2; u++) E.gcode[u] = (a.obs && 64 * u < nobs) ? a.gather[64 * u + L < nobs ? 64 * u + L : 0] : -1;
 }
 
+// (the caller has put the unfactorised inertia matrix back at S[l.LD..]: mkeep_put)
 __device__ inline void stage_euler(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, const EulerK& E, real* S,
                                    int L) {
   real h = m.timestep;
   bool damped = wv::ballot(L < m.nv && K.d_damping > 0) != 0ull;
   if (damped) {
     // (M + h*diag(damping)) qacc = qfrc_smooth + qfrc_constraint
+    wv::sync();
     if (L < m.nv) {
-#pragma unroll
-      for (int t = 0; t < MAX_DOF_DEPTH; t++)
-        if (t <= K.d_depth) S[l.LD + K.d_Madr + t] = E.mg[t] + (t == 0 ? h * K.d_damping : 0.0);
+      S[l.LD + K.d_Madr] += h * K.d_damping;
       S[l.x + L] = S[l.smooth + L] + S[l.qfc + L];
     }
     wv::sync();
@@ -2827,7 +2833,9 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     load_geom_constants(m, MJ_L, GK);
     FactorRing ring;
     factor_prefetch(m, MJ_L, ring);
-    stage_crb(m, l, K, S, MJ_L, a.inertia + (size_t)env * m.nM);
+    MKeep Mk;
+    stage_crb(m, l, K, S, MJ_L);
+    mkeep_take(m, l, S, MJ_L, Mk);
     MJ_STAMP(ST_CRB)
     factor_ld(m, S, l.LD, l.Dinv, MJ_L, ring);
     MJ_STAMP(ST_FACTOR)
@@ -2852,13 +2860,15 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     RK.dof = wv::opaque_lane(RK.dof);
     stage_pgs<DIAG>(m, l, K, RK, S, MJ_L, stamps);
     MJ_STAMP(ST_PGS)
-    const bool integrate = !a.forward_only && m.integrator == 0;
-    load_euler_constants(m, a, K, MJ_L, a.inertia + (size_t)env * m.nM, integrate, EK);
+    load_euler_constants(m, a, MJ_L, EK);
     // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)
     if (m.integrator == 0 || a.rk_stage == 0) stage_sensors(m, l, K, S, MJ_L);
     MJ_STAMP(ST_SENSORS)
     if constexpr (DIAG)
-      if (a.dbg && a.dbg_stage == 0) MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
+      if (a.dbg && a.dbg_stage == 0) {
+        MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
+        wv::sync();          // (the integrator's first act is to put the inertia matrix back over its factor)
+      }
     if (a.frames) {
       real* F = a.frames + (size_t)env * frame_doubles(m);
       const int* I = (const int*)(S + l.ints);
@@ -2879,7 +2889,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     }
     if (!a.forward_only) {
       RK.dof = wv::opaque_lane(RK.dof);
-      if (m.integrator == 0) stage_euler(m, l, K, RK, EK, S, MJ_L);
+      if (m.integrator == 0) { mkeep_put(m, l, S, MJ_L, Mk); stage_euler(m, l, K, RK, EK, S, MJ_L); }
       else stage_rk4(m, l, S, MJ_L, a.rk_stage, a.rk + (size_t)env * (m.nq + 3 * m.nv));
     }
     if (ops_staged) {
@@ -2894,7 +2904,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
     MJ_STAMP(ST_EULER)
   }
   // (a launch cut at `store` ends here: cut launches write no state back, so the launches cut at successive stages
-  // of tools/stage_mix.py all run on the same states; the inertia scratch row is rewritten by every step anyway)
+  // of tools/stage_mix.py all run on the same states)
   MJ_CUT(ST_STORE)
   // state out
   // The end of the step reads its arguments and the copy's id afresh (wv::fresh: the same values, their origin hidden

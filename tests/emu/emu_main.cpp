@@ -192,10 +192,8 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   mj::Lay l;
   mj::make_layout(m, l);
   std::vector<double> lds(l.total, 0.0);
-  std::vector<double> inertia(m.nM > 0 ? m.nM : 1, 0.0);      // the per-copy HBM scratch of the real launch
-  std::vector<double> rk(m.nq + 3 * m.nv + 1, 0.0);           // and the Runge-Kutta scratch
+  std::vector<double> rk(m.nq + 3 * m.nv + 1, 0.0);           // the per-copy Runge-Kutta scratch of the real launch
   mj::StepArgs a{};
-  a.inertia = inertia.data();
   a.rk = rk.data();
   a.qpos = qpos; a.qvel = qvel; a.ctrl = ctrl; a.warm = warm; a.sensordata = sens; a.timestep = timestep;
   a.actions = actions; a.scatter = scatter; a.n_agent = n_agent; a.act_dim = act_dim; a.scatter_mode = scatter_mode;
