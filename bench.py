@@ -490,7 +490,7 @@ def main():
                 break
         kernels = batch.kernel
         if cameras:
-            kernels += " + mjrl_camera_frames_kernel + mjrl_render_kernel"
+            kernels += " + mjrl_render_kernel"       # (the scene rows come from the step kernel: mjrl_set_scene_cache)
         if work.get("encoder"):
             kernels += " + mjrl_encoder_conv_kernel + mjrl_encoder_dense_kernel"
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

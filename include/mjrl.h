@@ -166,10 +166,18 @@ int mjrl_set_query_cache(mjrl_env* env, int enabled);
  *   "ncon" [n_env] (as double)  "contact_geom" [n_env][nconmax][2] (as double, -1 padded). */
 int mjrl_query(mjrl_env* env, const char* name, double* h_out, size_t nbytes);
 
-/* Agent cameras (get_camera_data, mujoco_parent.py:540-555): every fixed camera of the level, ray cast at the
- * current state; rgb [n_env][ncam][height][width][3] uint8, rows bottom-up as glReadPixels returns them
- * (mujoco_parent.py:571, 538).  The image model (headlight Lambert shading of the geom colours, black background) is
- * this library's own: the reference's OpenGL output cannot be reproduced here. */
+/* Agent cameras (get_camera_data, mujoco_parent.py:540-555): every fixed camera of the level, ray cast;
+ * rgb [n_env][ncam][height][width][3] uint8, rows bottom-up as glReadPixels returns them (mujoco_parent.py:571, 538).
+ * The image model is OpenGL's fixed-function lighting equation with the parameters MuJoCo documents (headlight, the
+ * level's <light>s, materials); shadows, textures, the skybox and anti-aliasing are not drawn.
+ *
+ * WHICH frames are drawn: the reference calls mjv_updateScene(model, data, ...) (mujoco_parent.py:533), which reads the
+ * geom / camera / light frames out of MjData as the last forward pass left them -- after mj_step those are one
+ * integration older than qpos.  mjrl_set_scene_cache(env, 1) gives exactly that: every step (its last physics frame),
+ * forward pass and reset then leaves each copy's frames in a scene row, and the render entries draw the rows.  Turn it on
+ * before stepping (mjrl_set_camera_obs does).  With the cache off, or after a state was written by hand
+ * (mjrl_set_field), the frames are computed from the CURRENT qpos instead (one extra kernel per call). */
+int mjrl_set_scene_cache(mjrl_env* env, int enabled);
 int mjrl_render_device(mjrl_env* env, int width, int height, uint8_t* d_rgb);
 int mjrl_render_host(mjrl_env* env, int width, int height, uint8_t* h_rgb);
 

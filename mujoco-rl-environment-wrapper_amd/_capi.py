@@ -18,7 +18,7 @@ SYMBOLS = [
     "mjrl_version", "mjrl_last_error", "mjrl_create", "mjrl_destroy", "mjrl_set_stream", "mjrl_sync",
     "mjrl_set_gather_tables", "mjrl_set_scatter_tables", "mjrl_set_max_steps", "mjrl_size", "mjrl_reset",
     "mjrl_step_device", "mjrl_step_host", "mjrl_get_field", "mjrl_set_field", "mjrl_query", "mjrl_step_debug",
-    "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache",
+    "mjrl_lds_offset", "mjrl_step_profile", "mjrl_set_program", "mjrl_set_query_cache", "mjrl_set_scene_cache",
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
     "mjrl_step_truncated", "mjrl_host_buffers", "mjrl_step_pinned", "mjrl_set_autoreset",
     "mjrl_reset_device", "mjrl_set_step_reset_mask", "mjrl_set_tag_tables", "mjrl_set_env_base", "mjrl_set_variants",
@@ -73,6 +73,7 @@ def load():
     L.mjrl_step_profile.argtypes = [vp, vp, ci, ci, vp, ci]
     L.mjrl_set_program.argtypes = [vp, ci, ip, vp, ci, ci, ip]
     L.mjrl_set_query_cache.argtypes = [vp, ci]
+    L.mjrl_set_scene_cache.argtypes = [vp, ci]
     L.mjrl_render_device.argtypes = [vp, ci, ci, vp]
     L.mjrl_render_host.argtypes = [vp, ci, ci, vp]
     L.mjrl_load_kernel.argtypes = [vp, ctypes.c_char_p]
@@ -168,6 +169,11 @@ class Handle:
 
     def set_query_cache(self, enabled: bool):
         self._check(self._lib.mjrl_set_query_cache(self._h, int(bool(enabled))))
+
+    def set_scene_cache(self, enabled: bool):
+        """Render what the last forward pass left (after a step: frames one integration older than qpos, what
+        mjv_updateScene reads out of MjData) instead of fresh kinematics of the current qpos."""
+        self._check(self._lib.mjrl_set_scene_cache(self._h, int(bool(enabled))))
 
     def set_max_steps(self, n: int):
         self._check(self._lib.mjrl_set_max_steps(self._h, int(n)))

@@ -40,9 +40,12 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
                                   int* timestep, const unsigned char* mask, int n_env, double* store, int store_per_env,
                                   const double* warm0, const double* sens0, const int32_t* gather, int n_agent, int obs_dim,
                                   double* obs, int* variant, int* episode, int n_variant, unsigned long long variant_seed,
-                                  int env_base, unsigned char* auto_mask) {
+                                  int env_base, unsigned char* auto_mask, double* scene, const double* scene0) {
   int env = blockIdx.x;
   if (env >= n_env || (mask && !mask[env])) return;
+  // (the ray caster's scene row: the frames mj_forward leaves at the reset state)
+  if (scene && scene0)
+    for (int i = threadIdx.x; i < mj::scene_doubles(m); i += blockDim.x) scene[(size_t)env * mj::scene_doubles(m) + i] = scene0[i];
   if (auto_mask && threadIdx.x == 0) auto_mask[env] = 0;      // (a reset by hand settles a pending autoreset)
   // A new episode.  The episode count of a copy always moves (it is part of the key of every on-device random choice,
   // so that episodes differ from one another the way the reference's random.randint draws do); with level variants on,
@@ -83,7 +86,7 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
 // mjrl_render_kernel, grid (n_env, ncam * tiles): a wave renders a group of 8x8 pixel blocks of one camera of one copy
 // from that row.  (Round 1 let every render wave redo the copy's kinematics behind the 20 KB step image: 16 tiles x 2
 // cameras repeated it 32 times per copy and the image held a CU to 7 waves.)
-inline __host__ __device__ int scene_doubles(const DevModel& m) { return 12 * m.ngeom + 12 * m.ncam + 6 * m.nlight; }
+using mj::scene_doubles;
 // x^y for x in [0, 1], y >= 0 as exp2(y log2 x) on the transcendental unit (v_log_f32, v_exp_f32): three instructions
 // where the library's powf -- also behind __powf -- is 170; a tenth of a colour level at worst after the 255 scaling
 __device__ __forceinline__ float fast_pow(float x, float y) {
@@ -109,32 +112,11 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
   tab_issue(m, L, TR);
   KinK KK;
   load_kin_constants(m, L, K, KK);
-  GeomK GK;
-  load_geom_constants(m, L, GK);
   for (int i = L; i < m.nq; i += 64) S[l.qpos + i] = qpos[(size_t)env * m.nq + i];
   stage_constants(m, l, S, L, TR);
   wv::sync();
   stage_kinematics(m, l, K, KK, S, L);
-  stage_geoms(m, l, GK, S, L);
-  double* out = scene + (size_t)env * scene_doubles(m);
-  for (int g = L; g < m.ngeom; g += 64) {
-    st3(out + 3 * g, ld3(S + l.gpos + 3 * g));
-    M3 gm = qmat(ldq(S + l.gquat + 4 * g));
-    for (int k = 0; k < 9; k++) out[3 * m.ngeom + 9 * g + k] = gm.m[k];
-  }
-  for (int cam = L; cam < m.ncam; cam += 64) {
-    const int body = m.cam_bodyid[cam];
-    const Quat bq = ldq(S + l.xquat + 4 * body);
-    st3(out + 12 * m.ngeom + 3 * cam, ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.cam_pos + 3 * cam)));
-    M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
-    for (int k = 0; k < 9; k++) out[12 * m.ngeom + 3 * m.ncam + 9 * cam + k] = cm.m[k];
-  }
-  for (int li = L; li < m.nlight; li += 64) {        // the level's lights ride on their bodies
-    const int body = m.light_bodyid[li];
-    const Quat bq = ldq(S + l.xquat + 4 * body);
-    st3(out + 12 * m.ngeom + 12 * m.ncam + 3 * li, ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.light_pos + 3 * li)));
-    st3(out + 12 * m.ngeom + 12 * m.ncam + 3 * m.nlight + 3 * li, rot(bq, ld3(m.light_dir + 3 * li)));
-  }
+  write_scene_row(m, l, S, L, scene + (size_t)env * scene_doubles(m));
 }
 
 // (Single precision: the kernel is bound by vector-instruction issue -- 93 M VALU instructions per 512 x 2 cameras,
@@ -353,7 +335,11 @@ struct mjrl_env {
   hipStream_t stream = nullptr, own_stream = nullptr;
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
   unsigned long long* overflow = nullptr;   // [2] sticky cap-overflow counters (mjrl_cap_overflows)
-  double* scene = nullptr;         // [n_env][12 ngeom + 12 ncam] geom and camera frames of the camera kernels
+  double* scene = nullptr;         // [n_env][scene_doubles] geom, camera and light frames for the ray caster
+  double* reset_scene = nullptr;   // [scene_doubles] the same at the reset state
+  // mjrl_set_scene_cache: the step kernel leaves every copy's scene row as its forward pass computed it; scene_valid says
+  // that every row belongs to the copies' last forward pass (no state has been written by hand since)
+  bool scene_on = false, scene_valid = false;
   double* rk = nullptr;            // [n_env][nq + 3 nv] Runge-Kutta scratch (models with <option integrator="RK4">)
   int* stats = nullptr;            // [n_env][4] ncon, nefc, solver sweeps, warning bits of each copy's last physics frame
   int* timestep = nullptr;
@@ -456,7 +442,7 @@ void mjrl_destroy(mjrl_env* e) {
   void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_part, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
-                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->overflow, e->auto_mask};
+                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->overflow, e->auto_mask, e->reset_scene};
   for (void* p : ptrs) if (p) hipFree(p);
   void* pinned[] = {e->p_act, e->p_obs, e->p_rew, e->p_term, e->p_trunc};
   for (void* p : pinned) if (p) hipHostFree(p);
@@ -470,7 +456,7 @@ static int launch_reset(mjrl_env* e, const unsigned char* d_mask, double* d_obs 
   hipLaunchKernelGGL(mjrl_reset_kernel, dim3(e->n_env), dim3(64), 0, e->stream, e->dm, e->qpos, e->qvel, e->ctrl, e->warm,
                      e->sens, e->timestep, d_mask, e->n_env, e->store, e->n_agent * e->n_slot, e->reset_warm, e->reset_sens,
                      e->d_gather, e->n_agent, e->obs_dim, d_obs, e->variant, e->episode, e->n_variant, e->variant_seed,
-                     e->env_base, e->auto_mask);
+                     e->env_base, e->auto_mask, e->scene_on ? e->scene : nullptr, e->reset_scene);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }
@@ -553,6 +539,14 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
   e->reset_warm = w0; e->reset_sens = s0;
   if (he == hipSuccess) he = hipMemset(e->episode, 0, sizeof(int) * n_env);     // (the reset above was not an episode's)
+  if (he == hipSuccess && m.ncam > 0) {         // the ray caster's scene row at the reset state
+    he = hipMalloc(&e->reset_scene, sizeof(double) * mj::scene_doubles(m));
+    if (he == hipSuccess) {
+      hipLaunchKernelGGL(mjrl_camera_frames_kernel, dim3(1), dim3(64), lds_bytes, e->stream, e->dm, e->dm.qpos0, 1, e->reset_scene);
+      he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+  }
   if (he != hipSuccess) return fail(6, std::string("reset image: ") + hipGetErrorString(he));
   *out = e;
   return 0;
@@ -908,6 +902,20 @@ int mjrl_encode_host(mjrl_env* e, const uint8_t* h_rgb, int n_img, float* h_late
   return rc;
 }
 
+static int ensure_scene(mjrl_env* e) {
+  if (!e->scene) MJRL_HIP(e, hipMalloc(&e->scene, sizeof(double) * (size_t)e->n_env * scene_doubles(e->hm)));
+  return 0;
+}
+
+int mjrl_set_scene_cache(mjrl_env* e, int enabled) {
+  MJRL_ENTER(e);
+  if (enabled && e->hm.ncam == 0) MJRL_FAIL(e, 3, "set_scene_cache: the level has no cameras");
+  if (enabled) if (int rc = ensure_scene(e)) return rc;
+  if ((enabled != 0) != e->scene_on) e->scene_valid = false;
+  e->scene_on = enabled != 0;
+  return 0;
+}
+
 int mjrl_set_camera_obs(mjrl_env* e, int n_agent, const int32_t* agent_cam) {
   MJRL_ENTER(e);
   if (n_agent == 0 || !agent_cam) {            // off
@@ -924,6 +932,7 @@ int mjrl_set_camera_obs(mjrl_env* e, int n_agent, const int32_t* agent_cam) {
   if (!e->enc_rgb) MJRL_HIP(e, hipMalloc(&e->enc_rgb, (size_t)e->n_env * e->hm.ncam * enc::IMG * enc::IMG * 3));
   e->h_agent_cam.assign(agent_cam, agent_cam + n_agent);
   e->n_cam_obs = e->enc_latent;
+  if (!e->scene_on) if (int rc = mjrl_set_scene_cache(e, 1)) return rc;      // (the step hands its frames to the ray caster)
   return upload_gather(e);
 }
 
@@ -1012,12 +1021,14 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.reset_mask = forward_only ? nullptr : e->step_reset_mask;
   a.reset_warm = e->reset_warm;
   a.reset_sens = e->reset_sens;
+  a.reset_scene = e->reset_scene;
   a.auto_mask = forward_only ? nullptr : e->auto_mask;
   a.auto_mode = e->auto_mode;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
   a.agent_body = e->d_agent_body; a.agent_obs_len = e->d_obs_len; a.store = e->store;
   if (e->n_op && !forward_only && !a.actions && d_actions) a.actions = d_actions;   // ops read their action slots
   if (e->frames && skip_frames > 0) e->frames_valid = true;
+  if (e->scene_on && skip_frames > 0) e->scene_valid = true;
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
   if (const char* pad = getenv("MJRL_LDS_BYTES")) lds_bytes = std::max(lds_bytes, (size_t)atoi(pad));   // experiments: residency
   // The kernel advances one physics frame; a step of skipFrames frames (mujoco_parent.py:333-336) is that many launches
@@ -1036,6 +1047,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     a.first_frame = f == 0;
     a.dbg = last ? d_dbg : nullptr;
     a.frames = last ? e->frames : nullptr;
+    a.scene = (last && e->scene_on) ? e->scene : nullptr;
     a.lpt_count_in = nullptr; a.lpt_mask_in = nullptr; a.lpt_count_out = nullptr; a.lpt_mask_out = nullptr;
     a.lpt_count_clear = nullptr; a.lpt_mask_clear = nullptr;
     a.lpt_words = e->lpt_words;
@@ -1266,6 +1278,7 @@ int mjrl_reset(mjrl_env* e, const uint8_t* h_mask, double* d_obs) {
     d_mask = e->d_mask;
   }
   e->frames_valid = false;
+  if (!d_mask && e->scene_on) e->scene_valid = true;        // (every row is the reset image's)
   // mj_resetData + mj_forward (mujoco_parent.py:349-350) from the reset image; unselected copies are not touched
   return launch_reset(e, d_mask, d_obs);
 }
@@ -1273,6 +1286,7 @@ int mjrl_reset(mjrl_env* e, const uint8_t* h_mask, double* d_obs) {
 int mjrl_reset_device(mjrl_env* e, const uint8_t* d_mask, double* d_obs) {
   MJRL_ENTER(e);
   e->frames_valid = false;
+  if (!d_mask && e->scene_on) e->scene_valid = true;
   return launch_reset(e, d_mask, d_obs);
 }
 
@@ -1314,10 +1328,15 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
   MJRL_ENTER(e);
   if (width <= 0 || height <= 0 || !d_rgb) MJRL_FAIL(e, 3, "render: bad arguments");
   if (e->hm.ncam == 0) MJRL_FAIL(e, 3, "render: the level has no cameras");
-  if (!e->scene) MJRL_HIP(e, hipMalloc(&e->scene, sizeof(double) * (size_t)e->n_env * scene_doubles(e->hm)));
-  hipLaunchKernelGGL(mjrl_camera_frames_kernel, dim3(e->n_env), dim3(64), (size_t)e->lay.total * sizeof(double), e->stream, e->dm,
-                     e->qpos, e->n_env, e->scene);
-  MJRL_HIP(e, hipGetLastError());
+  if (int rc = ensure_scene(e)) return rc;
+  // With the scene cache on, the rows are the ones the copies' last forward pass left (a step's: one integration older
+  // than qpos, what mjv_updateScene finds in MjData, mujoco_parent.py:533).  Without it, or after a state was written by
+  // hand, the frames are computed from the current qpos.
+  if (!(e->scene_on && e->scene_valid)) {
+    hipLaunchKernelGGL(mjrl_camera_frames_kernel, dim3(e->n_env), dim3(64), (size_t)e->lay.total * sizeof(double), e->stream, e->dm,
+                       e->qpos, e->n_env, e->scene);
+    MJRL_HIP(e, hipGetLastError());
+  }
   // groups of 8x8 pixel blocks per camera: enough workgroups to fill the chip's wave slots a few times over
   const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
   const int target = 8 * 2048;
@@ -1359,6 +1378,7 @@ int mjrl_set_field(mjrl_env* e, const char* name, const void* h_in, size_t nbyte
   field_ref f;
   if (int rc = find_field(e, name, &f)) return rc;
   e->frames_valid = false;      // the state the cached frames belong to is being replaced
+  e->scene_valid = false;
   if (nbytes != f.bytes) MJRL_FAIL(e, 4, "set_field(%s): buffer holds %zu bytes, field has %zu", name, nbytes, f.bytes);
   MJRL_HIP(e, hipStreamSynchronize(e->stream));
   if (f.bytes) MJRL_HIP(e, hipMemcpy(f.ptr, h_in, f.bytes, hipMemcpyHostToDevice));
@@ -1456,9 +1476,13 @@ int mjrl_query(mjrl_env* e, const char* name, double* h_out, size_t nbytes) {
   if (kind == WARN) {
     // cap-overflow flags live in the LDS image only: one debug forward pass
     if (int rc = ensure_dbg(e)) return rc;
-    bool keep = e->frames_valid;
-    if (int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, e->dbg, 0, 2, nullptr, nullptr)) return rc;
-    e->frames_valid = keep;
+    // (this pass runs at the current state, not at the one the cached frames and scene rows belong to: it leaves both alone)
+    double* frames = e->frames;
+    const bool keep = e->frames_valid, scene_on = e->scene_on, scene_valid = e->scene_valid;
+    e->frames = nullptr; e->scene_on = false;
+    int rc = launch_step(e, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, e->dbg, 0, 2, nullptr, nullptr);
+    e->frames = frames; e->frames_valid = keep; e->scene_on = scene_on; e->scene_valid = scene_valid;
+    if (rc) return rc;
     MJRL_HIP(e, hipStreamSynchronize(e->stream));
     std::vector<double> lds((size_t)e->n_env * e->lay.total);
     MJRL_HIP(e, hipMemcpy(lds.data(), e->dbg, sizeof(double) * lds.size(), hipMemcpyDeviceToHost));

@@ -190,6 +190,12 @@ struct StepArgs {
   // mujoco_parent.py:404-416, 472-475): [n_env][frame_doubles] = xpos | xquat | gpos | gquat | ncon | contact geoms.
   // The reference reads those after mj_step, i.e. as the forward pass inside the step left them (pre-integration).
   real* frames;
+  // Optional scene rows for the ray caster (mjrl_set_scene_cache): [n_env][scene_doubles] = geom pos 3G | geom matrix 9G |
+  // camera pos 3C | camera matrix 9C | light pos 3N | light dir 3N, as the forward pass of this launch left them --
+  // what mjv_updateScene reads out of MjData after mj_step (mujoco_parent.py:533): frames one integration older than
+  // qpos.  reset_scene [scene_doubles] is the row of the reset image, for copies that are reset without a physics frame.
+  real* scene;
+  const real* reset_scene;
   // Longest-first dispatch: a copy's solver work (rows x sweeps) in the previous step predicts this step's, and
   // workgroups are dispatched in index order, so handing the heavy copies to the lowest workgroup ids keeps a straggler
   // from starting last.  Each wave files its copy under a work bucket for the next launch -- one count and one bit set
@@ -767,6 +773,31 @@ __device__ __forceinline__ void geom_frame(const DevModel& m, const Lay& l, cons
   Quat bq = ldq(S + l.xquat + 4 * b);
   pos = ld3(S + l.xpos + 3 * b) + rot(bq, ld3(m.geom_pos + 3 * g));
   quat = qmul(bq, ldq(m.geom_quat + 4 * g));
+}
+
+// The ray caster's scene row of one copy (StepArgs::scene) from the body frames in LDS.
+__host__ __device__ inline int scene_doubles(const DevModel& m) { return 12 * m.ngeom + 12 * m.ncam + 6 * m.nlight; }
+__device__ inline void write_scene_row(const DevModel& m, const Lay& l, const real* S, int L, real* out) {
+  for (int g = L; g < m.ngeom; g += 64) {
+    V3 gp; Quat gq;
+    geom_frame(m, l, S, g, gp, gq);
+    st3(out + 3 * g, gp);
+    M3 gm = qmat(gq);
+    for (int k = 0; k < 9; k++) out[3 * m.ngeom + 9 * g + k] = gm.m[k];
+  }
+  for (int cam = L; cam < m.ncam; cam += 64) {
+    const int body = m.cam_bodyid[cam];
+    const Quat bq = ldq(S + l.xquat + 4 * body);
+    st3(out + 12 * m.ngeom + 3 * cam, ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.cam_pos + 3 * cam)));
+    M3 cm = qmat(qmul(bq, ldq(m.cam_quat + 4 * cam)));
+    for (int k = 0; k < 9; k++) out[12 * m.ngeom + 3 * m.ncam + 9 * cam + k] = cm.m[k];
+  }
+  for (int li = L; li < m.nlight; li += 64) {        // the level's lights ride on their bodies
+    const int body = m.light_bodyid[li];
+    const Quat bq = ldq(S + l.xquat + 4 * body);
+    st3(out + 12 * m.ngeom + 12 * m.ncam + 3 * li, ld3(S + l.xpos + 3 * body) + rot(bq, ld3(m.light_pos + 3 * li)));
+    st3(out + 12 * m.ngeom + 12 * m.ncam + 3 * m.nlight + 3 * li, rot(bq, ld3(m.light_dir + 3 * li)));
+  }
 }
 
 // The lane's geom record and the candidate pairs of the first broad-phase chunks, fetched two stages ahead (before the
@@ -1993,7 +2024,12 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   const bool in_registers = (m.rowmap && !cross && tmax <= 16) || wide || tall;
   // what a sweep of this copy costs relative to one of the 16-row register solver (for the longest-first dispatch: rows x
   // sweeps of a copy on the wide, schedule or serial path stand for three to four times the wave time)
-  if (L == 0) I[I_COST] = (in_registers && !wide && !tall) ? 1 : (tall ? 2 : 4);
+  // (a tree of 13+ rows is three contacts from the wide path: such a copy counts double, so that it is not the one the
+  // launch waits for if it crosses over in the step the key predicts)
+#ifndef MJRL_NEAR_WIDE
+#define MJRL_NEAR_WIDE 13
+#endif
+  if (L == 0) I[I_COST] = (in_registers && !wide && !tall) ? (tmax >= MJRL_NEAR_WIDE ? 2 : 1) : (tall ? 2 : 4);
   if (!in_registers) {
     // warm start: keep the forces implied by last step's acceleration only if they beat f = 0
     if (dof)
@@ -2887,6 +2923,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
         F[7 * m.nbody + 7 * m.ngeom + 2 + 2 * c] = c < ncon ? I[l.i_cong2 + c] : -1;
       }
     }
+    if (a.scene) write_scene_row(m, l, S, MJ_L, a.scene + (size_t)env * scene_doubles(m));
     if (!a.forward_only) {
       RK.dof = wv::opaque_lane(RK.dof);
       if (m.integrator == 0) { mkeep_put(m, l, S, MJ_L, Mk); stage_euler(m, l, K, RK, EK, S, MJ_L); }
@@ -2986,6 +3023,7 @@ __device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real*
       if (a.trunc) a.trunc[(size_t)env * a.n_agent + L] = 0;
     }
     if (a.store) MJ_FOR(k, a.n_agent * a.n_slot) a.store[(size_t)env * a.n_agent * a.n_slot + k] = __builtin_nan("");
+    if (a.scene && a.reset_scene) MJ_FOR(k, scene_doubles(m)) a.scene[(size_t)env * scene_doubles(m) + k] = a.reset_scene[k];
     if (L == 0) {
       a.timestep[env] = 0;
       if (a.auto_mask) a.auto_mask[env] = 0;

@@ -190,6 +190,11 @@ class MuJoCoParent:
             self._handle.set_env_base(self.first_env_id)
         if self._variants is not None:
             self._handle.set_variants(self._variants["rgba"], self._variant_seed)
+        # images show MjData's frames as the last forward pass left them (mjv_updateScene, mujoco_parent.py:533): the
+        # step kernel keeps them for the ray caster from the first step on
+        self._scene_cache = bool(self.agent_cameras) and len(self._compiled.names["camera"]) > 0
+        if self._scene_cache:
+            self._handle.set_scene_cache(True)
         self.model = ModelView(self._compiled)
         self.data = DataView(self)
         self._episode = None
@@ -483,6 +488,11 @@ class MuJoCoParent:
         width, height = self.sensor_resolution
         names = self._compiled.names["camera"]
         images = self._handle.render(width, height)            # [n_env, ncam, H, W, 3], rows bottom-up
+        if not self._scene_cache and names:
+            # (a camera asked for by name on a handle made without agentCameras: this image was drawn from the current
+            # qpos; from the next step on the step keeps its frames and the images follow the reference's rule)
+            self._handle.set_scene_cache(True)
+            self._scene_cache = True
         images = images.reshape(self.n_env, len(names), width, height, 3)   # the reference's (W, H, 3) view of it
         if cam_object in self.rgb_sensors:
             picked = images[:, [names.index(c) for c in self.rgb_sensors[cam_object]]]

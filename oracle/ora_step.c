@@ -966,8 +966,11 @@ static void ora_shade(const ora_model* m, const ora_data* d, const double* cm, i
   }
 }
 
+/* Which frames: mjv_updateScene(model, data, ...) (mujoco_parent.py:533) reads the geom, camera and light frames out of
+ * MjData as the last forward pass left them -- after mj_step (forward, then integrate) they are one integration older
+ * than qpos, and the reference calls no mj_forward in between (mujoco_parent.py:333-336 -> 540-555).  So this draws the
+ * frames d holds and runs no kinematics of its own; a caller that wrote qpos by hand calls ora_forward first. */
 void ora_render(const ora_model* m, ora_data* d, int cam, int width, int height, unsigned char* out) {
-  ora_kinematics(m, d);
   const double* cp = d->cam_xpos + 3 * cam;
   const double* cm = d->cam_xmat + 9 * cam;
   double t = tan(0.5 * m->cam_fovy[cam] * ORA_PI / 180.0), aspect = (double)width / (double)height;

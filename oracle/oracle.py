@@ -132,7 +132,8 @@ class OracleEnv:
         return lib().ora_time(self._d)
 
     def render(self, cam: int, width: int = 64, height: int = 64):
-        """uint8 image (width, height, 3) of fixed camera ``cam`` at the current qpos (rows bottom-up)."""
+        """uint8 image (width, height, 3) of fixed camera ``cam`` (rows bottom-up), drawn from the frames the last
+        forward pass left in the data (step, forward or reset) -- what mjv_updateScene would read."""
         out = np.zeros((height, width, 3), np.uint8)
         lib().ora_render(self._m, self._d, cam, width, height, out.ctypes.data_as(ctypes.c_void_p))
         return out.reshape(width, height, 3)

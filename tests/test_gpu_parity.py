@@ -285,7 +285,8 @@ def test_agent_cameras_match_the_oracle_ray_caster():
     assert images.shape == (3, 1, 64, 64, 3) and images.dtype == np.uint8
     assert env.get_camera_data("receiver_camera").shape == (3, 64, 64, 3)
     for e, o in enumerate(oras):
-        o.qpos[:] = env._handle.get_field("qpos")[e]          # render the very same state
+        # (both sides draw the frames their last step's forward pass left -- what mjv_updateScene reads out of MjData,
+        # mujoco_parent.py:533 --, not kinematics of the integrated qpos: agentCameras turns the scene cache on)
         for cam, agent in enumerate(AGENTS):
             ref = o.render(cam, 64, 64).astype(int)
             got = env.get_camera_data(agent)[e, 0].astype(int)
@@ -514,6 +515,7 @@ def test_render_block_tiling_at_odd_sizes_and_batch_sizes():
     for _ in range(300):
         ora.ctrl[:] = rng.uniform(-1, 1, model.nu)
         ora.step()
+    ora.forward()             # (a state written by hand is drawn at its own qpos on the device: fresh frames here too)
     for n_env, (w, h) in ((1, (37, 21)), (5, (64, 64)), (40, (20, 12))):
         handle = _capi.Handle(packed, n_env)
         handle.reset()

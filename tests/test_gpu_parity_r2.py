@@ -295,6 +295,9 @@ def test_camera_batch_properties_at_512_copies():
     for t in range(60):
         act = np.tile(base[t], (n_env // 8, 1, 1))
         env.step({a: act[:, k] for k, a in enumerate(AGENTS)})
+    # (this test moves states between copies by hand: images of the CURRENT qpos, i.e. without the scene cache that
+    # agentCameras turned on -- the cached frames of a step are covered by test_render_draws_the_frames_of_the_last_forward_pass)
+    env._handle.set_scene_cache(False)
     img1 = env._handle.render(64, 64)
     assert img1.shape == (n_env, 2, 64, 64, 3) and img1.dtype == np.uint8
     assert np.array_equal(img1[:8], img1[8:16]) and np.array_equal(img1[:8], img1[-8:])
@@ -307,6 +310,7 @@ def test_camera_batch_properties_at_512_copies():
     o = OracleEnv(env._blob)
     for e in (0, 3, 7):
         o.qpos[:] = qpos[e]
+        o.forward()
         for cam in range(2):
             ref = o.render(cam, 64, 64).reshape(64, 64, 3).astype(int)
             differ = np.abs(ref - img1[e, cam].astype(int)).max(axis=-1) > 0

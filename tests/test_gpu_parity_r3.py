@@ -328,6 +328,7 @@ def test_arena_with_73_geoms_on_the_device(tmp_path):
     packed = blob.pack(model)
     for specialize in (True, False):
         h = _capi.Handle(packed, 3, specialize=specialize)
+        h.set_scene_cache(True)         # (images of the step's own frames, like the oracle's and the reference's)
         h.reset()
         oras = [OracleEnv(packed) for _ in range(3)]
         rng = np.random.default_rng(2)
@@ -398,3 +399,72 @@ def test_autoreset_with_several_frames_per_step_and_runge_kutta():
             else:
                 assert not trunc.any()
         vec.close()
+
+
+# --------------------------------------------------------------------------- which frames the cameras draw
+def test_render_draws_the_frames_of_the_last_forward_pass():
+    """mjv_updateScene(model, data, ...) (mujoco_parent.py:533) reads the geom / camera / light frames out of MjData as the
+    last forward pass left them: after mj_step they are one integration older than qpos.  With the scene cache on
+    (agentCameras turns it on) the device images are those of the step's own frames -- the oracle's after the same
+    steps, not the oracle's after a fresh forward pass --, a copy reset inside a launch or by the host shows the reset
+    image, and a state written by hand is drawn at its own qpos."""
+    import torch
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    packed = blob.pack(model)
+    h = _capi.Handle(packed, 4)
+    h.set_scene_cache(True)
+    h.reset()
+    oras = [OracleEnv(packed) for _ in range(4)]
+
+    def same(got, ref, frac=0.004):
+        got, ref = got.astype(int), np.asarray(ref).reshape(got.shape).astype(int)
+        return (np.abs(got - ref).max(axis=-1) > 0).mean() < frac
+
+    reset_images = h.render(64, 64)
+    assert all(same(reset_images[e, cam], oras[e].render(cam, 64, 64)) for e in range(4) for cam in range(2))
+    rng = np.random.default_rng(21)
+    for _ in range(60):
+        ctrl = rng.uniform(-1, 1, (4, model.nu))
+        h.set_field("ctrl", ctrl)
+        h.step_device(None, 0, 1)
+        for e, o in enumerate(oras):
+            o.ctrl[:] = ctrl[e]
+            o.step()
+    images = h.render(64, 64)
+    for e, o in enumerate(oras):
+        assert np.allclose(h.get_field("qpos")[e], o.qpos, rtol=0, atol=1e-9)
+        for cam in range(2):
+            assert same(images[e, cam], o.render(cam, 64, 64)), (e, cam)
+    # ... and NOT the image of the integrated state (the agents are moving: one integration shifts their cameras' views)
+    fresh = OracleEnv(packed)
+    fresh.qpos[:] = oras[0].qpos
+    fresh.forward()
+    moved = [(np.abs(fresh.render(cam, 64, 64).reshape(64, 64, 3).astype(int) - images[0, cam].astype(int)).max(axis=-1) > 0).mean()
+             for cam in range(2)]
+    assert max(moved) > 0.0, moved
+    # copy 1 is reset inside the launch without a physics frame (flag 2), copy 2 reset and stepped (flag 1)
+    mask = torch.tensor([0, 2, 1, 0], dtype=torch.uint8, device="cuda")
+    h.set_step_reset_mask(mask.data_ptr())
+    h.step_device(None, 0, 1)
+    h.set_step_reset_mask(None)
+    oras[1].reset()
+    oras[2].reset(); oras[2].ctrl[:] = 0; oras[2].step()
+    oras[0].step(); oras[3].step()
+    after = h.render(64, 64)
+    assert np.array_equal(after[1], reset_images[1])
+    for e in (0, 2, 3):
+        assert all(same(after[e, cam], oras[e].render(cam, 64, 64)) for cam in range(2)), e
+    # a masked reset by the host
+    h.reset(np.array([0, 0, 0, 1], np.uint8))
+    again = h.render(64, 64)
+    assert np.array_equal(again[3], reset_images[3]) and np.array_equal(again[:3], after[:3])
+    # a state written by hand is drawn at its own qpos
+    q = h.get_field("qpos")
+    h.set_field("qpos", q)
+    by_hand = h.render(64, 64)
+    fresh.qpos[:] = q[0]
+    fresh.forward()
+    assert all(same(by_hand[0, cam], fresh.render(cam, 64, 64)) for cam in range(2))
+    fresh.close(); h.close()
+    for o in oras:
+        o.close()
