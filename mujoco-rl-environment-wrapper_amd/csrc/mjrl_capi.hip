@@ -122,13 +122,17 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
 // (Single precision: the kernel is bound by vector-instruction issue -- 93 M VALU instructions per 512 x 2 cameras,
 // profiles/r02_pmc_render.txt -- and fp32 issues at twice the fp64 rate.  The tests bound the pixels that may differ from
 // the oracle's fp64 ray caster.)
-__global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
-                                                         int tiles, unsigned char* rgb, const int* variant,
-                                                         const double* variant_rgba) {
-  extern __shared__ float ldsf[];
+// The ray caster proper: blocks blk0, blk0 + blk_step, .. (< blk1) of camera `cam` of the copy whose scene row is `row`, drawn by the
+// calling wave into `img` (rows of row_bytes bytes).  The tables are staged in `ldsf` by all `nthr` threads of the
+// workgroup -- one wave in mjrl_render_kernel; MULTI = true is the form for a workgroup of several waves (the fused
+// render + convolution kernel of DESIGN.md section 9, measured and not kept).
+template <bool MULTI>
+__device__ __forceinline__ void render_body(const DevModel& m, const double* row, int cam, int width, int height, int blk0,
+                                            int blk1, int blk_step, float* ldsf, unsigned char* img, int row_bytes,
+                                            const double* rgba_tab, int tid, int nthr) {
   using namespace mj;
-  const int L = wv::lane(), env = blockIdx.x;
-  const int cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
+  const int L = tid & 63;
+  auto barrier = [&]() { if constexpr (MULTI) __syncthreads(); else wv::sync(); };
   // LDS: the copy's geom positions, matrices and sizes
   float* GP = ldsf;
   float* GM = ldsf + 3 * m.ngeom;
@@ -136,9 +140,8 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   float* MP = ldsf + 15 * m.ngeom;            // material properties: specular, 128 x shininess, emission
   float* GC = ldsf + 18 * m.ngeom;            // the copy's geom colours (its level variant's)
   float* LT = ldsf + 21 * m.ngeom;            // light table: entry 0 the headlight, then the level's lights
-  const double* row = scene + (size_t)env * scene_doubles(m);
-  for (int i = L; i < 12 * m.ngeom; i += 64) ldsf[i] = (float)row[i];
-  for (int i = L; i < 3 * m.ngeom; i += 64) {
+  for (int i = tid; i < 12 * m.ngeom; i += nthr) ldsf[i] = (float)row[i];
+  for (int i = tid; i < 3 * m.ngeom; i += nthr) {
     GS[i] = (float)m.geom_size[i];
     MP[i] = (float)m.geom_matprop[i] * (i % 3 == 1 ? 128.0f : 1.0f);
   }
@@ -148,16 +151,15 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   // (the camera matrix lives in LDS, behind the light table: nine wave-uniform floats would otherwise sit in nine vector
   // registers for the whole kernel -- there is no scalar float unit to keep them in -- and cost a wave per SIMD)
   float* cm = LT + LIGHT_FLOATS * (m.nlight + 1);
-  if (L < 9) cm[L] = (float)row[12 * m.ngeom + 3 * m.ncam + 9 * cam + L];
-  wv::sync();
-  for (int g = L; g < m.ngeom; g += 64) {       // camera-relative positions
+  if (tid < 9) cm[tid] = (float)row[12 * m.ngeom + 3 * m.ncam + 9 * cam + tid];
+  barrier();
+  for (int g = tid; g < m.ngeom; g += nthr) {       // camera-relative positions
     GP[3 * g] = (float)(row[3 * g] - cpx); GP[3 * g + 1] = (float)(row[3 * g + 1] - cpy); GP[3 * g + 2] = (float)(row[3 * g + 2] - cpz);
   }
   // the copy's colours: its level variant's (mjrl_set_variants), else the model's
-  const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
   auto rgba_of = [&](int g, int k) { return (float)(rgba_tab ? rgba_tab[4 * g + k] : (double)m.geom_rgba[4 * g + k]); };
-  for (int i = L; i < 3 * m.ngeom; i += 64) GC[i] = rgba_of(i / 3, i % 3);
-  if (L == 0) {
+  for (int i = tid; i < 3 * m.ngeom; i += nthr) GC[i] = rgba_of(i / 3, i % 3);
+  if (tid == 0) {
     // the headlight (visual/headlight) as entry 0: directional, shining along the viewing direction (L = V = the
     // camera's +z axis); an inactive one contributes nothing
     float* T = LT;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
     for (int k = 0; k < 9; k++) T[11 + k] = on * (float)m.headlight[1 + k];
     T[20] = 1.0f;
   }
-  for (int li = L; li < m.nlight; li += 64) {   // the level's lights, camera-relative
+  for (int li = tid; li < m.nlight; li += nthr) {   // the level's lights, camera-relative
     float* T = LT + LIGHT_FLOATS * (li + 1);
     const double* lp = row + 12 * m.ngeom + 12 * m.ncam + 3 * li;
     const double* ld = row + 12 * m.ngeom + 12 * m.ncam + 3 * m.nlight + 3 * li;
@@ -185,16 +187,15 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
     T[10] = (float)m.light_exponent[li];
     T[20] = m.light_directional[li] ? 1.0f : 0.0f;
   }
-  wv::sync();
+  barrier();
   const F3 origin = f3(0, 0, 0);
   const float t = (float)tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (float)width / (float)height;
   const float inv_w = 2.0f / (float)width, inv_h = 2.0f / (float)height;
-  unsigned char* img = rgb + ((size_t)env * m.ncam + cam) * width * height * 3;
   // The wave's 64 rays cover an 8x8 block of pixels at a time.  Lane g first tests geom g's bounding sphere against the
   // block's bounding cone (all geoms at once); the rays then visit only the geoms that passed, each ray with its own
   // bounding-sphere test before the type-specific one.  Both tests are conservative (they may pass a geom the ray misses).
   const int bw = (width + 7) / 8, nblock = bw * ((height + 7) / 8);
-  const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
+  (void)nblock;
   auto pixel_ray = [&](float px, float py) {        // px, py in pixel units, pixel centres at +0.5
     return normalizedf(mulf(cm, f3((px * inv_w - 1.0f) * t * aspect, (py * inv_h - 1.0f) * t, -1.0f)));
   };
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   const int my_type = my_geom ? m.geom_type[L] : -1;
   const float my_rb = my_geom ? (float)m.geom_rbound[L] * (1.0f + 1e-5f) + 1e-5f : 0.0f;     // (rounded up)
   const F3 my_rel = my_geom ? ldf3(GP + 3 * L) : origin;
-  for (int blk = blk0; blk < blk1; blk++) {
+  for (int blk = blk0; blk < blk1; blk += blk_step) {
     const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 8;
     const F3 axis = pixel_ray(c0 + 4.0f, r0 + 4.0f);
     float cosmin = 1.0f;
@@ -211,7 +212,6 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
     const float cos_t = cosmin * (1.0f - 1e-5f) - 1e-6f, sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.0f));
     const int r = r0 + (L >> 3), c = c0 + (L & 7);
     const bool inside = r < height && c < width;
-    const int pix = r * width + c;
     const F3 vec = pixel_ray(c + 0.5f, r + 0.5f);
     float best = -1;
     int hit = -1;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
     // neighbouring lanes' pixels (round 2 stored 3 single bytes per lane: 192 byte stores per block, and four times the
     // pixels' bytes in HBM write traffic, profiles/r02_pmc_render_fp64.txt).  Needs dword-aligned rows, i.e. a width
     // that is a multiple of 4, and a block wholly inside the image; anything else keeps the byte stores.
-    const bool whole = MJRL_RENDER_VARIANT != 2 && (width & 3) == 0 && r0 + 8 <= height && c0 + 8 <= width;
+    const bool whole = MJRL_RENDER_VARIANT != 2 && (row_bytes & 3) == 0 && r0 + 8 <= height && c0 + 8 <= width;
     if (whole) {
       const unsigned packed = (unsigned)out[0] | ((unsigned)out[1] << 8) | ((unsigned)out[2] << 16);
       const int prow = L / 6, j = L - 6 * prow;             // lanes 0..47: dword j of the block's pixel row prow
@@ -308,11 +308,24 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
       const int src = (prow & 7) * 8 + pa;
       const unsigned lo = (unsigned)wv::shfl((int)packed, src), hi = (unsigned)wv::shfl((int)packed, (src + 1) & 63);
       const unsigned long long q = (unsigned long long)lo | ((unsigned long long)hi << 24);
-      if (L < 48) *(unsigned*)(img + (size_t)(r0 + prow) * width * 3 + 3 * c0 + 4 * j) = (unsigned)(q >> (8 * o));
+      if (L < 48) *(unsigned*)(img + (size_t)(r0 + prow) * row_bytes + 3 * c0 + 4 * j) = (unsigned)(q >> (8 * o));
     } else if (inside) {
-      img[3 * pix] = out[0]; img[3 * pix + 1] = out[1]; img[3 * pix + 2] = out[2];
+      unsigned char* at = img + (size_t)r * row_bytes + 3 * c;
+      at[0] = out[0]; at[1] = out[1]; at[2] = out[2];
     }
   }
+}
+
+__global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
+                                                         int tiles, unsigned char* rgb, const int* variant,
+                                                         const double* variant_rgba) {
+  extern __shared__ float ldsf[];
+  const int env = blockIdx.x, cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
+  const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
+  const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
+  const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
+  render_body<false>(m, scene + (size_t)env * scene_doubles(m), cam, width, height, blk0, blk1, 1, ldsf,
+                     rgb + ((size_t)env * m.ncam + cam) * width * height * 3, 3 * width, rgba_tab, wv::lane(), 64);
 }
 
 // the ray kernel's LDS: geom positions, matrices and sizes

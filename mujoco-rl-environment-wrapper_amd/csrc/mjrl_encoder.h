@@ -76,27 +76,13 @@ __device__ __forceinline__ int a1_pixel(int p) { return p ^ ((p >> 1) & 1); }
 // MFMAs -- 700 of them in 35 k cycles with four waves --, and the LDS tile limits a CU to two images at a time, so the
 // only way to more waves in flight is more waves per image: half the tiles and half the rows each.)
 enum { CONV_WAVES = 8, CONV_THREADS = 64 * CONV_WAVES, CONV_ROWS = H2 / CONV_WAVES };
-__global__ __launch_bounds__(CONV_THREADS) void mjrl_encoder_conv_kernel(const unsigned char* __restrict__ rgb, int n_img,
-                                                                const frag_ab* __restrict__ w1p, const float* __restrict__ b1,
-                                                                const frag_ab* __restrict__ w2p, const float* __restrict__ b2,
-                                                                unsigned short* __restrict__ a2) {
-  extern __shared__ unsigned char lds_raw[];
-  unsigned char* img = lds_raw;
-  unsigned short* a1 = (unsigned short*)(lds_raw + IMG_LDS);
-  const int image = blockIdx.x;
-  if (image >= n_img) return;
+// Both convolutions of one image from the padded uint8 image in LDS (all CONV_THREADS threads of the workgroup, after a
+// barrier behind whoever filled the image: the staging loop of mjrl_encoder_conv_kernel).
+__device__ __forceinline__ void conv_layers(const unsigned char* img, unsigned short* a1, int image, const frag_ab* __restrict__ w1p,
+                                            const float* __restrict__ b1, const frag_ab* __restrict__ w2p,
+                                            const float* __restrict__ b2, unsigned short* __restrict__ a2) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 15, grp = lane >> 4;
-  {  // stage the image: 64 rows of 192 bytes into rows of ROWB, 8 bytes per thread and pass; zero the padding
-    const uint2* src = (const uint2*)(rgb + (size_t)image * IMG * IMG * 3);
-    for (int i = tid; i < IMG * IMG * 3 / 8; i += CONV_THREADS) {
-      const int r = i / 24, c = i - 24 * r;
-      *(uint2*)(img + r * ROWB + 8 * c) = src[i];
-    }
-    if (tid < IMG) *(uint2*)(img + tid * ROWB + IMG * 3) = uint2{0u, 0u};
-    if (tid < ROWB / 8) *(uint2*)(img + IMG * ROWB + 8 * tid) = uint2{0u, 0u};
-  }
-  __syncthreads();
 #ifndef MJRL_CONV_VARIANT
 #define MJRL_CONV_VARIANT 0           // (experiments: 1 no conv2 taps, 2 no conv1 tiles, 3 no epilogue stores)
 #endif
@@ -196,6 +182,28 @@ __global__ __launch_bounds__(CONV_THREADS) void mjrl_encoder_conv_kernel(const u
       if (MJRL_CONV_VARIANT != 3 || v.x == 0x12345678u) out[((oy * 2 + p) * 16 + col) * 4 + grp] = v;
     }
   }
+}
+__global__ __launch_bounds__(CONV_THREADS) void mjrl_encoder_conv_kernel(const unsigned char* __restrict__ rgb, int n_img,
+                                                                const frag_ab* __restrict__ w1p, const float* __restrict__ b1,
+                                                                const frag_ab* __restrict__ w2p, const float* __restrict__ b2,
+                                                                unsigned short* __restrict__ a2) {
+  extern __shared__ unsigned char lds_raw[];
+  unsigned char* img = lds_raw;
+  unsigned short* a1 = (unsigned short*)(lds_raw + IMG_LDS);
+  const int image = blockIdx.x;
+  if (image >= n_img) return;
+  const int tid = threadIdx.x;
+  {  // stage the image: 64 rows of 192 bytes into rows of ROWB, 8 bytes per thread and pass; zero the padding
+    const uint2* src = (const uint2*)(rgb + (size_t)image * IMG * IMG * 3);
+    for (int i = tid; i < IMG * IMG * 3 / 8; i += CONV_THREADS) {
+      const int r = i / 24, c = i - 24 * r;
+      *(uint2*)(img + r * ROWB + 8 * c) = src[i];
+    }
+    if (tid < IMG) *(uint2*)(img + tid * ROWB + IMG * 3) = uint2{0u, 0u};
+    if (tid < ROWB / 8) *(uint2*)(img + IMG * ROWB + 8 * tid) = uint2{0u, 0u};
+  }
+  __syncthreads();
+  conv_layers(img, a1, image, w1p, b1, w2p, b2, a2);
 }
 
 // element e of the activation vector as the conv kernel writes it -> its index (h * 16 + w) * 64 + c in Keras' Flatten order
