@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
 template <bool MULTI>
 __device__ __forceinline__ void render_body(const DevModel& m, const double* row, int cam, int width, int height, int blk0,
                                             int blk1, int blk_step, float* ldsf, unsigned char* img, int row_bytes,
-                                            const double* rgba_tab, int tid, int nthr) {
+                                            const double* rgba_tab, const float* consts, int tid, int nthr) {
   using namespace mj;
   const int L = tid & 63;
   auto barrier = [&]() { if constexpr (MULTI) __syncthreads(); else wv::sync(); };
@@ -182,14 +182,15 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
       T[14 + k] = (float)m.light_diffuse[3 * li + k];
       T[17 + k] = (float)m.light_specular[3 * li + k];
     }
-    // (cutoff >= 180: no cone -- a cosine no (-L . dir) can fall below)
-    T[9] = m.light_cutoff[li] < 180.0 ? (float)cos(m.light_cutoff[li] * 3.14159265358979323846 / 180.0) : -2.0f;
+    T[9] = consts[m.ncam + li];
     T[10] = (float)m.light_exponent[li];
     T[20] = m.light_directional[li] ? 1.0f : 0.0f;
   }
   barrier();
   const F3 origin = f3(0, 0, 0);
-  const float t = (float)tan(0.5 * m.cam_fovy[cam] * 3.14159265358979323846 / 180.0), aspect = (float)width / (float)height;
+  // (tan(fovy / 2) per camera and cos(cutoff) per light come from the host, mjrl_create: in double precision on the
+  // device they were 600 of a wave's 5 k instructions)
+  const float t = consts[cam], aspect = (float)width / (float)height;
   const float inv_w = 2.0f / (float)width, inv_h = 2.0f / (float)height;
   // The wave's 64 rays cover an 8x8 block of pixels at a time.  Lane g first tests geom g's bounding sphere against the
   // block's bounding cone (all geoms at once); the rays then visit only the geoms that passed, each ray with its own
@@ -209,7 +210,7 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
     float cosmin = 1.0f;
     for (int k = 0; k < 4; k++)
       cosmin = fminf(cosmin, dotf(axis, pixel_ray(c0 + ((k & 1) ? 7.5f : 0.5f), r0 + ((k & 2) ? 7.5f : 0.5f))));
-    const float cos_t = cosmin * (1.0f - 1e-5f) - 1e-6f, sin_t = sqrtf(fmaxf(1.0f - cos_t * cos_t, 0.0f));
+    const float cos_t = cosmin * (1.0f - 1e-5f) - 1e-6f, sin_t = fsqrt(fmaxf(1.0f - cos_t * cos_t, 0.0f));
     const int r = r0 + (L >> 3), c = c0 + (L & 7);
     const bool inside = r < height && c < width;
     const F3 vec = pixel_ray(c + 0.5f, r + 0.5f);
@@ -220,7 +221,7 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
     auto visit = [&](int base, bool geom_on, int type_v, float rb_v, F3 rel_v) {
       bool cand = geom_on;
       if (geom_on && type_v != GEOM_PLANE) {
-        const float along = dotf(rel_v, axis), perp = sqrtf(fmaxf(dotf(rel_v, rel_v) - along * along, 0.0f));
+        const float along = dotf(rel_v, axis), perp = fsqrt(fmaxf(dotf(rel_v, rel_v) - along * along, 0.0f));
         // (perp cos - along sin is a lower bound of the centre's distance to the cone, negative inside it)
         cand = !(along + rb_v < 0.0f) && perp * cos_t - along * sin_t <= rb_v + 1e-5f * (1.0f + perp);
       }
@@ -278,7 +279,7 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
           if (d2 < 1e-30f) continue;
           const float inv = rsqrtf(d2), dist = d2 * inv;
           Ld = Ld * inv;
-          scale = 1.0f / (T[6] + T[7] * dist + T[8] * d2);
+          scale = frcp(T[6] + T[7] * dist + T[8] * d2);
           const float c = -dotf(Ld, dir);
           if (T[9] > -1.5f) scale = c < T[9] ? 0.0f : scale * fast_pow(fmaxf(c, 0.0f), T[10]);
         }
@@ -318,14 +319,14 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
 
 __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
                                                          int tiles, unsigned char* rgb, const int* variant,
-                                                         const double* variant_rgba) {
+                                                         const double* variant_rgba, const float* consts) {
   extern __shared__ float ldsf[];
   const int env = blockIdx.x, cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
   const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
   const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
   const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
   render_body<false>(m, scene + (size_t)env * scene_doubles(m), cam, width, height, blk0, blk1, 1, ldsf,
-                     rgb + ((size_t)env * m.ncam + cam) * width * height * 3, 3 * width, rgba_tab, wv::lane(), 64);
+                     rgb + ((size_t)env * m.ncam + cam) * width * height * 3, 3 * width, rgba_tab, consts, wv::lane(), 64);
 }
 
 // the ray kernel's LDS: geom positions, matrices and sizes
@@ -350,6 +351,7 @@ struct mjrl_env {
   unsigned long long* overflow = nullptr;   // [2] sticky cap-overflow counters (mjrl_cap_overflows)
   double* scene = nullptr;         // [n_env][scene_doubles] geom, camera and light frames for the ray caster
   double* reset_scene = nullptr;   // [scene_doubles] the same at the reset state
+  float* render_consts = nullptr;  // [ncam + nlight] tan(fovy / 2) per camera, cos(cutoff) per light (-2: no cone)
   // mjrl_set_scene_cache: the step kernel leaves every copy's scene row as its forward pass computed it; scene_valid says
   // that every row belongs to the copies' last forward pass (no state has been written by hand since)
   bool scene_on = false, scene_valid = false;
@@ -455,7 +457,7 @@ void mjrl_destroy(mjrl_env* e) {
   void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_part, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
-                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->overflow, e->auto_mask, e->reset_scene};
+                  e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->overflow, e->auto_mask, e->reset_scene, e->render_consts};
   for (void* p : ptrs) if (p) hipFree(p);
   void* pinned[] = {e->p_act, e->p_obs, e->p_rew, e->p_term, e->p_trunc};
   for (void* p : pinned) if (p) hipHostFree(p);
@@ -552,8 +554,15 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
   e->reset_warm = w0; e->reset_sens = s0;
   if (he == hipSuccess) he = hipMemset(e->episode, 0, sizeof(int) * n_env);     // (the reset above was not an episode's)
-  if (he == hipSuccess && m.ncam > 0) {         // the ray caster's scene row at the reset state
-    he = hipMalloc(&e->reset_scene, sizeof(double) * mj::scene_doubles(m));
+  if (he == hipSuccess && m.ncam > 0) {         // the ray caster's constants, and its scene row at the reset state
+    std::vector<float> rc(m.ncam + m.nlight);
+    const double pi = 3.14159265358979323846;
+    for (int c = 0; c < m.ncam; c++) rc[c] = (float)tan(0.5 * m.cam_fovy[c] * pi / 180.0);
+    for (int li = 0; li < m.nlight; li++)         // (cutoff >= 180: no cone -- a cosine no (-L . dir) can fall below)
+      rc[m.ncam + li] = m.light_cutoff[li] < 180.0 ? (float)cos(m.light_cutoff[li] * pi / 180.0) : -2.0f;
+    he = hipMalloc(&e->render_consts, sizeof(float) * rc.size());
+    if (he == hipSuccess) he = hipMemcpy(e->render_consts, rc.data(), sizeof(float) * rc.size(), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc(&e->reset_scene, sizeof(double) * mj::scene_doubles(m));
     if (he == hipSuccess) {
       hipLaunchKernelGGL(mjrl_camera_frames_kernel, dim3(1), dim3(64), lds_bytes, e->stream, e->dm, e->dm.qpos0, 1, e->reset_scene);
       he = hipGetLastError();
@@ -1356,7 +1365,7 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
   int tiles = (int)((target + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
   tiles = std::max(1, std::min(tiles, std::max(1, nblock / 2)));
   hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), render_lds_bytes(e->hm), e->stream, e->dm,
-                     e->scene, e->n_env, width, height, tiles, d_rgb, e->variant, e->variant_rgba);
+                     e->scene, e->n_env, width, height, tiles, d_rgb, e->variant, e->variant_rgba, e->render_consts);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }

@@ -9,6 +9,14 @@
 
 namespace mj {
 
+// Reciprocal, square root and reciprocal square root as the hardware's one-instruction approximations (v_rcp_f32,
+// v_sqrt_f32, v_rsq_f32: 1 ulp).  The correctly rounded forms the compiler emits for `/` and sqrtf are 10 and 12
+// instructions each -- 25 divisions and 19 square roots made a fifth of the ray kernel's instructions -- and the last
+// bit of a ray parameter decides nothing an 8-bit image shows beyond the silhouette pixels the tests already allow.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ F3 ldf3(const float* p) { return f3(p[0], p[1], p[2]); }
@@ -17,8 +25,8 @@ __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y -
 __device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
 __device__ __forceinline__ float dotf(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ F3 normalizedf(F3 a) {
-  float n = sqrtf(dotf(a, a));
-  return n < 1e-20f ? f3(1, 0, 0) : a * (1.0f / n);
+  float n2 = dotf(a, a);
+  return n2 < 1e-40f ? f3(1, 0, 0) : a * frsq(n2);
 }
 // row-major 3x3 in nine floats
 __device__ __forceinline__ F3 mulf(const float* m, F3 v) {
@@ -34,7 +42,7 @@ __device__ __forceinline__ float ray_sphere_atf(F3 center, float r, F3 pnt, F3 v
   float b = dotf(vec, rel), cc = dotf(rel, rel) - r * r;
   float det = b * b - cc;
   if (det < 0) return -1;
-  float sq = sqrtf(det);
+  float sq = fsqrt(det);
   float x0 = -b - sq, x1 = -b + sq;
   if (x0 >= 0) return x0;
   if (x1 >= 0) return x1;
@@ -47,7 +55,7 @@ __device__ __forceinline__ float ray_geomf(int type, F3 gp, const float* gm, F3 
     F3 n = colf(gm, 2);
     float denom = dotf(vec, n);
     if (denom > -1e-15f) return -1;
-    float x = -dotf(rel, n) / denom;
+    float x = -dotf(rel, n) * frcp(denom);
     if (x < 0) return -1;
     F3 hit = rel + vec * x;
     if (gs.x > 0 && fabsf(dotf(hit, colf(gm, 0))) > gs.x) return -1;
@@ -56,51 +64,60 @@ __device__ __forceinline__ float ray_geomf(int type, F3 gp, const float* gm, F3 
   }
   if (type == GEOM_SPHERE) return ray_sphere_atf(gp, gs.x, pnt, vec);
   if (type == GEOM_CAPSULE) {
-    F3 axis = colf(gm, 2);
-    float r = gs.x, len = gs.y, best = -1;
-    float va = dotf(vec, axis), ra = dotf(rel, axis);
-    F3 vp = vec - axis * va, rp = rel - axis * ra;
-    float a = dotf(vp, vp), b = dotf(vp, rp), cc = dotf(rp, rp) - r * r;
+    // The rangefinder's construction (ray_geom: the side's quadratic, then a sphere at either end, the smallest x >= 0
+    // that lies on the capsule), with the three quadratics written in the four products they share -- vec . axis,
+    // rel . axis, vec . rel, rel . rel (|vec| = 1) -- instead of through the projected vectors and the caps' own centres:
+    // a capsule is what most candidates of a block are (the agents' legs), and this is a third of its instructions.
+    const F3 axis = colf(gm, 2);
+    const float r = gs.x, len = gs.y;
+    float best = -1;
+    const float va = dotf(vec, axis), ra = dotf(rel, axis), bv = dotf(vec, rel), rr = dotf(rel, rel);
+    const float a = dotf(vec, vec) - va * va, b = bv - va * ra, cc = rr - ra * ra - r * r;
     if (a > 1e-15f) {
-      float det = b * b - a * cc;
+      const float det = b * b - a * cc;
       if (det >= 0) {
-        float sq = sqrtf(det), inv = 1.0f / a;
-        float xs[2] = {(-b - sq) * inv, (-b + sq) * inv};
+        const float sq = fsqrt(det), inv = frcp(a);
+        const float xs[2] = {(-b - sq) * inv, (-b + sq) * inv};
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          float x = xs[k];
+          const float x = xs[k];
           if (x >= 0 && fabsf(ra + x * va) <= len && (best < 0 || x < best)) best = x;
         }
       }
     }
+    const float cap = rr + len * len - r * r, lva = len * va, lra2 = 2.0f * len * ra;
 #pragma unroll
     for (int s = -1; s <= 1; s += 2) {
-      float x = ray_sphere_atf(gp + axis * (s * len), r, pnt, vec);
-      if (x >= 0) {
-        float h = ra + x * va;
-        if (s * h >= len && (best < 0 || x < best)) best = x;
+      // sphere of radius r at gp + s len axis: rel_s = rel - s len axis
+      const float bs = bv - s * lva, cs = cap - s * lra2, det = bs * bs - cs;
+      if (det >= 0) {
+        const float sq = fsqrt(det), x0 = -bs - sq, x1 = -bs + sq;
+        const float x = x0 >= 0 ? x0 : x1;
+        if (x >= 0 && s * (ra + x * va) >= len && (best < 0 || x < best)) best = x;
       }
     }
     return best;
   }
   if (type == GEOM_BOX) {
+    // Slab form of the rangefinder's face enumeration (ray_geom: the smallest x >= 0 among the six face planes' hits that
+    // lie inside the face): the ray is inside the box for x in [max_k near_k, min_k far_k], so the answer is that
+    // interval's start if it is >= 0, else its end -- the same two candidates, a third of the instructions.  An axis the
+    // ray runs parallel to constrains nothing if the origin lies inside its slab and everything if not.
     F3 lpv = mulTf(gm, rel), lvv = mulTf(gm, vec);
-    float lp[3] = {lpv.x, lpv.y, lpv.z}, lv[3] = {lvv.x, lvv.y, lvv.z}, s[3] = {gs.x, gs.y, gs.z};
-    float best = -1;
+    const float lp[3] = {lpv.x, lpv.y, lpv.z}, lv[3] = {lvv.x, lvv.y, lvv.z}, s[3] = {gs.x, gs.y, gs.z};
+    float tn = -3.0e38f, tf = 3.0e38f;
+    bool miss = false;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      if (fabsf(lv[k]) < 1e-15f) continue;
-      const float inv = 1.0f / lv[k];
-#pragma unroll
-      for (int sg = -1; sg <= 1; sg += 2) {
-        float x = (sg * s[k] - lp[k]) * inv;
-        if (x < 0) continue;
-        int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
-        float h1 = lp[k1] + x * lv[k1], h2 = lp[k2] + x * lv[k2];
-        if (fabsf(h1) <= s[k1] && fabsf(h2) <= s[k2] && (best < 0 || x < best)) best = x;
-      }
+      const bool par = fabsf(lv[k]) < 1e-15f;
+      const float inv = frcp(par ? 1.0f : lv[k]);
+      const float t1 = (-s[k] - lp[k]) * inv, t2 = (s[k] - lp[k]) * inv;
+      miss = miss || (par && fabsf(lp[k]) > s[k]);
+      tn = par ? tn : fmaxf(tn, fminf(t1, t2));
+      tf = par ? tf : fminf(tf, fmaxf(t1, t2));
     }
-    return best;
+    const float x = tn >= 0 ? tn : tf;
+    return (!miss && tn <= tf && x >= 0) ? x : -1;
   }
   return -1;
 }
@@ -115,7 +132,7 @@ __device__ __forceinline__ F3 geom_normalf(int type, F3 gp, const float* gm, F3 
     return normalizedf(rel - axis * h);
   }
   F3 loc = mulTf(gm, rel);
-  float ax = fabsf(loc.x) / gs.x, ay = fabsf(loc.y) / gs.y, az = fabsf(loc.z) / gs.z;
+  float ax = fabsf(loc.x) * frcp(gs.x), ay = fabsf(loc.y) * frcp(gs.y), az = fabsf(loc.z) * frcp(gs.z);
   int face = 0;
   float best = ax;
   if (ay > best) { best = ay; face = 1; }
