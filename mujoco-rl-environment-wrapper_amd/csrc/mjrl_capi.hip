@@ -204,13 +204,26 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
   const int my_type = my_geom ? m.geom_type[L] : -1;
   const float my_rb = my_geom ? (float)m.geom_rbound[L] * (1.0f + 1e-5f) + 1e-5f : 0.0f;     // (rounded up)
   const F3 my_rel = my_geom ? ldf3(GP + 3 * L) : origin;
-  for (int blk = blk0; blk < blk1; blk += blk_step) {
-    const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 8;
-    const F3 axis = pixel_ray(c0 + 4.0f, r0 + 4.0f);
-    float cosmin = 1.0f;
-    for (int k = 0; k < 4; k++)
-      cosmin = fminf(cosmin, dotf(axis, pixel_ray(c0 + ((k & 1) ? 7.5f : 0.5f), r0 + ((k & 2) ? 7.5f : 0.5f))));
-    const float cos_t = cosmin * (1.0f - 1e-5f) - 1e-6f, sin_t = fsqrt(fmaxf(1.0f - cos_t * cos_t, 0.0f));
+  // The bounding cones of the wave's blocks -- axis through the block's centre, half-angle from its corner rays: five
+  // rays per block -- are computed 64 blocks at a time, lane j the cone of the j-th block to come, and handed out
+  // through scalar registers (every lane computing every block's cone was 85 of a block's 800 instructions).
+  F3 cone_axis = origin;
+  float cone_cos = 1.0f, cone_sin = 0.0f;
+  int ahead = 0;
+  for (int blk = blk0; blk < blk1; blk += blk_step, ahead++) {
+    if ((ahead & 63) == 0) {
+      const int mine = blk + L * blk_step, mr0 = (mine / bw) * 8, mc0 = (mine % bw) * 8;
+      cone_axis = pixel_ray(mc0 + 4.0f, mr0 + 4.0f);
+      float cosmin = 1.0f;
+      for (int k = 0; k < 4; k++)
+        cosmin = fminf(cosmin, dotf(cone_axis, pixel_ray(mc0 + ((k & 1) ? 7.5f : 0.5f), mr0 + ((k & 2) ? 7.5f : 0.5f))));
+      cone_cos = cosmin * (1.0f - 1e-5f) - 1e-6f;
+      cone_sin = fsqrt(fmaxf(1.0f - cone_cos * cone_cos, 0.0f));
+    }
+    const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 8, from = ahead & 63;
+    auto pick = [&](float v) { return __int_as_float(wv::lane_int(__float_as_int(v), from)); };
+    const F3 axis = f3(pick(cone_axis.x), pick(cone_axis.y), pick(cone_axis.z));
+    const float cos_t = pick(cone_cos), sin_t = pick(cone_sin);
     const int r = r0 + (L >> 3), c = c0 + (L & 7);
     const bool inside = r < height && c < width;
     const F3 vec = pixel_ray(c + 0.5f, r + 0.5f);
