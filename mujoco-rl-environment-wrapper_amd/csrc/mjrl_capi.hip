@@ -93,7 +93,7 @@ __device__ __forceinline__ float fast_pow(float x, float y) {
   return y > 0.0f ? __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)) : 1.0f;
 }
 #ifndef MJRL_RENDER_VARIANT
-#define MJRL_RENDER_VARIANT 0        // (experiments: 1 = round 2's shading, 2 = byte stores)
+#define MJRL_RENDER_VARIANT 0        // (experiments: 1 = round 2's shading, 2 = byte stores, 3 = no type-specific tests, 4 = one candidate)
 #endif
 // one light of the ray kernel in LDS (floats): camera-relative position 3 | direction 3 | attenuation 3 | cos(cutoff) |
 // exponent | ambient 3 | diffuse 3 | specular 3 | directional
@@ -239,6 +239,9 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
         cand = !(along + rb_v < 0.0f) && perp * cos_t - along * sin_t <= rb_v + 1e-5f * (1.0f + perp);
       }
       unsigned long long todo = wv::ballot(cand);
+#if MJRL_RENDER_VARIANT == 4       // (experiment: no candidates at all)
+      todo &= 1ull;
+#endif
       while (todo) {
         const int g = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -253,7 +256,11 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
           if (d2 > rb * rb + 1e-5f * (1.0f + dotf(rel, rel)) || along + rb < 0.0f) gt = -1;
         }
         if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
+#if MJRL_RENDER_VARIANT == 3       // (experiment: the candidate loop without the type-specific tests)
+        const float x = gt >= 0 ? dotf(rel, vec) : -1.0f;
+#else
         const float x = ray_geomf(gt, rel, GM + 9 * (base + g), ldf3(GS + 3 * (base + g)), origin, vec);
+#endif
         if (x >= 0 && (best < 0 || x < best)) { best = x; hit = base + g; }
       }
     };
