@@ -123,16 +123,13 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
 // profiles/r02_pmc_render.txt -- and fp32 issues at twice the fp64 rate.  The tests bound the pixels that may differ from
 // the oracle's fp64 ray caster.)
 // The ray caster proper: blocks blk0, blk0 + blk_step, .. (< blk1) of camera `cam` of the copy whose scene row is `row`, drawn by the
-// calling wave into `img` (rows of row_bytes bytes).  The tables are staged in `ldsf` by all `nthr` threads of the
-// workgroup -- one wave in mjrl_render_kernel; MULTI = true is the form for a workgroup of several waves (the fused
-// render + convolution kernel of DESIGN.md section 9, measured and not kept).
-template <bool MULTI>
+// calling wave into `img` (rows of row_bytes bytes), its tables staged in the wave's LDS `ldsf`.
 __device__ __forceinline__ void render_body(const DevModel& m, const double* row, int cam, int width, int height, int blk0,
                                             int blk1, int blk_step, float* ldsf, unsigned char* img, int row_bytes,
-                                            const double* rgba_tab, const float* consts, int tid, int nthr) {
+                                            const double* rgba_tab, const float* consts) {
   using namespace mj;
-  const int L = tid & 63;
-  auto barrier = [&]() { if constexpr (MULTI) __syncthreads(); else wv::sync(); };
+  const int L = wv::lane(), tid = L, nthr = 64;
+  auto barrier = [&]() { wv::sync(); };
   // LDS: the copy's geom positions, matrices and sizes
   float* GP = ldsf;
   float* GM = ldsf + 3 * m.ngeom;
@@ -345,8 +342,8 @@ __global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const doubl
   const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
   const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
   const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
-  render_body<false>(m, scene + (size_t)env * scene_doubles(m), cam, width, height, blk0, blk1, 1, ldsf,
-                     rgb + ((size_t)env * m.ncam + cam) * width * height * 3, 3 * width, rgba_tab, consts, wv::lane(), 64);
+  render_body(m, scene + (size_t)env * scene_doubles(m), cam, width, height, blk0, blk1, 1, ldsf,
+              rgb + ((size_t)env * m.ncam + cam) * width * height * 3, 3 * width, rgba_tab, consts);
 }
 
 // the ray kernel's LDS: geom positions, matrices and sizes
