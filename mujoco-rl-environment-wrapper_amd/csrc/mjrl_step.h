@@ -1834,6 +1834,7 @@ __device__ MJRL_TALL_INLINE TallOut pgs_tall_registers(real* S, const int* I, in
 // than 256 registers.)
 struct SchedArgs {
   int o_rowid, o_rowinfo, o_row, o_J, o_tab;   // LDS offsets (Lay)
+  int o_Dinv, adr0;                            // 1 / D of the factorised inertia matrix, first dof of the lane's tree
   int base, len, iterations;                   // the lane's list, sweep length, sweep cap
   int tab_dtree, tab_bytes;                    // dof -> tree table (Tab)
   int depth;                                   // of the lane's dof (RowK)
@@ -1946,6 +1947,200 @@ __device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool
   iter_io = iter;
   return u;
 }
+
+// The same schedule (at most 16 positions: lane k of a tree's 16 owns position k of the tree's list) in RESIDUAL form --
+// the 16-row register solver of stage_pgs, generalised to rows that couple two trees.  Such a row sits at the same
+// position of both its trees' lists and is kept twice, once per tree: each copy owns the part of the row's residual
+// that comes through its tree's dofs, r_t = (B_t D_t^-1 B_t' f), with R f + b added in the lower-numbered tree's copy.
+// A step on a coupling position adds the two parts through the LDS crossbar (a + b == b + a: both copies get the same
+// bits), takes the step in both copies at once, and every tree updates its own rows' residuals with its own column of
+// AR.  Everything else -- one max, one DPP broadcast and one fused multiply-add per row step, the cost changes from
+// captured residuals once per sweep and one sweep late, the guarded sweeps -- is the 16-row solver's, so a copy with an
+// agent-against-agent contact no longer runs the u-form sweep (45 instructions and a 16-lane reduction per position:
+// 140-180 us per wave on the 4-agent arena, up to 320 -- the waves its launches waited for).
+// AR's columns for a coupling position cannot be read from the row's J block (it is stored along its two chains, not in
+// the tree's slots): they are formed from the lanes' own coefficients `bid` (lane = dof), broadcast one dof at a time.
+#define MJ_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+__device__ inline real pgs_schedule_residual(real* S, const int* I, int L, bool dof, SchedArgs w, int ntree, int& iter_io) {
+  const int k = L & 15, mytree = L >> 4;
+  const bool mine = w.len > 0;
+  const int len = wv::first_int(w.len), iterations = wv::first_int(w.iterations);
+  int iter = wv::first_int(iter_io);
+  const unsigned char* t8 = (const unsigned char*)(S + w.o_tab);
+  auto dof_tree = [&](int d) { return w.tab_bytes ? (int)t8[w.tab_dtree + d] : (int)((const unsigned short*)t8)[w.tab_dtree + d]; };
+  auto entry = [&](int p) { return (mine && p < len) ? I[w.o_rowid + w.base + p] : -1; };
+  auto coef = [&](int r, int info) -> real {
+    const int rt = (info >> CHAIN_BITS) - 2;
+    const int sl = rt >= 0 ? (rt == mytree ? k : -1) : row_slot(info, w.below, w.depth);
+    return (dof && sl >= 0) ? S[w.o_J + JW * r + sl] : 0.0;
+  };
+  // the lane's (= its dof's) coefficient at every position of its tree's list
+  real bid[16];
+#pragma unroll
+  for (int p = 0; p < 16; p++) {
+    const int e = entry(p);
+    bid[p] = e >= 0 ? coef(e, I[w.o_rowinfo + e]) : 0.0;
+  }
+  // the record of the lane's own position
+  const int e_me = entry(k);
+  const bool has = e_me >= 0;
+  const int row = has ? e_me : 0;
+  real* Rm = S + w.o_row + ROW_STRIDE * row;
+  real fi = has ? Rm[ROW_F] : 0.0, bi = has ? Rm[ROW_B] : 0.0, Ri = has ? Rm[ROW_R] : 0.0;
+  const real aii = has ? Rm[ROW_ARII] : 1.0;
+  const real ainv = 1.0 / aii;
+  int partner = -1;               // first lane of the other tree of a coupling row
+  real once = has ? 1.0 : 0.0;    // 0 in the second copy of a coupling row: its cost change, R f and b count once
+  {
+    const int info = I[w.o_rowinfo + row];
+    if (has && (info >> CHAIN_BITS) == 0) {
+      const int t1 = dof_tree(info & 63), t2 = dof_tree(((info >> 9) & 127) - 1);
+      partner = 16 * (t1 == mytree ? t2 : t1);
+      if (mytree != (t1 < t2 ? t1 : t2)) { once = 0.0; bi = 0.0; Ri = 0.0; }
+    }
+  }
+  unsigned anyc;                  // positions at which some tree has a coupling row
+  {
+    const unsigned long long c0 = wv::ballot(partner >= 0);
+    anyc = (unsigned)((c0 | (c0 >> 16) | (c0 >> 32) | (c0 >> 48)) & 0xFFFFull);
+  }
+  // W = (the own row's coefficients in its tree's 16 slots) x D^-1; a tree-local row's are its J block
+  real W[16], A[16];
+#pragma unroll
+  for (int d = 0; d < 16; d++)
+    W[d] = (has && partner < 0) ? S[w.o_J + JW * row + d] * S[w.o_Dinv + w.adr0 + d] : 0.0;
+#define MJ_WSTEP(KK)                                                                  \
+  if (KK >= len) break;                                                               \
+  if ((anyc >> KK) & 1u) {                                                            \
+    _Pragma("unroll")                                                                 \
+    for (int d = 0; d < 16; d++) {                                                    \
+      const real x = wv::bcast16_var(bid[KK], d);                                     \
+      if (k == KK && partner >= 0) W[d] = x * S[w.o_Dinv + w.adr0 + d];               \
+    }                                                                                 \
+  }
+  do { MJ_ROWS16(MJ_WSTEP) } while (0);
+#undef MJ_WSTEP
+  const int has_i = has ? 1 : 0;
+#define MJ_ASTEP(KK)                                                                  \
+  if (KK >= len) break;                                                               \
+  {                                                                                   \
+    real p0 = 0, p1 = 0, p2 = 0, p3 = 0;                                              \
+    if ((anyc >> KK) & 1u) {                                                          \
+      _Pragma("unroll")                                                               \
+      for (int d = 0; d < 16; d += 4) {                                               \
+        p0 += W[d] * wv::bcast16_var(bid[KK], d); p1 += W[d + 1] * wv::bcast16_var(bid[KK], d + 1); \
+        p2 += W[d + 2] * wv::bcast16_var(bid[KK], d + 2); p3 += W[d + 3] * wv::bcast16_var(bid[KK], d + 3); \
+      }                                                                               \
+    } else {                                                                          \
+      const real* Bk = S + w.o_J + JW * wv::bcast16i<KK>(row);                        \
+      _Pragma("unroll")                                                               \
+      for (int d = 0; d < 16; d += 4) {                                               \
+        p0 += W[d] * Bk[d]; p1 += W[d + 1] * Bk[d + 1]; p2 += W[d + 2] * Bk[d + 2]; p3 += W[d + 3] * Bk[d + 3]; \
+      }                                                                               \
+      if (!wv::bcast16i<KK>(has_i)) { p0 = 0; p1 = 0; p2 = 0; p3 = 0; }               \
+    }                                                                                 \
+    real acc = (p0 + p1) + (p2 + p3);                                                 \
+    if (KK == k) acc += Ri;                                                           \
+    A[KK] = acc;                                                                      \
+  }
+#pragma unroll
+  for (int q = 0; q < 16; q++) A[q] = 0;
+  do { MJ_ROWS16(MJ_ASTEP) } while (0);
+#undef MJ_ASTEP
+  real r = bi;
+#define MJ_RINIT(KK) if (KK >= len) break; r += A[KK] * wv::bcast16<KK>(fi);
+  do { MJ_ROWS16(MJ_RINIT) } while (0);
+#undef MJ_RINIT
+  real sr = r * ainv;
+#pragma unroll
+  for (int q = 0; q < 16; q++) A[q] *= ainv;
+  const real haii = 0.5 * aii, scale = w.scale, tolerance = w.tolerance;
+  // the row's whole (scaled, negated) residual at a coupling position: this copy's part plus the other tree's
+#define MJ_WHOLE(KK, v)                                                               \
+  if ((anyc >> KK) & 1u) {                                                            \
+    const real other = wv::shfl(v, partner >= 0 ? partner + k : L);                   \
+    if (partner >= 0) v += other;                                                     \
+  }
+  real f_start = fi, s_start = sr, f_prev = fi, s_prev = sr, c_prev = 0;
+  bool pending = false, guarded = false;
+  while (iter < iterations) {
+    const int k_s = wv::opaque_lane(k), len_s = wv::opaque_uniform(len);
+    f_start = fi; s_start = sr;
+    real ns = -sr, nss = ns;
+    const real nf = -fi;
+    unsigned long long refused = 0ull, deciding = 1ull;
+    if (pending) { refused = wv::ballot(c_prev > 1e-10); deciding = wv::ballot((-c_prev - 1e-8) * scale >= tolerance); }
+#define MJ_FSTEP(KK)                                                                  \
+    {                                                                                 \
+      real nsx = ns;                                                                  \
+      MJ_WHOLE(KK, nsx)                                                               \
+      real db = wv::bcast16<KK>(fmax(nsx, nf));                                       \
+      if (k_s == KK) nss = nsx;                                                       \
+      ns = __builtin_fma(-A[KK], db, ns);                                             \
+    }
+    MJ_FSTEP(0) MJ_FSTEP(1)
+    if (pending && (refused != 0ull || deciding == 0ull)) {
+      const real improvement = wv::rows_sum(wv::sum16(-c_prev), ntree);
+      if (refused != 0ull || wv::ballot(improvement * scale < tolerance)) {
+        if (refused != 0ull) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
+        else { sr = s_start; }                                                       // it had converged
+        pending = false;
+        break;
+      }
+    }
+    do {
+      if (2 >= len_s) break;
+      MJ_FSTEP(2) MJ_FSTEP(3)
+      if (4 >= len_s) break;
+      MJ_FSTEP(4) MJ_FSTEP(5) MJ_FSTEP(6) MJ_FSTEP(7)
+      if (8 >= len_s) break;
+      MJ_FSTEP(8) MJ_FSTEP(9) MJ_FSTEP(10) MJ_FSTEP(11)
+      if (12 >= len_s) break;
+      MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
+    } while (0);
+#undef MJ_FSTEP
+    sr = -ns;
+    const real ss = -nss;
+    fi = fmax(f_start - ss, 0.0);
+    const real dsweep = fi - f_start;
+    c_prev = (dsweep * dsweep * haii + dsweep * (ss * aii)) * once;
+    f_prev = f_start; s_prev = s_start;
+    pending = true;
+    iter++;
+  }
+  if (pending && wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
+  while (guarded && iter < iterations) {
+    real imp = 0;
+    const int k_g = wv::opaque_lane(k);
+#define MJ_GSTEP(KK)                                                                  \
+    if (KK < len) {                                                                   \
+      real srx = sr;                                                                  \
+      MJ_WHOLE(KK, srx)                                                               \
+      real fn = fmax(fi - srx, 0.0);                                                  \
+      real delta = fn - fi;                                                           \
+      real change = delta * delta * haii + delta * (srx * aii);                       \
+      bool act = k_g == KK && has && !(change > 1e-10);                               \
+      if (!act) { delta = 0; change = 0; fn = fi; }                                   \
+      fi = fn;                                                                        \
+      imp -= change * once;                                                           \
+      sr += A[KK] * wv::bcast16<KK>(delta);                                           \
+    }
+    MJ_ROWS16(MJ_GSTEP)
+#undef MJ_GSTEP
+    iter++;
+    if (wv::rows_sum(wv::sum16(imp), ntree) * scale < tolerance) break;
+  }
+#undef MJ_WHOLE
+  if (has && once != 0.0) Rm[ROW_F] = fi;
+  // u = B' f for the lane's dof
+  real u = 0;
+#define MJ_USTEP(KK) if (KK >= len) break; u += bid[KK] * wv::bcast16<KK>(fi);
+  do { MJ_ROWS16(MJ_USTEP) } while (0);
+#undef MJ_USTEP
+  iter_io = iter;
+  return u;
+}
+#undef MJ_ROWS16
 
 __device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
 #if defined(MJRL_SPEC) || !defined(__HIPCC__)
@@ -2263,8 +2458,13 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       w.tab_dtree = T.dtree; w.tab_bytes = T.bytes ? 1 : 0;
       w.depth = RK.depth; w.below = RK.below;
       w.tolerance = m.tolerance; w.scale = scale; w.dinv = dinv; w.u = u;
+      w.o_Dinv = l.Dinv; w.adr0 = mytree < m.ntree ? m.tree_dofadr[mytree] : 0;
       int it = iter;        // (a local of its own: the counter of the other solver paths never has its address taken)
+#ifdef MJRL_NO_SCHED_RESIDUAL      // (experiments: the u-form sweep for every schedule, as before)
       u = sched_len <= 16 ? pgs_schedule_registers<16>(S, I, L, dof, w, it) : pgs_schedule_registers<32>(S, I, L, dof, w, it);
+#else
+      u = sched_len <= 16 ? pgs_schedule_residual(S, I, L, dof, w, m.ntree, it) : pgs_schedule_registers<32>(S, I, L, dof, w, it);
+#endif
       iter = it;
       wv::sync();
     } else {

@@ -78,6 +78,15 @@ __device__ __forceinline__ double bcast16(double v) { return dpp<0x150 + N>(v); 
 
 template <int N>
 __device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, true); }
+// the same with the lane as an argument: for fully unrolled loops, where it is a constant by the time the switch is seen
+__device__ __forceinline__ double bcast16_var(double v, int n) {
+  switch (n & 15) {
+    case 0: return bcast16<0>(v); case 1: return bcast16<1>(v); case 2: return bcast16<2>(v); case 3: return bcast16<3>(v);
+    case 4: return bcast16<4>(v); case 5: return bcast16<5>(v); case 6: return bcast16<6>(v); case 7: return bcast16<7>(v);
+    case 8: return bcast16<8>(v); case 9: return bcast16<9>(v); case 10: return bcast16<10>(v); case 11: return bcast16<11>(v);
+    case 12: return bcast16<12>(v); case 13: return bcast16<13>(v); case 14: return bcast16<14>(v); default: return bcast16<15>(v);
+  }
+}
 
 // the caller's value from the lower (HIGH = false) or upper half of the wave, in both halves: lane i and lane i + 32
 // both get lane (i + 32 HIGH)'s value.  One v_permlane32_swap per dword (gfx950).

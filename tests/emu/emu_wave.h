@@ -70,6 +70,7 @@ template <int N>
 inline double bcast16(double v) { return shfl(v, (lane() & ~15) + N); }   // lane N of the caller's row of 16
 template <int N>
 inline int bcast16i(int v) { return shfl(v, (lane() & ~15) + N); }   // lane N of the caller's row of 16
+inline double bcast16_var(double v, int n) { return shfl(v, (lane() & ~15) + (n & 15)); }
 template <bool HIGH>
 inline int half_to_all_i(int v) { return shfl(v, (lane() & 31) + (HIGH ? 32 : 0)); }
 template <bool HIGH>
