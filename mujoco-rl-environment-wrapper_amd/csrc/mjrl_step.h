@@ -1825,13 +1825,8 @@ __device__ MJRL_TALL_INLINE TallOut pgs_tall_registers(real* S, const int* I, in
 }
 #undef MJ_ROWS32
 
-// The sweep of a copy on a row schedule (pgs_coupled_schedule: every tree's list of rows, coupling rows at the same
-// position of both their trees' lists) of at most 16 positions, with everything but the arithmetic out of the loop:
-// the lane's coefficient in the row at every position in 16 registers, the rows' records (R, b, AR_ii, its reciprocal,
-// the force) in the lanes -- lane k of a tree's 16 keeps position k -- and broadcast by DPP.  Operation for operation
-// the LDS-resident sweep of stage_pgs (same sums, same order), at a third of its instructions.  (Inlined: as a function
-// of its own its argument list alone cost the kernel 80 B of scratch per lane; 32 positions, two per lane, need more
-// than 256 registers.)
+// Arguments of the register solver for a copy on a row schedule (pgs_coupled_schedule: every tree's list of rows, coupling
+// rows at the same position of both their trees' lists).
 struct SchedArgs {
   int o_rowid, o_rowinfo, o_row, o_J, o_tab;   // LDS offsets (Lay)
   int o_Dinv, adr0;                            // 1 / D of the factorised inertia matrix, first dof of the lane's tree
@@ -1841,127 +1836,27 @@ struct SchedArgs {
   unsigned long long below;
   real tolerance, scale, dinv, u;
 };
-template <int NP>       // 16: one position per lane; 32: two (more than 256 registers: for images that hold a CU to 4 copies anyway)
-__device__ inline real pgs_schedule_registers(real* S, const int* I, int L, bool dof, SchedArgs w, int& iter_io) {
-  const int k = L & 15, mytree = L >> 4;
-  // (the sweep length is wave-uniform -- lane 0's, tree 0 always exists --; the rows of 16 lanes of a tree the model does
-  // not have come in with length 0 and hold no list: treated as a tree they would walk tree 0's list on their own,
-  // write their forces over the real ones and add to the sweep's improvement)
-  const bool mine = w.len > 0;
-  const int len = wv::first_int(w.len), iterations = wv::first_int(w.iterations);
-  int iter = wv::first_int(iter_io);
-  const unsigned char* t8 = (const unsigned char*)(S + w.o_tab);
-  auto dof_tree = [&](int d) { return w.tab_bytes ? (int)t8[w.tab_dtree + d] : (int)((const unsigned short*)t8)[w.tab_dtree + d]; };
-  auto entry = [&](int p) { return (mine && p < len) ? I[w.o_rowid + w.base + p] : -1; };
-  auto coef = [&](int r, int info) -> real {
-    const int rt = (info >> CHAIN_BITS) - 2;
-    const int sl = rt >= 0 ? (rt == mytree ? k : -1) : row_slot(info, w.below, w.depth);
-    return (dof && sl >= 0) ? S[w.o_J + JW * r + sl] : 0.0;
-  };
-  // the lane's coefficient at every position
-  real bid[NP];
-#pragma unroll
-  for (int p = 0; p < NP; p++) {
-    const int e = entry(p);
-    bid[p] = e >= 0 ? coef(e, I[w.o_rowinfo + e]) : 0.0;
-  }
-  // the record of position k (an empty position: reciprocal 0, so its step changes nothing)
-  struct Own { int row; bool has; real f, Ri, bi, aii, ainv, cnt; int partner; };
-  auto own = [&](int p) {
-    Own o;
-    const int e = entry(p);
-    o.has = e >= 0;
-    o.row = o.has ? e : 0;
-    const real* R = S + w.o_row + ROW_STRIDE * o.row;
-    const int info = I[w.o_rowinfo + o.row];
-    o.f = o.has ? R[ROW_F] : 0.0; o.Ri = o.has ? R[ROW_R] : 0.0; o.bi = o.has ? R[ROW_B] : 0.0;
-    o.aii = o.has ? R[ROW_ARII] : 1.0;
-    o.ainv = o.has ? 1.0 / o.aii : 0.0;
-    o.cnt = o.has ? 1.0 : 0.0;
-    o.partner = -1;
-    if (o.has && (info >> CHAIN_BITS) == 0) {        // a row that couples two trees
-      const int t1 = dof_tree(info & 63), t2 = dof_tree(((info >> 9) & 127) - 1);
-      o.partner = 16 * (t1 == mytree ? t2 : t1);
-      if (mytree != (t1 < t2 ? t1 : t2)) o.cnt = 0.0;     // its cost change enters the sweep's improvement once
-    }
-    return o;
-  };
-  Own o0 = own(k), o1 = own(NP > 16 ? k + 16 : (1 << 20));
-  // positions at which some tree has a coupling row (bit p)
-  unsigned anyc;
-  {
-    const unsigned long long c0 = wv::ballot(o0.partner >= 0), c1 = wv::ballot(o1.partner >= 0);
-    anyc = (unsigned)((c0 | (c0 >> 16) | (c0 >> 32) | (c0 >> 48)) & 0xFFFFull)
-         | ((unsigned)((c1 | (c1 >> 16) | (c1 >> 32) | (c1 >> 48)) & 0xFFFFull) << 16);
-  }
-  const real dinv = w.dinv, scale = w.scale, tolerance = w.tolerance;
-  real u = w.u;
-  while (iter < iterations) {
-    real imp = 0;
-    const int len_s = wv::opaque_uniform(len);
-#define MJ_PSTEP(P)                                                                   \
-      {                                                                               \
-        const real Ri = tall_bcast<P>(o0.Ri, o1.Ri), bi = tall_bcast<P>(o0.bi, o1.bi);  \
-        const real aii = tall_bcast<P>(o0.aii, o1.aii), ainv = tall_bcast<P>(o0.ainv, o1.ainv); \
-        const real fi = tall_bcast<P>(o0.f, o1.f), cnt = tall_bcast<P>(o0.cnt, o1.cnt); \
-        real res = wv::sum16(bid[P < NP ? P : 0] * dinv * u);                         \
-        if ((anyc >> P) & 1u) {                                                       \
-          const int pl = wv::bcast16i<(P & 15)>(P < 16 ? o0.partner : o1.partner);    \
-          const real other = wv::shfl(res, pl >= 0 ? pl + k : L);                     \
-          if (pl >= 0) res += other;                                                  \
-        }                                                                             \
-        res = res + Ri * fi + bi;                                                     \
-        real fn = fi - res * ainv;                                                    \
-        if (fn < 0) fn = 0;                                                           \
-        real delta = fn - fi;                                                         \
-        real change = 0.5 * delta * delta * aii + delta * res;                        \
-        if (change > 1e-10) { fn = fi; delta = 0; change = 0; }                       \
-        imp -= change * cnt;                                                          \
-        u += delta * bid[P < NP ? P : 0];                                             \
-        if (k == (P & 15)) { if (P < 16) o0.f = fn; else o1.f = fn; }                 \
-      }
-    do {
-      MJ_PSTEP(0) MJ_PSTEP(1) MJ_PSTEP(2) MJ_PSTEP(3)
-      if (4 >= len_s) break;
-      MJ_PSTEP(4) MJ_PSTEP(5) MJ_PSTEP(6) MJ_PSTEP(7)
-      if (8 >= len_s) break;
-      MJ_PSTEP(8) MJ_PSTEP(9) MJ_PSTEP(10) MJ_PSTEP(11)
-      if (12 >= len_s) break;
-      MJ_PSTEP(12) MJ_PSTEP(13) MJ_PSTEP(14) MJ_PSTEP(15)
-      if (NP <= 16 || 16 >= len_s) break;
-      MJ_PSTEP(16) MJ_PSTEP(17) MJ_PSTEP(18) MJ_PSTEP(19)
-      if (20 >= len_s) break;
-      MJ_PSTEP(20) MJ_PSTEP(21) MJ_PSTEP(22) MJ_PSTEP(23)
-      if (24 >= len_s) break;
-      MJ_PSTEP(24) MJ_PSTEP(25) MJ_PSTEP(26) MJ_PSTEP(27)
-      if (28 >= len_s) break;
-      MJ_PSTEP(28) MJ_PSTEP(29) MJ_PSTEP(30) MJ_PSTEP(31)
-    } while (0);
-#undef MJ_PSTEP
-    iter++;
-    const real improvement = wv::rows4_sum(imp);
-    if (improvement * scale < tolerance) break;
-  }
-  if (o0.has) S[w.o_row + ROW_STRIDE * o0.row + ROW_F] = o0.f;
-  if (o1.has) S[w.o_row + ROW_STRIDE * o1.row + ROW_F] = o1.f;
-  iter_io = iter;
-  return u;
-}
-
-// The same schedule (at most 16 positions: lane k of a tree's 16 owns position k of the tree's list) in RESIDUAL form --
-// the 16-row register solver of stage_pgs, generalised to rows that couple two trees.  Such a row sits at the same
+// The sweep of a copy on a row schedule (lane k of a tree's 16 owns position k of the tree's list) in RESIDUAL form --
+// the 16-row register solver of stage_pgs, generalised to rows that couple two trees.  (Round 2 and most of round 3 ran
+// these copies in u-form from registers -- pgs_schedule_registers: the lane's coefficient at every position, the rows'
+// records broadcast by DPP, a 16-lane reduction per position: 45 instructions per position.)  Such a row sits at the same
 // position of both its trees' lists and is kept twice, once per tree: each copy owns the part of the row's residual
 // that comes through its tree's dofs, r_t = (B_t D_t^-1 B_t' f), with R f + b added in the lower-numbered tree's copy.
 // A step on a coupling position adds the two parts through the LDS crossbar (a + b == b + a: both copies get the same
 // bits), takes the step in both copies at once, and every tree updates its own rows' residuals with its own column of
 // AR.  Everything else -- one max, one DPP broadcast and one fused multiply-add per row step, the cost changes from
 // captured residuals once per sweep and one sweep late, the guarded sweeps -- is the 16-row solver's, so a copy with an
-// agent-against-agent contact no longer runs the u-form sweep (45 instructions and a 16-lane reduction per position:
-// 140-180 us per wave on the 4-agent arena, up to 320 -- the waves its launches waited for).
+// agent-against-agent contact costs a dozen instructions per position instead of 45 (those waves took 140-180 us on the
+// 4-agent arena, up to 320: the waves its launches waited for).
 // AR's columns for a coupling position cannot be read from the row's J block (it is stored along its two chains, not in
-// the tree's slots): they are formed from the lanes' own coefficients `bid` (lane = dof), broadcast one dof at a time.
-#define MJ_ROWS16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
-__device__ inline real pgs_schedule_residual(real* S, const int* I, int L, bool dof, SchedArgs w, int ntree, int& iter_io) {
+// the tree's slots): they are formed from the lanes' own coefficients (lane = dof, `bid`), broadcast one dof at a time.
+// (NP = 16: one position per lane; NP = 32: two, lane k owns positions k and k + 16 -- some 400 registers, for images
+// that hold a CU to one wave per SIMD anyway, like pgs_tall_registers)
+#define MJ_POS32(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+                    X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+template <int NP>
+__device__ inline __attribute__((always_inline)) real pgs_schedule_residual(real* S, const int* I, int L, bool dof, SchedArgs w, int ntree, int& iter_io) {
+  constexpr int RP = NP / 16;     // records (positions) per lane
   const int k = L & 15, mytree = L >> 4;
   const bool mine = w.len > 0;
   const int len = wv::first_int(w.len), iterations = wv::first_int(w.iterations);
@@ -1974,116 +1869,176 @@ __device__ inline real pgs_schedule_residual(real* S, const int* I, int L, bool 
     const int sl = rt >= 0 ? (rt == mytree ? k : -1) : row_slot(info, w.below, w.depth);
     return (dof && sl >= 0) ? S[w.o_J + JW * r + sl] : 0.0;
   };
-  // the lane's (= its dof's) coefficient at every position of its tree's list
-  real bid[16];
-#pragma unroll
-  for (int p = 0; p < 16; p++) {
+  // the lane's (= its dof's) coefficient at position p of its tree's list
+  auto bid = [&](int p) -> real {
     const int e = entry(p);
-    bid[p] = e >= 0 ? coef(e, I[w.o_rowinfo + e]) : 0.0;
-  }
-  // the record of the lane's own position
-  const int e_me = entry(k);
-  const bool has = e_me >= 0;
-  const int row = has ? e_me : 0;
-  real* Rm = S + w.o_row + ROW_STRIDE * row;
-  real fi = has ? Rm[ROW_F] : 0.0, bi = has ? Rm[ROW_B] : 0.0, Ri = has ? Rm[ROW_R] : 0.0;
-  const real aii = has ? Rm[ROW_ARII] : 1.0;
-  const real ainv = 1.0 / aii;
-  int partner = -1;               // first lane of the other tree of a coupling row
-  real once = has ? 1.0 : 0.0;    // 0 in the second copy of a coupling row: its cost change, R f and b count once
-  {
-    const int info = I[w.o_rowinfo + row];
-    if (has && (info >> CHAIN_BITS) == 0) {
+    return e >= 0 ? coef(e, I[w.o_rowinfo + (e >= 0 ? e : 0)]) : 0.0;
+  };
+  // the records of the lane's own positions
+  bool has[RP];
+  int row[RP], has_i[RP], partner[RP];      // partner: first lane of the other tree of a coupling row, else -1
+  real fi[RP], bi[RP], Ri[RP], aii[RP], ainv[RP], haii[RP];
+  real once[RP];                            // 0 in the second copy of a coupling row: its cost change, R f and b count once
+  real* Rm[RP];
+#pragma unroll
+  for (int j = 0; j < RP; j++) {
+    const int e = entry(k + 16 * j);
+    has[j] = e >= 0; has_i[j] = has[j] ? 1 : 0;
+    row[j] = has[j] ? e : 0;
+    Rm[j] = S + w.o_row + ROW_STRIDE * row[j];
+    fi[j] = has[j] ? Rm[j][ROW_F] : 0.0; bi[j] = has[j] ? Rm[j][ROW_B] : 0.0; Ri[j] = has[j] ? Rm[j][ROW_R] : 0.0;
+    aii[j] = has[j] ? Rm[j][ROW_ARII] : 1.0;
+    ainv[j] = 1.0 / aii[j];
+    haii[j] = 0.5 * aii[j];
+    partner[j] = -1;
+    once[j] = has[j] ? 1.0 : 0.0;
+    const int info = I[w.o_rowinfo + row[j]];
+    if (has[j] && (info >> CHAIN_BITS) == 0) {
       const int t1 = dof_tree(info & 63), t2 = dof_tree(((info >> 9) & 127) - 1);
-      partner = 16 * (t1 == mytree ? t2 : t1);
-      if (mytree != (t1 < t2 ? t1 : t2)) { once = 0.0; bi = 0.0; Ri = 0.0; }
+      partner[j] = 16 * (t1 == mytree ? t2 : t1);
+      if (mytree != (t1 < t2 ? t1 : t2)) { once[j] = 0.0; bi[j] = 0.0; Ri[j] = 0.0; }
     }
   }
-  unsigned anyc;                  // positions at which some tree has a coupling row
-  {
-    const unsigned long long c0 = wv::ballot(partner >= 0);
-    anyc = (unsigned)((c0 | (c0 >> 16) | (c0 >> 32) | (c0 >> 48)) & 0xFFFFull);
-  }
-  // W = (the own row's coefficients in its tree's 16 slots) x D^-1; a tree-local row's are its J block
-  real W[16], A[16];
+  unsigned anyc = 0u;             // positions at which some tree has a coupling row
 #pragma unroll
-  for (int d = 0; d < 16; d++)
-    W[d] = (has && partner < 0) ? S[w.o_J + JW * row + d] * S[w.o_Dinv + w.adr0 + d] : 0.0;
-#define MJ_WSTEP(KK)                                                                  \
-  if (KK >= len) break;                                                               \
-  if ((anyc >> KK) & 1u) {                                                            \
-    _Pragma("unroll")                                                                 \
-    for (int d = 0; d < 16; d++) {                                                    \
-      const real x = wv::bcast16_var(bid[KK], d);                                     \
-      if (k == KK && partner >= 0) W[d] = x * S[w.o_Dinv + w.adr0 + d];               \
-    }                                                                                 \
+  for (int j = 0; j < RP; j++) {
+    const unsigned long long c = wv::ballot(partner[j] >= 0);
+    anyc |= (unsigned)((c | (c >> 16) | (c >> 32) | (c >> 48)) & 0xFFFFull) << (16 * j);
   }
-  do { MJ_ROWS16(MJ_WSTEP) } while (0);
+  // AR, one of the lane's own rows at a time (both at once is 64 more registers at the solver's widest point):
+  // W = (the own row's coefficients in its tree's 16 slots) x D^-1 -- a tree-local row's are its J block, a coupling
+  // row's come over DPP from the dof lanes --, then column P of AR against it, the column's coefficients streamed
+  real A[RP][NP];
+#pragma unroll
+  for (int j = 0; j < RP; j++) {
+    real W[16];
+#pragma unroll
+    for (int d = 0; d < 16; d++)
+      W[d] = (has[j] && partner[j] < 0) ? S[w.o_J + JW * row[j] + d] * S[w.o_Dinv + w.adr0 + d] : 0.0;
+#define MJ_WSTEP(P)                                                                   \
+    if (P >= NP || P >= len) break;                                                   \
+    if (((anyc >> P) & 1u) && (P < NP ? P : 0) / 16 == j) {                           \
+      const real mine_p = bid(P);                                                     \
+      _Pragma("unroll")                                                               \
+      for (int d = 0; d < 16; d++) {                                                  \
+        const real x = wv::bcast16_var(mine_p, d);                                    \
+        if (k == (P & 15) && partner[j] >= 0) W[d] = x * S[w.o_Dinv + w.adr0 + d];    \
+      }                                                                               \
+    }
+    do { MJ_POS32(MJ_WSTEP) } while (0);
 #undef MJ_WSTEP
-  const int has_i = has ? 1 : 0;
-#define MJ_ASTEP(KK)                                                                  \
-  if (KK >= len) break;                                                               \
-  {                                                                                   \
-    real p0 = 0, p1 = 0, p2 = 0, p3 = 0;                                              \
-    if ((anyc >> KK) & 1u) {                                                          \
-      _Pragma("unroll")                                                               \
-      for (int d = 0; d < 16; d += 4) {                                               \
-        p0 += W[d] * wv::bcast16_var(bid[KK], d); p1 += W[d + 1] * wv::bcast16_var(bid[KK], d + 1); \
-        p2 += W[d + 2] * wv::bcast16_var(bid[KK], d + 2); p3 += W[d + 3] * wv::bcast16_var(bid[KK], d + 3); \
-      }                                                                               \
-    } else {                                                                          \
-      const real* Bk = S + w.o_J + JW * wv::bcast16i<KK>(row);                        \
-      _Pragma("unroll")                                                               \
-      for (int d = 0; d < 16; d += 4) {                                               \
-        p0 += W[d] * Bk[d]; p1 += W[d + 1] * Bk[d + 1]; p2 += W[d + 2] * Bk[d + 2]; p3 += W[d + 3] * Bk[d + 3]; \
-      }                                                                               \
-      if (!wv::bcast16i<KK>(has_i)) { p0 = 0; p1 = 0; p2 = 0; p3 = 0; }               \
-    }                                                                                 \
-    real acc = (p0 + p1) + (p2 + p3);                                                 \
-    if (KK == k) acc += Ri;                                                           \
-    A[KK] = acc;                                                                      \
-  }
 #pragma unroll
-  for (int q = 0; q < 16; q++) A[q] = 0;
-  do { MJ_ROWS16(MJ_ASTEP) } while (0);
+    for (int q = 0; q < NP; q++) A[j][q] = 0;
+#define MJ_ASTEP(P)                                                                   \
+    if (P >= NP || P >= len) break;                                                   \
+    {                                                                                 \
+      constexpr int PP = P < NP ? P : 0, PJ = PP / 16;                                \
+      real p0 = 0, p1 = 0, p2 = 0, p3 = 0;                                            \
+      if ((anyc >> P) & 1u) {                                                         \
+        const real mine_p = bid(P);                                                   \
+        _Pragma("unroll")                                                             \
+        for (int d = 0; d < 16; d += 4) {                                             \
+          p0 += W[d] * wv::bcast16_var(mine_p, d); p1 += W[d + 1] * wv::bcast16_var(mine_p, d + 1); \
+          p2 += W[d + 2] * wv::bcast16_var(mine_p, d + 2); p3 += W[d + 3] * wv::bcast16_var(mine_p, d + 3); \
+        }                                                                             \
+      } else {                                                                        \
+        const real* Bk = S + w.o_J + JW * wv::bcast16i<(P & 15)>(row[PJ]);            \
+        _Pragma("unroll")                                                             \
+        for (int d = 0; d < 16; d += 4) {                                             \
+          p0 += W[d] * Bk[d]; p1 += W[d + 1] * Bk[d + 1]; p2 += W[d + 2] * Bk[d + 2]; p3 += W[d + 3] * Bk[d + 3]; \
+        }                                                                             \
+        if (!wv::bcast16i<(P & 15)>(has_i[PJ])) { p0 = 0; p1 = 0; p2 = 0; p3 = 0; }   \
+      }                                                                               \
+      real acc = (p0 + p1) + (p2 + p3);                                               \
+      if (k == (P & 15) && j == PJ) acc += Ri[j];                                     \
+      A[j][PP] = acc;                                                                 \
+    }
+    do { MJ_POS32(MJ_ASTEP) } while (0);
 #undef MJ_ASTEP
-  real r = bi;
-#define MJ_RINIT(KK) if (KK >= len) break; r += A[KK] * wv::bcast16<KK>(fi);
-  do { MJ_ROWS16(MJ_RINIT) } while (0);
-#undef MJ_RINIT
-  real sr = r * ainv;
-#pragma unroll
-  for (int q = 0; q < 16; q++) A[q] *= ainv;
-  const real haii = 0.5 * aii, scale = w.scale, tolerance = w.tolerance;
-  // the row's whole (scaled, negated) residual at a coupling position: this copy's part plus the other tree's
-#define MJ_WHOLE(KK, v)                                                               \
-  if ((anyc >> KK) & 1u) {                                                            \
-    const real other = wv::shfl(v, partner >= 0 ? partner + k : L);                   \
-    if (partner >= 0) v += other;                                                     \
   }
-  real f_start = fi, s_start = sr, f_prev = fi, s_prev = sr, c_prev = 0;
+  real sr[RP];
+#pragma unroll
+  for (int j = 0; j < RP; j++) sr[j] = bi[j];
+#define MJ_RINIT(P)                                                                   \
+  if (P >= NP || P >= len) break;                                                     \
+  {                                                                                   \
+    const real fk = wv::bcast16<(P & 15)>(fi[(P < NP ? P : 0) / 16]);                 \
+    _Pragma("unroll")                                                                 \
+    for (int j = 0; j < RP; j++) sr[j] += A[j][P < NP ? P : 0] * fk;                  \
+  }
+  do { MJ_POS32(MJ_RINIT) } while (0);
+#undef MJ_RINIT
+  // scaled residuals s = r / AR_kk and AR's rows scaled likewise (as in the 16-row solver)
+#pragma unroll
+  for (int j = 0; j < RP; j++) {
+    sr[j] *= ainv[j];
+#pragma unroll
+    for (int q = 0; q < NP; q++) A[j][q] *= ainv[j];
+  }
+  const real scale = w.scale, tolerance = w.tolerance;
+  // the row's whole (scaled, negated) residual at a coupling position: this copy's part plus the other tree's
+  // (through the LDS crossbar; reading every tree's lane into scalar registers and picking the partner's -- a dozen
+  // instructions, no LDS round trip -- measured no faster: 13.75 against 13.80 M env-steps/s on the 4-agent arena)
+  // (anyc_s, part_s: per-sweep copies of anyc and partner whose origin the optimiser cannot see -- it would hoist one
+  // 64-bit mask per position and per test out of the sweeps, and they do not fit the scalar registers)
+#define MJ_WHOLE(P, v)                                                                \
+  if ((anyc_s >> P) & 1u) {                                                           \
+    const int pl = part_s[(P < NP ? P : 0) / 16];                                     \
+    const real other = wv::shfl(v, pl >= 0 ? pl + k : L);                             \
+    if (pl >= 0) v += other;                                                          \
+  }
+  real f_start[RP], s_start[RP], f_prev[RP], s_prev[RP], c_prev[RP];
+#pragma unroll
+  for (int j = 0; j < RP; j++) { f_start[j] = fi[j]; s_start[j] = sr[j]; f_prev[j] = fi[j]; s_prev[j] = sr[j]; c_prev[j] = 0; }
   bool pending = false, guarded = false;
+  auto any_refused = [&]() {
+    bool b = c_prev[0] > 1e-10;
+    if constexpr (RP > 1) b = b || c_prev[RP - 1] > 1e-10;
+    return wv::ballot(b);
+  };
+  auto cost_sum = [&]() {
+    real c = -c_prev[0];
+    if constexpr (RP > 1) c -= c_prev[RP - 1];
+    return wv::rows_sum(wv::sum16(c), ntree);
+  };
   while (iter < iterations) {
     const int k_s = wv::opaque_lane(k), len_s = wv::opaque_uniform(len);
-    f_start = fi; s_start = sr;
-    real ns = -sr, nss = ns;
-    const real nf = -fi;
+    const unsigned anyc_s = (unsigned)wv::opaque_uniform((int)anyc);
+    int part_s[RP];
+#pragma unroll
+    for (int j = 0; j < RP; j++) part_s[j] = wv::opaque_lane(partner[j]);
+    real ns[RP], nss[RP], nf[RP];
+#pragma unroll
+    for (int j = 0; j < RP; j++) { f_start[j] = fi[j]; s_start[j] = sr[j]; ns[j] = -sr[j]; nss[j] = ns[j]; nf[j] = -fi[j]; }
     unsigned long long refused = 0ull, deciding = 1ull;
-    if (pending) { refused = wv::ballot(c_prev > 1e-10); deciding = wv::ballot((-c_prev - 1e-8) * scale >= tolerance); }
-#define MJ_FSTEP(KK)                                                                  \
+    if (pending) {
+      refused = any_refused();
+      bool dec = (-c_prev[0] - 1e-8) * scale >= tolerance;
+      if constexpr (RP > 1) dec = dec || (-c_prev[RP - 1] - 1e-8) * scale >= tolerance;
+      deciding = wv::ballot(dec);
+    }
+#define MJ_FSTEP(P)                                                                   \
     {                                                                                 \
-      real nsx = ns;                                                                  \
-      MJ_WHOLE(KK, nsx)                                                               \
-      real db = wv::bcast16<KK>(fmax(nsx, nf));                                       \
-      if (k_s == KK) nss = nsx;                                                       \
-      ns = __builtin_fma(-A[KK], db, ns);                                             \
+      constexpr int PP = P < NP ? P : 0, PJ = PP / 16;                                \
+      real nsx = ns[PJ];                                                              \
+      MJ_WHOLE(P, nsx)                                                                \
+      const real db = wv::bcast16<(P & 15)>(fmax(nsx, nf[PJ]));                       \
+      if (k_s == (P & 15)) nss[PJ] = nsx;                                             \
+      _Pragma("unroll")                                                               \
+      for (int j = 0; j < RP; j++) ns[j] = __builtin_fma(-A[j][PP], db, ns[j]);       \
     }
     MJ_FSTEP(0) MJ_FSTEP(1)
     if (pending && (refused != 0ull || deciding == 0ull)) {
-      const real improvement = wv::rows_sum(wv::sum16(-c_prev), ntree);
+      const real improvement = cost_sum();
       if (refused != 0ull || wv::ballot(improvement * scale < tolerance)) {
-        if (refused != 0ull) { fi = f_prev; sr = s_prev; iter--; guarded = true; }   // redo that sweep
-        else { sr = s_start; }                                                       // it had converged
+        if (refused != 0ull) {                                  // redo that sweep, guarded
+#pragma unroll
+          for (int j = 0; j < RP; j++) { fi[j] = f_prev[j]; sr[j] = s_prev[j]; }
+          iter--; guarded = true;
+        } else {                                                // it had converged
+#pragma unroll
+          for (int j = 0; j < RP; j++) sr[j] = s_start[j];
+        }
         pending = false;
         break;
       }
@@ -2097,57 +2052,97 @@ __device__ inline real pgs_schedule_residual(real* S, const int* I, int L, bool 
       MJ_FSTEP(8) MJ_FSTEP(9) MJ_FSTEP(10) MJ_FSTEP(11)
       if (12 >= len_s) break;
       MJ_FSTEP(12) MJ_FSTEP(13) MJ_FSTEP(14) MJ_FSTEP(15)
+      if (NP <= 16 || 16 >= len_s) break;
+      MJ_FSTEP(16) MJ_FSTEP(17) MJ_FSTEP(18) MJ_FSTEP(19)
+      if (20 >= len_s) break;
+      MJ_FSTEP(20) MJ_FSTEP(21) MJ_FSTEP(22) MJ_FSTEP(23)
+      if (24 >= len_s) break;
+      MJ_FSTEP(24) MJ_FSTEP(25) MJ_FSTEP(26) MJ_FSTEP(27)
+      if (28 >= len_s) break;
+      MJ_FSTEP(28) MJ_FSTEP(29) MJ_FSTEP(30) MJ_FSTEP(31)
     } while (0);
 #undef MJ_FSTEP
-    sr = -ns;
-    const real ss = -nss;
-    fi = fmax(f_start - ss, 0.0);
-    const real dsweep = fi - f_start;
-    c_prev = (dsweep * dsweep * haii + dsweep * (ss * aii)) * once;
-    f_prev = f_start; s_prev = s_start;
+#pragma unroll
+    for (int j = 0; j < RP; j++) {
+      sr[j] = -ns[j];
+      const real ss = -nss[j];
+      fi[j] = fmax(f_start[j] - ss, 0.0);
+      const real dsweep = fi[j] - f_start[j];
+      c_prev[j] = (dsweep * dsweep * haii[j] + dsweep * (ss * aii[j])) * once[j];
+      f_prev[j] = f_start[j]; s_prev[j] = s_start[j];
+    }
     pending = true;
     iter++;
   }
-  if (pending && wv::ballot(c_prev > 1e-10)) { fi = f_prev; sr = s_prev; iter--; guarded = true; }
+  if (pending && any_refused()) {       // the sweep cap was reached and the last sweep has a refused step
+#pragma unroll
+    for (int j = 0; j < RP; j++) { fi[j] = f_prev[j]; sr[j] = s_prev[j]; }
+    iter--; guarded = true;
+  }
   while (guarded && iter < iterations) {
     real imp = 0;
     const int k_g = wv::opaque_lane(k);
-#define MJ_GSTEP(KK)                                                                  \
-    if (KK < len) {                                                                   \
-      real srx = sr;                                                                  \
-      MJ_WHOLE(KK, srx)                                                               \
-      real fn = fmax(fi - srx, 0.0);                                                  \
-      real delta = fn - fi;                                                           \
-      real change = delta * delta * haii + delta * (srx * aii);                       \
-      bool act = k_g == KK && has && !(change > 1e-10);                               \
-      if (!act) { delta = 0; change = 0; fn = fi; }                                   \
-      fi = fn;                                                                        \
-      imp -= change * once;                                                           \
-      sr += A[KK] * wv::bcast16<KK>(delta);                                           \
+    const unsigned anyc_s = (unsigned)wv::opaque_uniform((int)anyc);
+    int part_s[RP];
+#pragma unroll
+    for (int j = 0; j < RP; j++) part_s[j] = wv::opaque_lane(partner[j]);
+#define MJ_GSTEP(P)                                                                   \
+    if (P < NP && P < len) {                                                          \
+      constexpr int PP = P < NP ? P : 0, PJ = PP / 16;                                \
+      real srx = sr[PJ];                                                              \
+      MJ_WHOLE(P, srx)                                                                \
+      real fn = fmax(fi[PJ] - srx, 0.0);                                              \
+      real delta = fn - fi[PJ];                                                       \
+      real change = delta * delta * haii[PJ] + delta * (srx * aii[PJ]);               \
+      const bool act = k_g == (P & 15) && has[PJ] && !(change > 1e-10);               \
+      if (!act) { delta = 0; change = 0; fn = fi[PJ]; }                               \
+      fi[PJ] = fn;                                                                    \
+      imp -= change * once[PJ];                                                       \
+      const real dk = wv::bcast16<(P & 15)>(delta);                                   \
+      _Pragma("unroll")                                                               \
+      for (int j = 0; j < RP; j++) sr[j] += A[j][PP] * dk;                            \
     }
-    MJ_ROWS16(MJ_GSTEP)
+    MJ_POS32(MJ_GSTEP)
 #undef MJ_GSTEP
     iter++;
     if (wv::rows_sum(wv::sum16(imp), ntree) * scale < tolerance) break;
   }
 #undef MJ_WHOLE
-  if (has && once != 0.0) Rm[ROW_F] = fi;
-  // u = B' f for the lane's dof
+#pragma unroll
+  for (int j = 0; j < RP; j++)
+    if (has[j] && once[j] != 0.0) Rm[j][ROW_F] = fi[j];
+  // u = B' f for the lane's dof (its coefficients fetched again: kept across the sweeps they would cost NP registers)
   real u = 0;
-#define MJ_USTEP(KK) if (KK >= len) break; u += bid[KK] * wv::bcast16<KK>(fi);
-  do { MJ_ROWS16(MJ_USTEP) } while (0);
+#define MJ_USTEP(P)                                                                   \
+  if (P >= NP || P >= len) break;                                                     \
+  {                                                                                   \
+    u += bid(P) * wv::bcast16<(P & 15)>(fi[(P < NP ? P : 0) / 16]);                   \
+  }
+  do { MJ_POS32(MJ_USTEP) } while (0);
 #undef MJ_USTEP
   iter_io = iter;
   return u;
 }
-#undef MJ_ROWS16
+#undef MJ_POS32
 
-__device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
+// The two-position form as the kernels call it: inlined into a model-specialised kernel (and the CPU emulation), a
+// function with a register allocation of its own in the generic GPU kernel, like pgs_tall_registers there.
 #if defined(MJRL_SPEC) || !defined(__HIPCC__)
-  return m.ntree > 2 && (size_t)l.total * sizeof(real) > 32 * 1024;
+#define MJRL_SCHED32_INLINE inline __attribute__((always_inline))
 #else
-  return false;
+#define MJRL_SCHED32_INLINE __attribute__((noinline))
 #endif
+__device__ MJRL_SCHED32_INLINE real pgs_schedule_residual32(real* S, const int* I, int L, bool dof, const SchedArgs& w, int ntree,
+                                                            int iter_in, int* iter_out) {
+  int it = iter_in;
+  const real u = pgs_schedule_residual<32>(S, I, L, dof, w, ntree, it);
+  *iter_out = it;
+  return u;
+}
+
+// a model whose LDS image holds a CU to one wave per SIMD anyway: the forms that need more than 256 registers are free
+__device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
+  return m.ntree > 2 && (size_t)l.total * sizeof(real) > 32 * 1024;
 }
 
 // projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f >= 0, with A = B D^-1 B' never formed: the lane that
@@ -2448,8 +2443,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     const int C = m.njmax / m.ntree;
     const Tab T = make_tab(m, l, S);
     // two positions per lane only where the LDS image already holds the CU to four copies (one wave per SIMD): the
-    // form needs more than 256 registers.  (Specialised builds and the CPU emulation; the generic GPU kernel keeps the
-    // LDS-resident sweep there -- the same arithmetic, so the two builds still agree to the bit.)
+    // form needs more than 256 registers
     const bool roomy = pgs_roomy(m, l);
     if (sched_len <= 16 || (roomy && sched_len <= 32)) {
       SchedArgs w;
@@ -2460,11 +2454,8 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       w.tolerance = m.tolerance; w.scale = scale; w.dinv = dinv; w.u = u;
       w.o_Dinv = l.Dinv; w.adr0 = mytree < m.ntree ? m.tree_dofadr[mytree] : 0;
       int it = iter;        // (a local of its own: the counter of the other solver paths never has its address taken)
-#ifdef MJRL_NO_SCHED_RESIDUAL      // (experiments: the u-form sweep for every schedule, as before)
-      u = sched_len <= 16 ? pgs_schedule_registers<16>(S, I, L, dof, w, it) : pgs_schedule_registers<32>(S, I, L, dof, w, it);
-#else
-      u = sched_len <= 16 ? pgs_schedule_residual(S, I, L, dof, w, m.ntree, it) : pgs_schedule_registers<32>(S, I, L, dof, w, it);
-#endif
+      if (sched_len <= 16) u = pgs_schedule_residual<16>(S, I, L, dof, w, m.ntree, it);
+      else u = pgs_schedule_residual32(S, I, L, dof, w, m.ntree, it, &it);
       iter = it;
       wv::sync();
     } else {
@@ -2904,8 +2895,10 @@ __device__ inline int lpt_copy_of(const StepArgs& a, int L, int wg, int my_count
 // stamps / timeline / dbg / stop_after) do not exist in it -- as run-time branches they cost the shipped kernel a stack
 // object (the clock), a hundred scalar registers' worth of spills and an exec-masked block per stage.  Launches that ask
 // for any of them go to the DIAG = true build (mjrl_step_kernel_diag; a specialised kernel built with -DMJRL_DIAG).
+// (inlined by force: past some size the inliner leaves it a function of its own, and the kernel then hands it the model
+// -- every size a constant of a specialised build -- as a 1.3 KB struct on the stack)
 template <bool DIAG>
-__device__ inline void env_step_t(const DevModel& m, const StepArgs& a_in, real* S) {
+__device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_in, real* S) {
   const StepArgs& a = a_in;
   const int L = wv::lane();
   int env = wv::env_index();

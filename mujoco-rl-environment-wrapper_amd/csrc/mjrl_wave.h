@@ -132,7 +132,13 @@ __device__ __forceinline__ double first(double v) {
 // values its per-step conditions derive from: hoisted out of the loop those conditions become one 64-bit lane mask
 // each, too many for the scalar registers, and come back through v_readlane at every use.
 __device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
-__device__ __forceinline__ int opaque_uniform(int v) { asm volatile("" : "+s"(v)); return v; }
+// (through a VECTOR register and back with v_readfirstlane: an "s" constraint on the asm operand makes the build fail --
+// "illegal VGPR to SGPR copy" -- whenever the register allocator, short of scalar registers in a kernel this size, has
+// chosen to keep the value in a vector register at that point; a copy into a vector register is always legal)
+__device__ __forceinline__ int opaque_uniform(int v) {
+  asm volatile("" : "+v"(v));
+  return __builtin_amdgcn_readfirstlane(v);
+}
 // The same (wave-uniform) pointer INTO CONSTANT MEMORY (the kernel's argument segment) as a value the optimiser has not
 // seen before: what is loaded through it is not merged with earlier loads through the original, so nothing fetched early
 // stays live in registers until here.  The result is re-typed as a constant-address-space pointer before it goes back
@@ -142,7 +148,9 @@ template <typename T>
 __device__ __forceinline__ const T* fresh(const T* p) {
   unsigned long long v = (unsigned long long)p;
   unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-  asm volatile("" : "+s"(lo), "+s"(hi));
+  asm volatile("" : "+v"(lo), "+v"(hi));       // (see opaque_uniform)
+  lo = (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+  hi = (unsigned)__builtin_amdgcn_readfirstlane((int)hi);
   return (const T*)(const T __attribute__((address_space(4)))*)(((unsigned long long)hi << 32) | lo);
 }
 
