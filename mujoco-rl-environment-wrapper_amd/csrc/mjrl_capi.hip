@@ -17,18 +17,33 @@ namespace {
 // The model descriptor (sizes + ~100 section pointers) is read through a pointer: passed by value it would sit in
 // SGPRs for the whole kernel and spill to VGPR lanes (2600 v_readlane/v_writelane in the ISA); behind a const
 // __restrict__ pointer every field is a scalar load at its point of use.
-__global__ __launch_bounds__(64) void mjrl_step_kernel(const DevModel* __restrict__ mp, mj::StepArgs a) {
+// Two kinds (stage_pgs, BIG): mjrl_step_kernel without the solver forms that need more than 256 registers and held to 256
+// itself (with every size a run-time value the body wants 336: capped, it spills a hundred registers to scratch and
+// still runs the 2-agent level at 18.7 M env-steps/s against 13.4 at one wave per SIMD); mjrl_step_kernel_big with those
+// forms and no cap, for models whose LDS image allows one wave per SIMD anyway (mj::pgs_roomy).
+#define MJRL_TWO_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) MJRL_TWO_WAVES void mjrl_step_kernel(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
-  mj::env_step_t<false>(*mp, *mj::kernarg_step_args(8), lds);      // (the arguments where the packet left them: mjrl_step.h)
+  mj::env_step_t<false, false>(*mp, *mj::kernarg_step_args(8), lds);      // (the arguments where the packet left them: mjrl_step.h)
+}
+__global__ __launch_bounds__(64) void mjrl_step_kernel_big(const DevModel* __restrict__ mp, mj::StepArgs a) {
+  extern __shared__ double lds[];
+  mj::env_step_t<false, true>(*mp, *mj::kernarg_step_args(8), lds);
 }
 // The same step with the diagnostics compiled in (stage clock, wave timeline, LDS dump, stage cuts): the launches of
 // mjrl_step_debug / _profile / _timeline / _truncated and the LDS read-back of mjrl_query.  Same arithmetic, same bits.
-__global__ __launch_bounds__(64) void mjrl_step_kernel_diag(const DevModel* __restrict__ mp, mj::StepArgs a) {
+__global__ __launch_bounds__(64) MJRL_TWO_WAVES void mjrl_step_kernel_diag(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
   // (the diagnostic build checks what the production build assumes: the arguments sit 8 bytes into the kernarg segment)
   const mj::StepArgs* k = mj::kernarg_step_args(8);
   if (k->qpos != a.qpos || k->n_env != a.n_env || k->lpt_words != a.lpt_words) __builtin_trap();
-  mj::env_step_t<true>(*mp, *k, lds);
+  mj::env_step_t<true, false>(*mp, *k, lds);
+}
+__global__ __launch_bounds__(64) void mjrl_step_kernel_big_diag(const DevModel* __restrict__ mp, mj::StepArgs a) {
+  extern __shared__ double lds[];
+  const mj::StepArgs* k = mj::kernarg_step_args(8);
+  if (k->qpos != a.qpos || k->n_env != a.n_env || k->lpt_words != a.lpt_words) __builtin_trap();
+  mj::env_step_t<true, true>(*mp, *k, lds);
 }
 
 // Masked reset of the HBM state: mj_resetData + mj_forward (mujoco_parent.py:349-350) for the selected copies.  Every
@@ -360,6 +375,7 @@ struct mjrl_env {
   hipModule_t spec_module = nullptr;     // model-specialised step kernel, if one was attached (mjrl_load_kernel)
   hipFunction_t spec_fn = nullptr;
   bool spec_diag = false;                // that code object was built with the diagnostics (-DMJRL_DIAG)
+  bool big = false;                      // the generic kernels of the roomy kind serve this model (mj::pgs_roomy)
   void* d_blob = nullptr;
   DevModel* d_model = nullptr;     // device copy of `dm`
   int n_env = 0, device = 0;
@@ -554,8 +570,11 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     CK(hipMalloc(&e->lpt_mask[g], sizeof(unsigned) * mj::LPT_BUCKETS * (size_t)e->lpt_words));
     CK(hipMemset(e->lpt_mask[g], 0, sizeof(unsigned) * mj::LPT_BUCKETS * (size_t)e->lpt_words));
   }
+  e->big = mj::pgs_roomy(e->hm, e->lay);
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_camera_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
 #undef CK
   // the reset image: reset every copy (zero warm start, as mj_resetData leaves it), run mj_forward once, keep copy 0's
@@ -984,7 +1003,7 @@ int mjrl_size(const mjrl_env* e, const char* name) {
   if (!strcmp(name, "n_env")) return e->n_env;
   if (!strcmp(name, "blocks_per_cu")) {      // what the runtime says about residency of the step kernel
     int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)mjrl_step_kernel, 64,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, e->big ? (const void*)mjrl_step_kernel_big : (const void*)mjrl_step_kernel, 64,
                                                      (size_t)e->lay.total * sizeof(double)) != hipSuccess) return -1;
     return n;
   }
@@ -1108,10 +1127,12 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
       void* params[] = {(void*)&image, (void*)&a};
       MJRL_HIP(e, hipModuleLaunchKernel(e->spec_fn, e->n_env, 1, 1, 64, 1, 1, (unsigned)lds_bytes, e->stream, params, nullptr));
     } else if (diag) {
-      hipLaunchKernelGGL(mjrl_step_kernel_diag, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
+      if (e->big) hipLaunchKernelGGL(mjrl_step_kernel_big_diag, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
+      else hipLaunchKernelGGL(mjrl_step_kernel_diag, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
       MJRL_HIP(e, hipGetLastError());
     } else {
-      hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
+      if (e->big) hipLaunchKernelGGL(mjrl_step_kernel_big, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
+      else hipLaunchKernelGGL(mjrl_step_kernel, dim3(e->n_env), dim3(64), lds_bytes, e->stream, e->d_model, a);
       MJRL_HIP(e, hipGetLastError());
     }
   }

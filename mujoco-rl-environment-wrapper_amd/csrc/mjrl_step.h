@@ -2141,7 +2141,7 @@ __device__ MJRL_SCHED32_INLINE real pgs_schedule_residual32(real* S, const int* 
 }
 
 // a model whose LDS image holds a CU to one wave per SIMD anyway: the forms that need more than 256 registers are free
-__device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
+__host__ __device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
   return m.ntree > 2 && (size_t)l.total * sizeof(real) > 32 * 1024;
 }
 
@@ -2150,9 +2150,15 @@ __device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay& l) {
 // multiply-add.  In the tree-row lane map a constraint row that touches one kinematic tree only involves that tree's
 // row of 16 lanes, so the trees sweep their own rows side by side (rows of different trees commute, the order inside
 // a tree is the solver's row order); a step with a row that couples two trees falls back to the serial sweep.
-template <bool DIAG>
+// (BIG: the build holds the solver forms that need more than 256 registers -- pgs_tall_registers, the two-position
+// pgs_schedule_residual -- for models whose LDS image holds a CU to one wave per SIMD anyway, pgs_roomy.  A specialised
+// kernel is built with BIG and sheds them as dead code when its model is not roomy; the generic kernels come in both
+// kinds (mjrl_capi.hip), because a callee's registers count for the whole kernel: one generic kernel with the big forms
+// ran EVERY model at one wave per SIMD, the 2-agent level at 13.4 M env-steps/s instead of 21.)
+template <bool DIAG, bool BIG>
 __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L,
                                  Stamps* stamps) {
+  const bool roomy = BIG && pgs_roomy(m, l);
 #define MJ_SUBSTAMP(k)                                                     \
   if constexpr (DIAG) if (stamps) {                                        \
     unsigned long long t_now = wv::clock();                                \
@@ -2209,7 +2215,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
 #ifdef MJRL_NO_TALL       // (experiments: the schedule sweep for these copies, as before round 3)
   const bool tall = false;
 #else
-  const bool tall = m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree > 2 && m.ntree <= 4;     // pgs_tall_registers
+  const bool tall = roomy && m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree <= 4;     // pgs_tall_registers
 #endif
   const bool in_registers = (m.rowmap && !cross && tmax <= 16) || wide || tall;
   // what a sweep of this copy costs relative to one of the 16-row register solver (for the longest-first dispatch: rows x
@@ -2429,7 +2435,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     } while (0);
 #undef MJ_USTEP
     wv::sync();
-  } else if (m.rowmap && (cross || (pgs_roomy(m, l) && tmax > 16 && tmax <= 32)) &&
+  } else if (m.rowmap && (cross || (roomy && tmax > 16 && tmax <= 32)) &&
              pgs_coupled_schedule(m, l, S, L, nefc, sched_len)) {
     // (also a copy without coupling rows but with 17..32 rows in a tree of a model with more than two trees, where the
     // two-positions-per-lane form below is available: its plain per-tree lists are a schedule too)
@@ -2444,7 +2450,6 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
     const Tab T = make_tab(m, l, S);
     // two positions per lane only where the LDS image already holds the CU to four copies (one wave per SIMD): the
     // form needs more than 256 registers
-    const bool roomy = pgs_roomy(m, l);
     if (sched_len <= 16 || (roomy && sched_len <= 32)) {
       SchedArgs w;
       w.o_rowid = l.i_rowid; w.o_rowinfo = l.i_rowinfo; w.o_row = l.row; w.o_J = l.J; w.o_tab = l.tab;
@@ -2454,7 +2459,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
       w.tolerance = m.tolerance; w.scale = scale; w.dinv = dinv; w.u = u;
       w.o_Dinv = l.Dinv; w.adr0 = mytree < m.ntree ? m.tree_dofadr[mytree] : 0;
       int it = iter;        // (a local of its own: the counter of the other solver paths never has its address taken)
-      if (sched_len <= 16) u = pgs_schedule_residual<16>(S, I, L, dof, w, m.ntree, it);
+      if (!BIG || sched_len <= 16) u = pgs_schedule_residual<16>(S, I, L, dof, w, m.ntree, it);
       else u = pgs_schedule_residual32(S, I, L, dof, w, m.ntree, it, &it);
       iter = it;
       wv::sync();
@@ -2897,7 +2902,7 @@ __device__ inline int lpt_copy_of(const StepArgs& a, int L, int wg, int my_count
 // for any of them go to the DIAG = true build (mjrl_step_kernel_diag; a specialised kernel built with -DMJRL_DIAG).
 // (inlined by force: past some size the inliner leaves it a function of its own, and the kernel then hands it the model
 // -- every size a constant of a specialised build -- as a 1.3 KB struct on the stack)
-template <bool DIAG>
+template <bool DIAG, bool BIG = true>
 __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_in, real* S) {
   const StepArgs& a = a_in;
   const int L = wv::lane();
@@ -3087,7 +3092,7 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
     if constexpr (DIAG)
       if (raw_rows) MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     RK.dof = wv::opaque_lane(RK.dof);
-    stage_pgs<DIAG>(m, l, K, RK, S, MJ_L, stamps);
+    stage_pgs<DIAG, BIG>(m, l, K, RK, S, MJ_L, stamps);
     MJ_STAMP(ST_PGS)
     load_euler_constants(m, a, MJ_L, EK);
     // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)
