@@ -1915,9 +1915,14 @@ __device__ inline __attribute__((always_inline)) real pgs_schedule_residual(real
 #pragma unroll
     for (int d = 0; d < 16; d++)
       W[d] = (has[j] && partner[j] < 0) ? S[w.o_J + JW * row[j] + d] * S[w.o_Dinv + w.adr0 + d] : 0.0;
+    // (every chain of per-position tests works on its own copies of `len` and `anyc`, their origin hidden: shared, the
+    // compiler forms all 2 NP tests once, ahead of the first chain, and keeps them -- in spilled scalar registers.  Not
+    // in the two-position form: it has no vector register to spare for the detour, and spills to scratch.)
+    const int len_w = NP == 16 ? wv::opaque_uniform(len) : len;
+    const unsigned anyc_w = NP == 16 ? (unsigned)wv::opaque_uniform((int)anyc) : anyc;
 #define MJ_WSTEP(P)                                                                   \
-    if (P >= NP || P >= len) break;                                                   \
-    if (((anyc >> P) & 1u) && (P < NP ? P : 0) / 16 == j) {                           \
+    if (P >= NP || P >= len_w) break;                                                 \
+    if (((anyc_w >> P) & 1u) && (P < NP ? P : 0) / 16 == j) {                           \
       const real mine_p = bid(P);                                                     \
       _Pragma("unroll")                                                               \
       for (int d = 0; d < 16; d++) {                                                  \
@@ -1929,12 +1934,14 @@ __device__ inline __attribute__((always_inline)) real pgs_schedule_residual(real
 #undef MJ_WSTEP
 #pragma unroll
     for (int q = 0; q < NP; q++) A[j][q] = 0;
+    const int len_a = NP == 16 ? wv::opaque_uniform(len) : len;
+    const unsigned anyc_a = NP == 16 ? (unsigned)wv::opaque_uniform((int)anyc) : anyc;
 #define MJ_ASTEP(P)                                                                   \
-    if (P >= NP || P >= len) break;                                                   \
+    if (P >= NP || P >= len_a) break;                                                 \
     {                                                                                 \
       constexpr int PP = P < NP ? P : 0, PJ = PP / 16;                                \
       real p0 = 0, p1 = 0, p2 = 0, p3 = 0;                                            \
-      if ((anyc >> P) & 1u) {                                                         \
+      if ((anyc_a >> P) & 1u) {                                                         \
         const real mine_p = bid(P);                                                   \
         _Pragma("unroll")                                                             \
         for (int d = 0; d < 16; d += 4) {                                             \
@@ -1959,8 +1966,9 @@ __device__ inline __attribute__((always_inline)) real pgs_schedule_residual(real
   real sr[RP];
 #pragma unroll
   for (int j = 0; j < RP; j++) sr[j] = bi[j];
+  const int len_r = NP == 16 ? wv::opaque_uniform(len) : len;
 #define MJ_RINIT(P)                                                                   \
-  if (P >= NP || P >= len) break;                                                     \
+  if (P >= NP || P >= len_r) break;                                                   \
   {                                                                                   \
     const real fk = wv::bcast16<(P & 15)>(fi[(P < NP ? P : 0) / 16]);                 \
     _Pragma("unroll")                                                                 \
@@ -2086,8 +2094,10 @@ __device__ inline __attribute__((always_inline)) real pgs_schedule_residual(real
     int part_s[RP];
 #pragma unroll
     for (int j = 0; j < RP; j++) part_s[j] = wv::opaque_lane(partner[j]);
+    const int len_g = wv::opaque_uniform(len);
 #define MJ_GSTEP(P)                                                                   \
-    if (P < NP && P < len) {                                                          \
+    if (P >= NP || P >= len_g) break;                                                 \
+    {                                                                                 \
       constexpr int PP = P < NP ? P : 0, PJ = PP / 16;                                \
       real srx = sr[PJ];                                                              \
       MJ_WHOLE(P, srx)                                                                \
@@ -2102,7 +2112,7 @@ __device__ inline __attribute__((always_inline)) real pgs_schedule_residual(real
       _Pragma("unroll")                                                               \
       for (int j = 0; j < RP; j++) sr[j] += A[j][PP] * dk;                            \
     }
-    MJ_POS32(MJ_GSTEP)
+    do { MJ_POS32(MJ_GSTEP) } while (0);
 #undef MJ_GSTEP
     iter++;
     if (wv::rows_sum(wv::sum16(imp), ntree) * scale < tolerance) break;
@@ -2113,8 +2123,9 @@ __device__ inline __attribute__((always_inline)) real pgs_schedule_residual(real
     if (has[j] && once[j] != 0.0) Rm[j][ROW_F] = fi[j];
   // u = B' f for the lane's dof (its coefficients fetched again: kept across the sweeps they would cost NP registers)
   real u = 0;
+  const int len_u = NP == 16 ? wv::opaque_uniform(len) : len;
 #define MJ_USTEP(P)                                                                   \
-  if (P >= NP || P >= len) break;                                                     \
+  if (P >= NP || P >= len_u) break;                                                   \
   {                                                                                   \
     u += bid(P) * wv::bcast16<(P & 15)>(fi[(P < NP ? P : 0) / 16]);                   \
   }
