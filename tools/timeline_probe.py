@@ -55,7 +55,7 @@ for rep in range(3):
     print("                            duration " + " ".join(f"{dur[order[i * k:(i + 1) * k]].mean():6.1f}" for i in range(8)))
     last = np.argsort(end)[-5:]
     two_tree = ((trees == -2) & valid).sum(1)
-    print(f"  copies with rows that couple two trees (serial sweep): {(two_tree > 0).sum()}, their wave duration mean "
+    print(f"  copies with rows that couple two trees (schedule solver): {(two_tree > 0).sum()}, their wave duration mean "
           f"{dur[np.isin(env, np.nonzero(two_tree > 0)[0])].mean() if (two_tree > 0).any() else 0:.1f} us; copies with 17+ rows in a tree: {(per_tree > 16).sum()}")
     print("  last five waves: " + "; ".join(f"wg {w} start {start[w]:.1f} dur {dur[w]:.1f} rows/tree {per_tree[env[w]]} sweeps {niter[env[w]]}" for w in last))
     wide = per_tree[env] > 16
