@@ -89,7 +89,10 @@ int mjrl_set_env_base(mjrl_env* env, int first_env_id);
 int mjrl_set_variants(mjrl_env* env, int n_variant, const double* rgba, unsigned long long seed);
 
 /* Sizes a caller needs to allocate buffers: "nq","nv","nu","nbody","ngeom","nsensordata","obs_dim",
- * "n_agent","n_env","lds_doubles","ncon_stride", ...; -1 for an unknown name. */
+ * "n_agent","n_env","lds_doubles","ncon_stride", ...; "few": 1 when the batch leaves every SIMD of the device at most one
+ * wave (n_env <= 4 x the CUs) -- the step kernel then uses solver forms that need the whole register file, and a
+ * model-specialised kernel for such a handle is built with -DMJRL_FEW=1 (kernel_cache.code_object(blob, few=True)); -1 for
+ * an unknown name. */
 int mjrl_size(const mjrl_env* env, const char* name);
 
 /* Reset copies: qpos0 / zero velocity / zero ctrl / timestep 0 / empty data store, followed by mj_forward.

@@ -115,7 +115,7 @@ class Handle:
             specialize = os.environ.get("MJRL_SPECIALIZE", "1") != "0"
         if specialize:
             from . import kernel_cache
-            path = kernel_cache.code_object(blob)
+            path = kernel_cache.code_object(blob, few=bool(self.size("few")))
             if path is not None:
                 self.load_kernel(path)
 

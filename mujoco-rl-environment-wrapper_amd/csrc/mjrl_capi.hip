@@ -375,7 +375,8 @@ struct mjrl_env {
   hipModule_t spec_module = nullptr;     // model-specialised step kernel, if one was attached (mjrl_load_kernel)
   hipFunction_t spec_fn = nullptr;
   bool spec_diag = false;                // that code object was built with the diagnostics (-DMJRL_DIAG)
-  bool big = false;                      // the generic kernels of the roomy kind serve this model (mj::pgs_roomy)
+  bool big = false;                      // the generic kernels of the roomy kind serve this batch (mj::pgs_roomy, or few)
+  bool few = false;                      // the batch leaves every SIMD at most one wave (StepArgs::few)
   void* d_blob = nullptr;
   DevModel* d_model = nullptr;     // device copy of `dm`
   int n_env = 0, device = 0;
@@ -570,7 +571,13 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     CK(hipMalloc(&e->lpt_mask[g], sizeof(unsigned) * mj::LPT_BUCKETS * (size_t)e->lpt_words));
     CK(hipMemset(e->lpt_mask[g], 0, sizeof(unsigned) * mj::LPT_BUCKETS * (size_t)e->lpt_words));
   }
-  e->big = mj::pgs_roomy(e->hm, e->lay);
+  {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, device_id));
+    e->few = n_env <= 4 * prop.multiProcessorCount;
+    if (const char* f = getenv("MJRL_FEW")) e->few = atoi(f) != 0;      // (tests: either kind of solver forms at any batch size)
+  }
+  e->big = e->few || mj::pgs_roomy(e->hm, e->lay);
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1001,6 +1008,9 @@ int mjrl_size(const mjrl_env* e, const char* name) {
   if (!strcmp(name, "obs_dim")) return e->obs_dim;
   if (!strcmp(name, "n_agent")) return e->n_agent;
   if (!strcmp(name, "n_env")) return e->n_env;
+  // which specialised build fits the batch (kernel_cache.code_object): the one for few copies only where it differs --
+  // a roomy model's kernel holds the big solver forms at any batch size
+  if (!strcmp(name, "few")) return (e->few && !mj::pgs_roomy(e->hm, e->lay)) ? 1 : 0;
   if (!strcmp(name, "blocks_per_cu")) {      // what the runtime says about residency of the step kernel
     int n = -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, e->big ? (const void*)mjrl_step_kernel_big : (const void*)mjrl_step_kernel, 64,
@@ -1080,6 +1090,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.reset_warm = e->reset_warm;
   a.reset_sens = e->reset_sens;
   a.reset_scene = e->reset_scene;
+  a.few = e->few ? 1 : 0;
   a.auto_mask = forward_only ? nullptr : e->auto_mask;
   a.auto_mode = e->auto_mode;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;

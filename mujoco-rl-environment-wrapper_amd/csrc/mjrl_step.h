@@ -196,6 +196,10 @@ struct StepArgs {
   // qpos.  reset_scene [scene_doubles] is the row of the reset image, for copies that are reset without a physics frame.
   real* scene;
   const real* reset_scene;
+  // The batch leaves every SIMD at most one wave (n_env <= 4 x the CUs, mjrl_create): the solver forms that need more
+  // than 256 registers cost no residency then (stage_pgs: `few`).  Read by the generic kernels; a specialised kernel
+  // is built for one case or the other (-DMJRL_FEW=1, kernel_cache.code_object(..., few=True)).
+  int few;
   // Longest-first dispatch: a copy's solver work (rows x sweeps) in the previous step predicts this step's, and
   // workgroups are dispatched in index order, so handing the heavy copies to the lowest workgroup ids keeps a straggler
   // from starting last.  Each wave files its copy under a work bucket for the next launch -- one count and one bit set
@@ -2166,10 +2170,23 @@ __host__ __device__ __forceinline__ bool pgs_roomy(const DevModel& m, const Lay&
 // kernel is built with BIG and sheds them as dead code when its model is not roomy; the generic kernels come in both
 // kinds (mjrl_capi.hip), because a callee's registers count for the whole kernel: one generic kernel with the big forms
 // ran EVERY model at one wave per SIMD, the 2-agent level at 13.4 M env-steps/s instead of 21.)
+// `few` (StepArgs::few): a batch of at most one wave per SIMD is roomy whatever its model -- a launch of 1024 copies of
+// the 2-agent level lasted 130-140 us because of ONE copy on the 32-lane solver (21 rows in a tree, 90-100 sweeps: 1 us
+// per sweep) while every other wave was done after 80; with two rows per lane (pgs_tall_registers) that copy takes 95.
 template <bool DIAG, bool BIG>
 __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K, const RowK& RK, real* S, int L,
-                                 Stamps* stamps) {
-  const bool roomy = BIG && pgs_roomy(m, l);
+                                 Stamps* stamps, bool few_arg) {
+#if defined(MJRL_SPEC)
+#ifdef MJRL_FEW
+  constexpr bool few = true;
+#else
+  constexpr bool few = false;
+#endif
+  (void)few_arg;
+#else
+  const bool few = few_arg;
+#endif
+  const bool roomy = BIG && (few || pgs_roomy(m, l));
 #define MJ_SUBSTAMP(k)                                                     \
   if constexpr (DIAG) if (stamps) {                                        \
     unsigned long long t_now = wv::clock();                                \
@@ -2222,7 +2239,7 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
   tmax = wv::first_int(tmax);       // uniform by construction (ballot counts)
   wv::sync();
   MJ_SUBSTAMP(ST_PGS_LISTS)
-  const bool wide = m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree <= 2;
+  const bool wide = !roomy && m.rowmap && !cross && tmax > 16 && tmax <= 32 && m.ntree <= 2;
 #ifdef MJRL_NO_TALL       // (experiments: the schedule sweep for these copies, as before round 3)
   const bool tall = false;
 #else
@@ -3103,7 +3120,7 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
     if constexpr (DIAG)
       if (raw_rows) MJ_FOR(i, l.total) a.dbg[(size_t)env * l.total + i] = S[i];
     RK.dof = wv::opaque_lane(RK.dof);
-    stage_pgs<DIAG, BIG>(m, l, K, RK, S, MJ_L, stamps);
+    stage_pgs<DIAG, BIG>(m, l, K, RK, S, MJ_L, stamps, a.few != 0);
     MJ_STAMP(ST_PGS)
     load_euler_constants(m, a, MJ_L, EK);
     // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)

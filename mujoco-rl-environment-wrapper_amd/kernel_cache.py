@@ -45,18 +45,22 @@ def _source_digest() -> str:
     return h.hexdigest()[:12]
 
 
-def _flags_digest() -> str:
-    """Builds with other flags (the diagnostic build, ``MJRL_SPEC_FLAGS=-DMJRL_DIAG``) are cached side by side."""
-    return hashlib.sha1(" ".join(FLAGS).encode()).hexdigest()[:6]
+def _flags_digest(extra=()) -> str:
+    """Builds with other flags (the diagnostic build, ``MJRL_SPEC_FLAGS=-DMJRL_DIAG``; the few-copies build) are cached
+    side by side."""
+    return hashlib.sha1(" ".join([*FLAGS, *extra]).encode()).hexdigest()[:6]
 
 
 def spec_header(sizes: dict) -> str:
     return "".join(f"#define MJRL_SPEC_{k} {int(sizes[k])}\n" for k in _blob.SIZE_FIELDS)
 
 
-def object_path(sizes: dict) -> str:
+FEW_FLAGS = ("-DMJRL_FEW=1",)       # the build for batches of at most one wave per SIMD (csrc/mjrl_step.h stage_pgs)
+
+
+def object_path(sizes: dict, few: bool = False) -> str:
     key = hashlib.sha1(spec_header(sizes).encode()).hexdigest()[:16]
-    return os.path.join(CACHE, f"step_{key}{_flags_digest()}_{_source_digest()}.hsaco")
+    return os.path.join(CACHE, f"step_{key}{_flags_digest(FEW_FLAGS if few else ())}_{_source_digest()}.hsaco")
 
 
 def hipcc() -> str | None:
@@ -66,12 +70,14 @@ def hipcc() -> str | None:
     return None
 
 
-def code_object(blob: bytes, build: bool = True) -> str | None:
-    """Path of the code object for this blob's shape; built on a cache miss when hipcc is present, else None."""
+def code_object(blob: bytes, build: bool = True, few: bool = False) -> str | None:
+    """Path of the code object for this blob's shape; built on a cache miss when hipcc is present, else None.
+    ``few``: the build for a batch that leaves every SIMD at most one wave (``mjrl_size(h, "few")``): its solver forms may
+    use the whole register file."""
     sizes = blob_sizes(blob)
     if os.environ.get("MJRL_SPEC_OBJECT"):       # experiments only: A/B a saved code object of the same model shape
         return os.environ["MJRL_SPEC_OBJECT"]
-    path = object_path(sizes)
+    path = object_path(sizes, few)
     if os.path.exists(path):
         return path
     cc = hipcc()
@@ -87,7 +93,7 @@ def code_object(blob: bytes, build: bool = True) -> str | None:
         with open(hdr, "w") as f:
             f.write(spec_header(sizes))
         out = os.path.join(tmp, "step.hsaco")
-        cmd = [cc, "--genco", *FLAGS, f'-DMJRL_SPEC_HEADER="{hdr}"', "-I", CSRC,
+        cmd = [cc, "--genco", *FLAGS, *(FEW_FLAGS if few else ()), f'-DMJRL_SPEC_HEADER="{hdr}"', "-I", CSRC,
                os.path.join(CSRC, "mjrl_spec_kernel.hip"), "-o", out]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:

@@ -11,6 +11,11 @@ import __graft_entry__ as entry  # noqa: E402
 
 entry.load_package()
 
+# A handle for a batch that leaves every SIMD at most one wave picks the step kernel's build with the big solver forms
+# (mjrl_size "few").  The tests' batches are all that small, and most of them are there for the build the headline runs:
+# they get it unless a test asks for the other kind (monkeypatch.setenv("MJRL_FEW", "1")).
+os.environ.setdefault("MJRL_FEW", "0")
+
 LEVELS = os.path.join(ROOT, "tests", "levels")
 
 

@@ -434,11 +434,16 @@ def test_general_paths_and_two_chain_rows_on_the_gpu():
     assert rel(h.get_field("qvel"), np.stack([o.qvel for o in oras])) < 1e-8
 
 
-def test_wide_register_solver_on_the_gpu():
+@pytest.mark.parametrize("few", ["0", "1"])
+def test_wide_register_solver_on_the_gpu(few, monkeypatch):
     """17..32 constraint rows in one kinematic tree (an ant on its four feet with joints at their limits) take the
-    32-rows-per-tree register solver (pgs_wide_registers, a real function call inside the kernel)."""
+    32-rows-per-tree register solver (pgs_wide_registers) in the build for full batches and the two-rows-per-lane one
+    (pgs_tall_registers) in the build for batches of at most one wave per SIMD (mjrl_size "few"; MJRL_FEW picks the kind
+    whatever the batch size)."""
     from tests.test_emu_parity import _pose_with_many_rows_in_one_tree
+    monkeypatch.setenv("MJRL_FEW", few)
     model, packed, h = make("two_agent.xml", 3)
+    assert h.size("few") == int(few)
     q = _pose_with_many_rows_in_one_tree(model, packed)
     assert q is not None
     start = np.tile(q, (3, 1))

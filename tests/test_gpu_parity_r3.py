@@ -468,3 +468,44 @@ def test_render_draws_the_frames_of_the_last_forward_pass():
     fresh.close(); h.close()
     for o in oras:
         o.close()
+
+
+# --------------------------------------------------------------------------- the two specialised builds of a model
+@pytest.mark.parametrize("few", ["0", "1"])
+def test_agent_dropped_onto_agent_in_both_builds(few, monkeypatch):
+    """Rows that couple the two agents' trees (one ant dropped onto the other) through the residual-form schedule solver,
+    in the build for full batches and in the build for batches of at most one wave per SIMD (mjrl_size "few": schedules
+    of 17..32 positions then take the two-position form, 17+ rows in a tree the two-rows-per-lane solver): the oracle's
+    contact, row and sweep counts every step, its trajectory at the end."""
+    monkeypatch.setenv("MJRL_FEW", few)
+    model = mjcf.compile_mjcf(levels.level_path("two_agent.xml"))
+    packed = blob.pack(model)
+    h = _capi.Handle(packed, 2)
+    assert h.size("few") == int(few)
+    free = [j for j in range(model.njnt) if model.jnt_type[j] == 0]
+    a0, a1 = (int(model.jnt_qposadr[j]) for j in free)
+    q = model.qpos0.copy()
+    q[a1:a1 + 3] = q[a0:a0 + 3] + np.array([0.15, 0.1, 0.55])
+    h.reset()
+    h.set_field("qpos", np.tile(q, (2, 1)))
+    oras = [OracleEnv(packed) for _ in range(2)]
+    for o in oras:
+        o.qpos[:] = q
+    rng = np.random.default_rng(8)
+    coupled = longest = 0
+    for k in range(120):
+        ctrl = rng.uniform(-1, 1, (2, model.nu))
+        h.set_field("ctrl", ctrl)
+        h.step_device(None, 0, 1)
+        stats = h.get_field("solver_stats")
+        for e, o in enumerate(oras):
+            o.ctrl[:] = ctrl[e]
+            o.step()
+            assert (stats[e, 0], stats[e, 1], stats[e, 2]) == (o.ncon, o.nefc, o.niter), (few, k, e)
+        coupled += oras[0].ncon > 0
+        longest = max(longest, oras[0].nefc)
+    assert coupled > 20 and longest > 20
+    assert np.allclose(h.get_field("qpos"), np.stack([o.qpos for o in oras]), rtol=0, atol=1e-9)
+    h.close()
+    for o in oras:
+        o.close()
