@@ -578,6 +578,9 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
     if (const char* f = getenv("MJRL_FEW")) e->few = atoi(f) != 0;      // (tests: either kind of solver forms at any batch size)
   }
   e->big = e->few || mj::pgs_roomy(e->hm, e->lay);
+  // (a batch whose waves are all resident at once has no dispatch order to improve: its copies are stepped by workgroup
+  // id, without the look-up of the longest-first tables in every wave's prologue and without the filing at its end)
+  if (e->few) e->lpt_enabled = false;
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CK(hipFuncSetAttribute((const void*)mjrl_step_kernel_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
