@@ -188,10 +188,151 @@ class _Defaults:
         return merged
 
 
+# ----------------------------------------------------------------------------- the subset, stated
+class UnsupportedMJCF(ValueError):
+    """The level uses an MJCF feature this compiler does not implement.  ``mujoco.MjModel.from_xml_path``
+    (mujoco_parent.py:126) would simulate it; simulating it WITHOUT the feature would be a silently different level,
+    so it is refused with the element / attribute named."""
+
+
+_ORIENT = {"quat", "euler", "axisangle", "xyaxes", "zaxis"}
+# top-level sections: compiled, or read by nothing in the simulation (custom: user data; size: allocation hints,
+# the caps are config keys here; visual / statistic: rendering scale only)
+_SECTIONS = {"compiler", "option", "size", "default", "asset", "visual", "statistic", "worldbody", "actuator", "sensor",
+             "custom"}
+# attribute -> accepted values (None: any value is implemented)
+_COMPILER_ATTRS = {"angle": {"degree", "radian"}, "coordinate": {"local"}, "inertiafromgeom": {"true", "auto"},
+                   "eulerseq": None, "meshdir": None, "texturedir": None, "assetdir": None, "strippath": None,
+                   "autolimits": {"false"}, "fusestatic": {"false"}, "discardvisual": {"false"},
+                   "balanceinertia": {"false"}, "usethread": None}
+_OPTION_ATTRS = {"timestep": None, "gravity": None, "integrator": {"Euler", "RK4"}, "iterations": None,
+                 "tolerance": None, "impratio": None, "solver": {"PGS"}, "cone": {"pyramidal"},
+                 "jacobian": {"dense", "sparse", "auto"}, "collision": {"all"}, "noslip_iterations": {"0"},
+                 "mpr_iterations": None, "mpr_tolerance": None, "magnetic": None}
+# option attributes that are accepted only at the value that switches the feature off
+_OPTION_ZERO = {"wind", "density", "viscosity", "o_margin"}
+_ELEMENT_ATTRS = {
+    "body": {"name", "pos", "childclass"} | _ORIENT,
+    "geom": {"name", "class", "type", "size", "pos", "fromto", "friction", "density", "mass", "margin", "gap", "condim",
+             "contype", "conaffinity", "solref", "solimp", "solmix", "rgba", "material", "group"} | _ORIENT,
+    "joint": {"name", "class", "type", "pos", "axis", "limited", "range", "margin", "armature", "damping", "ref",
+              "solreflimit", "solimplimit", "group"},
+    "freejoint": {"name", "group"},
+    "site": {"name", "class", "pos", "size", "type", "rgba", "group", "material"} | _ORIENT,
+    "camera": {"name", "class", "pos", "fovy", "mode"} | _ORIENT,
+    "light": {"name", "class", "pos", "dir", "directional", "active", "attenuation", "cutoff", "exponent", "ambient",
+              "diffuse", "specular", "castshadow", "mode"},
+    "motor": {"name", "class", "joint", "gear", "ctrllimited", "ctrlrange", "group"},
+    "general": {"name", "class", "joint", "gear", "ctrllimited", "ctrlrange", "group"},
+    "sensor": {"name", "site", "objname", "objtype", "cutoff", "noise", "user"},
+}
+# attributes that may be present as long as they leave the feature off
+_NEUTRAL = {("joint", "stiffness"): 0.0, ("joint", "frictionloss"): 0.0, ("joint", "springref"): 0.0,
+            ("geom", "priority"): 0.0, ("body", "gravcomp"): 0.0, ("body", "mocap"): "false",
+            ("motor", "forcelimited"): "false", ("general", "forcelimited"): "false"}
+_BODY_CHILDREN = {"body", "geom", "joint", "freejoint", "site", "camera", "light"}
+_DEFAULT_CHILDREN = {"default", "geom", "joint", "site", "camera", "light", "motor", "general", "material"}
+_ASSET_CHILDREN = {"texture", "material"}        # textures are parsed and ignored (rendering: DESIGN 4.2)
+
+
+def _refuse(what):
+    raise UnsupportedMJCF(f"{what} is outside the supported MJCF subset (mjcf.py); the level would be simulated "
+                          "without it, so it is refused")
+
+
+def _check_attrs(el, tag=None):
+    tag = tag or el.tag
+    allowed = _ELEMENT_ATTRS[tag]
+    for key, value in el.attrib.items():
+        if key in allowed:
+            continue
+        off = _NEUTRAL.get((tag, key))
+        if off is not None:
+            try:
+                same = (value == off) if isinstance(off, str) else all(float(t) == off for t in value.split())
+            except ValueError:
+                same = False
+            if same:
+                continue
+        _refuse(f'attribute {key}="{value}" of <{el.tag}>')
+
+
+def check_subset(root: ET.Element):
+    """Raise :class:`UnsupportedMJCF` for anything in the document this compiler would otherwise skip over."""
+    if root.tag != "mujoco":
+        _refuse(f"root element <{root.tag}>")
+    for section in root:
+        if section.tag not in _SECTIONS:
+            _refuse(f"section <{section.tag}>")
+    for comp in root.findall("compiler"):
+        for key, value in comp.attrib.items():
+            if key not in _COMPILER_ATTRS:
+                _refuse(f'<compiler {key}="{value}">')
+            if _COMPILER_ATTRS[key] is not None and value not in _COMPILER_ATTRS[key]:
+                _refuse(f'<compiler {key}="{value}">')
+    for opt in root.findall("option"):
+        for key, value in opt.attrib.items():
+            if key in _OPTION_ZERO:
+                if any(float(t) != 0.0 for t in value.split()):
+                    _refuse(f'<option {key}="{value}">')
+                continue
+            if key not in _OPTION_ATTRS:
+                _refuse(f'<option {key}="{value}">')
+            if _OPTION_ATTRS[key] is not None and value not in _OPTION_ATTRS[key]:
+                _refuse(f'<option {key}="{value}">' + (" (this stepper solves with PGS on the pyramidal cone, "
+                                                        "BASELINE.json north_star)" if key in ("solver", "cone") else ""))
+        for child in opt:
+            # <flag>: every flag switches a stage of the step on or off
+            if child.tag == "flag" and all(v == ("disable" if k in _FLAGS_OFF else "enable")
+                                           for k, v in child.attrib.items()):
+                continue
+            _refuse(f"<option><{child.tag} {' '.join(child.attrib)}>")
+
+    def defaults(elem):
+        for child in elem:
+            if child.tag not in _DEFAULT_CHILDREN:
+                _refuse(f"<default><{child.tag}>")
+            if child.tag == "default":
+                defaults(child)
+            elif child.tag != "material":
+                _check_attrs(child)
+    for top in root.findall("default"):
+        defaults(top)
+    for asset in root.findall("asset"):
+        for child in asset:
+            if child.tag not in _ASSET_CHILDREN:
+                _refuse(f"<asset><{child.tag}>")
+
+    def body(elem):
+        for child in elem:
+            if child.tag not in _BODY_CHILDREN:
+                _refuse(f"<{child.tag}> inside <{elem.tag}>")
+            _check_attrs(child)
+            if child.tag == "body":
+                body(child)
+    for world in root.findall("worldbody"):
+        body(world)
+    for act in root.findall("actuator"):
+        for el in act:
+            if el.tag not in ("motor", "general"):
+                _refuse(f"actuator <{el.tag}>")
+            _check_attrs(el)
+    for sens in root.findall("sensor"):
+        for el in sens:
+            if el.tag not in SENSOR_TYPES:
+                _refuse(f"sensor <{el.tag}>")
+            _check_attrs(el, "sensor")
+
+
+# <option><flag>: MuJoCo's disable flags default to "enable", its enable flags (these) to "disable"
+_FLAGS_OFF = {"override", "energy", "fwdinv", "sensornoise", "multiccd", "island"}
+
+
 # ----------------------------------------------------------------------------- compiler
 class _Compiler:
     def __init__(self, xml_text: str):
         self.root = ET.fromstring(xml_text)
+        check_subset(self.root)
         comp = self.root.find("compiler")
         comp = comp.attrib if comp is not None else {}
         self.degree = comp.get("angle", "degree") == "degree"
@@ -274,7 +415,7 @@ class _Compiler:
                 a = self.defaults.apply(child, childclass)
                 self.cams.append(dict(name=a.get("name", ""), body=body_id,
                                       pos=_vec(a.get("pos"), 3, [0, 0, 0]), quat=self.orientation(a),
-                                      fovy=float(a.get("fovy", 45.0))))
+                                      fovy=float(a.get("fovy", 45.0)), mode=a.get("mode", "fixed")))
             elif child.tag == "light":
                 # XML reference, body/light: directional false, active true, pos 0 0 0, dir 0 0 -1, attenuation 1 0 0,
                 # cutoff 45, exponent 10, ambient 0 0 0, diffuse 0.7 0.7 0.7, specular 0.3 0.3 0.3 (castshadow: ignored)
@@ -373,6 +514,8 @@ class _Compiler:
             a.setdefault("damping", "0")
         else:
             a = self.defaults.apply(elem, childclass)
+        if a.get("type", "hinge") not in JNT_TYPES:
+            _refuse(f'joint type "{a.get("type")}"')
         jtype = JNT_TYPES[a.get("type", "hinge")]
         limited = a.get("limited", "false") == "true"
         rng = _vec(a.get("range"), 2, [0, 0])
@@ -393,6 +536,8 @@ class _Compiler:
 
     def _add_geom(self, elem, body_id, childclass):
         a = self.defaults.apply(elem, childclass)
+        if a.get("type", "sphere") not in GEOM_TYPES:
+            _refuse(f'geom type "{a.get("type")}"')
         gtype = GEOM_TYPES[a.get("type", "sphere")]
         size = _vec(a.get("size"), 3, [0, 0, 0])
         pos = _vec(a.get("pos"), 3, [0, 0, 0])
@@ -739,6 +884,9 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     m.names = dict(body=[b["name"] for b in c.bodies], joint=[j["name"] for j in c.joints],
                    geom=[g["name"] for g in c.geoms], site=[s["name"] for s in c.sites],
                    camera=[s["name"] for s in c.cams], actuator=[], sensor=[])
+    # a camera that is not "fixed" in its body (Ant.xml's mode="trackcom") follows a rule the ray caster does not
+    # implement: the level compiles (physics never reads a camera), drawing that camera is refused (get_camera_data)
+    m.camera_mode = [s["mode"] for s in c.cams]
 
     # ---- actuators (motors)
     act = c.root.find("actuator")

@@ -487,6 +487,11 @@ class MuJoCoParent:
         the device (mjrl_render_*), not OpenGL."""
         width, height = self.sensor_resolution
         names = self._compiled.names["camera"]
+        asked = self.rgb_sensors.get(cam_object, [cam_object] if cam_object in names else [])
+        for cam in asked:
+            mode = self._compiled.camera_mode[names.index(cam)]
+            if mode != "fixed":
+                raise Exception(f'camera {cam} has mode="{mode}"; the ray caster draws cameras fixed in their body only')
         images = self._handle.render(width, height)            # [n_env, ncam, H, W, 3], rows bottom-up
         if not self._scene_cache and names:
             # (a camera asked for by name on a handle made without agentCameras: this image was drawn from the current
