@@ -193,10 +193,12 @@ def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seco
 class DeviceBatch:
     """The product path: ``MuJoCoRL`` over libmjrl_hip.so, tensors resident in HBM."""
 
-    def __init__(self, torch, dev, level_file, agents, n_env, plugins, args, stream, cameras=False, encoder=False):
+    def __init__(self, torch, dev, level_file, agents, n_env, plugins, args, stream, cameras=False, encoder=False,
+                 shares_device=False):
         from mjrl_amd.mujoco_rl import MuJoCoRL
         self.torch, self.dev = torch, dev
         cfg = {"xmlPath": level_file, "agents": agents, "numEnvs": n_env, "deviceId": dev.index,
+               "sharesDevice": shares_device,
                "skipFrames": 1, "maxSteps": EPISODE, "environmentDynamics": plugins,
                "nconmax": args.nconmax, "njmax": args.njmax, "agentCameras": cameras}
         if encoder:          # random-init weights of the reference's architecture (no checkpoint ships, no network)
@@ -241,6 +243,9 @@ class DeviceBatch:
     def solver_stats(self):
         return self.env._handle.get_field("solver_stats")
 
+    def timesteps(self):
+        return self.env._handle.get_field("timestep").astype(np.int64)
+
     def cap_overflows(self):
         return self.env._handle.cap_overflows()
 
@@ -277,6 +282,9 @@ class RehearsalBatch:
 
     def solver_stats(self):
         return self.b.solver_stats()
+
+    def timesteps(self):
+        return self.b.timesteps()
 
     def cap_overflows(self):
         return self.b.cap_overflows()
@@ -411,7 +419,8 @@ def main():
                 batch = RehearsalBatch(level_file, agents, per, bool(plugins))
             else:
                 stream = torch.cuda.current_stream(dev) if groups == 1 else torch.cuda.Stream(dev)
-                batch = DeviceBatch(torch, dev, level_file, agents, per, plugins, args, stream, cameras=cameras, encoder=encoder)
+                batch = DeviceBatch(torch, dev, level_file, agents, per, plugins, args, stream, cameras=cameras, encoder=encoder,
+                                    shares_device=groups > 1)
             n_phys = max(len(batch.agents_action_index[a]) for a in agents)
             act_dim = n_phys + len(plugins)
             first = rank * n_env + g * per
@@ -437,6 +446,7 @@ def main():
         if not on_cpu:
             torch.cuda.synchronize(dev)
         barrier()
+        counters_before = [b.timesteps() for b in batches]
         kernel_ms = None
         if not on_cpu:
             # HIP events on the stream the step kernel is launched on
@@ -460,6 +470,16 @@ def main():
         for batch, (obs, _, _, _) in zip(batches, bufs):
             if not batch.finite(obs):
                 raise SystemExit("non-finite observations after the timed region")
+        # Every copy must have BEEN stepped: its step counter runs 1..EPISODE (an in-launch reset sets it to 0, the step
+        # of that launch to 1), so over the timed region it advanced by exactly `steps` modulo the episode length -- a
+        # kernel that returned early, read its arguments in the wrong place or skipped copies is an error, not a rate.
+        for batch, before in zip(batches, counters_before):
+            after = batch.timesteps()
+            moved = (after - before - steps) % EPISODE
+            if moved.any():
+                bad = int(np.flatnonzero(moved != 0)[0])
+                raise SystemExit(f"bench: {int((moved != 0).sum())} of {len(after)} copies were not stepped exactly {steps} "
+                                 f"times in the timed region (copy {bad}: counter {int(before[bad])} -> {int(after[bad])})")
         # what the copies did in the last timed step: with staggered episodes one step is a sample of the stationary mix
         stats = np.concatenate([np.asarray(b.solver_stats()) for b in batches]).astype(np.float64)
         n_phys = max(len(batches[0].agents_action_index[a]) for a in agents)

@@ -31,7 +31,11 @@ const char* mjrl_last_error(const mjrl_env* env);
 /* Upload a compiled model (blob.py layout) and allocate state for n_env copies on device_id.
  * Replaces: mj.MjModel.from_xml_path + mj.MjData (mujoco_parent.py:126-127), once per copy.
  * All copies start at qpos0 with zero velocity (as after mj_resetData, mujoco_parent.py:349).
- * flags bit 0: turn off the longest-first dispatch (copies are then stepped by workgroup id == copy id). */
+ * flags bit 0: turn off the longest-first dispatch (copies are then stepped by workgroup id == copy id).
+ * A batch of at most one wave per SIMD (n_env <= 4 x compute units) gets the step kernel's build for such batches
+ * (mjrl_size "few": solver forms that use the whole register file, no dispatch order).  The rule assumes that the handle
+ * has the device to itself: flags bit 1 = other handles step on this device at the same time, use the full-batch build
+ * whatever n_env is; flags bit 2 = use the few-copies build whatever n_env is. */
 int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out);
 void mjrl_destroy(mjrl_env* env);
 

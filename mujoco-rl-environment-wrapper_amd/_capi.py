@@ -101,11 +101,17 @@ def _host_ptr(arr):
 class Handle:
     """Owns one ``mjrl_env`` (one GPU, n_env copies of one model)."""
 
-    def __init__(self, blob: bytes, n_env: int, device_id: int = 0, specialize: bool | None = None):
+    def __init__(self, blob: bytes, n_env: int, device_id: int = 0, specialize: bool | None = None,
+                 few: bool | None = None):
+        """``few``: None = the library's rule (a batch of at most one wave per SIMD gets the build for such batches,
+        which assumes that this handle has the device to itself); False = other handles step beside this one, use the
+        full-batch build; True = the few-copies build whatever the batch size (mjrl_create flags bits 1 / 2)."""
         self._lib = load()
         self._h = ctypes.c_void_p()
         # (MJRL_CREATE_FLAGS: experiments only -- bit 0 switches the longest-first dispatch off)
         flags = int(os.environ.get("MJRL_CREATE_FLAGS", "0"))
+        if few is not None:
+            flags |= 4 if few else 2
         rc = self._lib.mjrl_create(blob, len(blob), int(n_env), int(device_id), flags, ctypes.byref(self._h))
         if rc:
             raise Exception(f"mjrl_create failed ({rc}): {self._lib.mjrl_last_error(None).decode()}")

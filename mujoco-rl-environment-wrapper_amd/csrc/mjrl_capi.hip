@@ -24,27 +24,35 @@ namespace {
 #define MJRL_TWO_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ __launch_bounds__(64) MJRL_TWO_WAVES void mjrl_step_kernel(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
-  mj::env_step_t<false, false>(*mp, *mj::kernarg_step_args(8), lds);      // (the arguments where the packet left them: mjrl_step.h)
+  mj::env_step_t<false, false>(*mp, *mj::kernarg_step_args(mj::STEP_ARGS_KERNARG_OFFSET), lds);      // (the arguments where the packet left them: mjrl_step.h)
 }
 __global__ __launch_bounds__(64) void mjrl_step_kernel_big(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
-  mj::env_step_t<false, true>(*mp, *mj::kernarg_step_args(8), lds);
+  mj::env_step_t<false, true>(*mp, *mj::kernarg_step_args(mj::STEP_ARGS_KERNARG_OFFSET), lds);
 }
 // The same step with the diagnostics compiled in (stage clock, wave timeline, LDS dump, stage cuts): the launches of
 // mjrl_step_debug / _profile / _timeline / _truncated and the LDS read-back of mjrl_query.  Same arithmetic, same bits.
 __global__ __launch_bounds__(64) MJRL_TWO_WAVES void mjrl_step_kernel_diag(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
   // (the diagnostic build checks what the production build assumes: the arguments sit 8 bytes into the kernarg segment)
-  const mj::StepArgs* k = mj::kernarg_step_args(8);
+  const mj::StepArgs* k = mj::kernarg_step_args(mj::STEP_ARGS_KERNARG_OFFSET);
   if (k->qpos != a.qpos || k->n_env != a.n_env || k->lpt_words != a.lpt_words) __builtin_trap();
   mj::env_step_t<true, false>(*mp, *k, lds);
 }
 __global__ __launch_bounds__(64) void mjrl_step_kernel_big_diag(const DevModel* __restrict__ mp, mj::StepArgs a) {
   extern __shared__ double lds[];
-  const mj::StepArgs* k = mj::kernarg_step_args(8);
+  const mj::StepArgs* k = mj::kernarg_step_args(mj::STEP_ARGS_KERNARG_OFFSET);
   if (k->qpos != a.qpos || k->n_env != a.n_env || k->lpt_words != a.lpt_words) __builtin_trap();
   mj::env_step_t<true, true>(*mp, *k, lds);
 }
+
+// Are the arguments where the production kernels read them (mj::kernarg_selfcheck)?  Same signature as the step kernels
+// plus a result word; run once per process by mjrl_create.
+__global__ __launch_bounds__(64) void mjrl_selfcheck_kernel(const DevModel* __restrict__ mp, mj::StepArgs a, int* ok) {
+  (void)mp;
+  mj::kernarg_selfcheck(a, ok);
+}
+const unsigned long long LIB_ABI[mj::SPEC_ABI_WORDS] = MJRL_SPEC_ABI_INIT;
 
 // Masked reset of the HBM state: mj_resetData + mj_forward (mujoco_parent.py:349-350) for the selected copies.  Every
 // copy resets to the same state, so what mj_forward leaves there -- the warm start and the sensor readings -- is computed
@@ -515,6 +523,14 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
                        unsigned long long* d_stamps = nullptr, unsigned long long* d_timeline = nullptr);
 static int launch_encoder(mjrl_env* e, const uint8_t* d_rgb, int n_img, float* d_latent, double* d_obs, const int* d_obs_row);
 
+// argument values the self-check kernels compare (never dereferenced)
+static mj::StepArgs selfcheck_args() {
+  mj::StepArgs a{};
+  a.qpos = (double*)0x1000; a.timestep = (int*)0x2000; a.obs = (double*)0x3000; a.n_env = 1234567; a.max_steps = 7654321;
+  a.stats = (int*)0x4000; a.few = 91; a.lpt_words = 4242; a.overflow = (unsigned long long*)0x5000; a.stop_after = 77;
+  return a;
+}
+
 int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsigned flags, mjrl_env** out) {
   if (!blob || !out || n_env <= 0) { g_create_error = "mjrl_create: bad arguments"; return 1; }
   mjrl_env* e = new mjrl_env();
@@ -574,8 +590,31 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, device_id));
+    // (the rule assumes that the handle has the device to itself; a caller that steps several handles side by side --
+    // train and eval envs, half-batches on two streams -- says so with flags bit 1, bit 2 forces the other way)
     e->few = n_env <= 4 * prop.multiProcessorCount;
+    if (flags & 2u) e->few = false;
+    if (flags & 4u) e->few = true;
     if (const char* f = getenv("MJRL_FEW")) e->few = atoi(f) != 0;      // (tests: either kind of solver forms at any batch size)
+  }
+  {
+    // the production kernels read their arguments at a fixed offset of the kernarg segment (mjrl_step.h,
+    // kernarg_step_args): checked once per process with a kernel of the same signature
+    static bool kernarg_checked = false;
+    if (!kernarg_checked) {
+      int* d_ok = nullptr;
+      int ok = 0;
+      CK(hipMalloc(&d_ok, sizeof(int)));
+      CK(hipMemset(d_ok, 0, sizeof(int)));
+      hipLaunchKernelGGL(mjrl_selfcheck_kernel, dim3(1), dim3(64), 0, e->stream, e->d_model, selfcheck_args(), d_ok);
+      CK(hipGetLastError());
+      CK(hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+      CK(hipStreamSynchronize(e->stream));
+      hipFree(d_ok);
+      if (!ok) return fail(6, "mjrl_create: the step kernels' arguments are not where the kernels read them "
+                              "(kernarg offset self-check failed): this build of libmjrl_hip.so must not step anything");
+      kernarg_checked = true;
+    }
   }
   e->big = e->few || mj::pgs_roomy(e->hm, e->lay);
   // (a batch whose waves are all resident at once has no dispatch order to improve: its copies are stepped by workgroup
@@ -1207,6 +1246,51 @@ int mjrl_load_kernel(mjrl_env* e, const char* path) {
   if (hipMemcpy(built, d_sizes, nb, hipMemcpyDeviceToHost) != hipSuccess || memcmp(built, want, nb) != 0) {
     hipModuleUnload(mod);
     MJRL_FAIL(e, 6, "load_kernel: %s was built for a different model shape", path);
+  }
+  // A code object is built apart from the library: it must agree with it on the layout of StepArgs, on where the kernels
+  // read it in the kernarg segment and on the kernel sources (mjrl_step.h, MJRL_SPEC_ABI_INIT).  An object that disagrees
+  // would read garbage pointers or step another revision's physics -- and be timed without complaint.
+  {
+    hipDeviceptr_t d_abi = nullptr;
+    size_t na = 0;
+    unsigned long long abi[mj::SPEC_ABI_WORDS] = {0, 0, 0};
+    if (hipModuleGetGlobal(&d_abi, &na, mod, "mjrl_spec_abi") != hipSuccess || na != sizeof(abi) ||
+        hipMemcpy(abi, d_abi, na, hipMemcpyDeviceToHost) != hipSuccess) {
+      hipModuleUnload(mod);
+      (void)hipGetLastError();
+      MJRL_FAIL(e, 6, "load_kernel: %s carries no mjrl_spec_abi record (built before the library's revision)", path);
+    }
+    if (abi[0] != LIB_ABI[0] || abi[2] != LIB_ABI[2]) {
+      hipModuleUnload(mod);
+      MJRL_FAIL(e, 6, "load_kernel: %s was built with another layout of the step arguments (StepArgs)", path);
+    }
+    // (experiments that A/B a saved object of an older revision against this library say so: MJRL_ALLOW_STALE_KERNEL=1)
+    const char* stale_ok = getenv("MJRL_ALLOW_STALE_KERNEL");
+    if (abi[1] != LIB_ABI[1] && !(stale_ok && atoi(stale_ok))) {
+      hipModuleUnload(mod);
+      MJRL_FAIL(e, 6, "load_kernel: %s was built from other kernel sources than this library (digest %012llx, library "
+                      "%012llx); rebuild it (kernel_cache.code_object)", path, abi[1], LIB_ABI[1]);
+    }
+    hipFunction_t check = nullptr;
+    int* d_ok = nullptr;
+    int ok = 0;
+    bool ran = hipModuleGetFunction(&check, mod, "mjrl_spec_selfcheck") == hipSuccess &&
+               hipMalloc(&d_ok, sizeof(int)) == hipSuccess && hipMemset(d_ok, 0, sizeof(int)) == hipSuccess;
+    if (ran) {
+      const void* image = e->d_blob;
+      mj::StepArgs probe = selfcheck_args();
+      void* params[] = {(void*)&image, (void*)&probe, (void*)&d_ok};
+      ran = hipModuleLaunchKernel(check, 1, 1, 1, 64, 1, 1, 0, e->stream, params, nullptr) == hipSuccess &&
+            hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+            hipStreamSynchronize(e->stream) == hipSuccess;
+    }
+    if (d_ok) hipFree(d_ok);
+    if (!ran || !ok) {
+      hipModuleUnload(mod);
+      (void)hipGetLastError();
+      MJRL_FAIL(e, 6, "load_kernel: %s failed the kernarg offset self-check (its kernel would read its arguments in the "
+                      "wrong place)", path);
+    }
   }
   size_t lds_bytes = (size_t)e->lay.total * sizeof(double);
   if (lds_bytes > 64 * 1024 &&

@@ -14,6 +14,9 @@ extern "C" __device__ const int mjrl_spec_sizes[MJRL_NSIZES] = {
 #undef X
 };
 
+// layout of StepArgs, digest of the kernel sources, kernarg offset: compared with the library's by mjrl_load_kernel
+extern "C" __device__ const unsigned long long mjrl_spec_abi[mj::SPEC_ABI_WORDS] = MJRL_SPEC_ABI_INIT;
+
 // experiments (tools/build_variant.py -- -DMJRL_SPEC_WAVES_PER_EU=3): cap the registers for that many waves per SIMD
 #ifdef MJRL_SPEC_WAVES_PER_EU
 #define MJRL_SPEC_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MJRL_SPEC_WAVES_PER_EU, MJRL_SPEC_WAVES_PER_EU)))
@@ -37,9 +40,15 @@ extern "C" __global__ __launch_bounds__(64) MJRL_SPEC_OCCUPANCY void mjrl_step_k
   mjrl_model_from_base(&m, (const char MJRL_GLOBAL*)image);
   // (`a` is read where the dispatch packet left it, field by field at its point of use: mj::kernarg_step_args; the
   // diagnostic build checks the offset that assumes)
-  const mj::StepArgs* k = mj::kernarg_step_args(8);
+  const mj::StepArgs* k = mj::kernarg_step_args(mj::STEP_ARGS_KERNARG_OFFSET);
 #ifdef MJRL_DIAG
   if (k->qpos != a.qpos || k->n_env != a.n_env || k->lpt_words != a.lpt_words) __builtin_trap();
 #endif
   mj::env_step_t<MJRL_SPEC_DIAG>(m, *k, lds);
+}
+
+// same signature as the step kernel plus a result word: run once by mjrl_load_kernel (mj::kernarg_selfcheck)
+extern "C" __global__ __launch_bounds__(64) void mjrl_spec_selfcheck(const char* __restrict__ image, mj::StepArgs a, int* ok) {
+  (void)image;
+  mj::kernarg_selfcheck(a, ok);
 }

@@ -3515,6 +3515,52 @@ __device__ __forceinline__ const StepArgs* kernarg_step_args(int offset) {
 }
 #endif
 
+// Where the StepArgs parameter of the step kernels -- all of the form kernel(pointer, StepArgs) -- sits in the kernarg
+// segment: behind the pointer, rounded up to the struct's alignment.  The kernels read their arguments THERE and never
+// name the by-value parameter, so nothing but these lines ties the offset to the signature.
+static_assert(sizeof(void*) == 8, "the step kernels' first parameter is one 8-byte pointer");
+static_assert(alignof(StepArgs) == 8, "a member with a wider alignment moves StepArgs in the kernarg segment");
+constexpr int STEP_ARGS_KERNARG_OFFSET = (int)((sizeof(void*) + alignof(StepArgs) - 1) / alignof(StepArgs) * alignof(StepArgs));
+
+// What a code object built apart from the library (a model-specialised step kernel, csrc/_spec/*.hsaco) must agree with
+// the library on before it may be launched: the layout of StepArgs -- its size and the offsets of fields spread over it,
+// folded into one word -- and the kernel sources both were built from (MJRL_SOURCE_DIGEST: the first 60 bits of the
+// SHA-1 of the header set, handed to both builds by csrc/Makefile and kernel_cache.py).  mjrl_load_kernel compares the
+// object's `mjrl_spec_abi` with the library's; a stale or mis-laid-out object is refused, not timed.
+#ifndef MJRL_SOURCE_DIGEST
+#define MJRL_SOURCE_DIGEST 0ull
+#endif
+constexpr unsigned long long step_args_layout() {
+  unsigned long long h = 1469598103934665603ull;
+#define MJ_LAYOUT_FIELD(f) h = (h ^ (unsigned long long)__builtin_offsetof(StepArgs, f)) * 1099511628211ull;
+  MJ_LAYOUT_FIELD(qpos) MJ_LAYOUT_FIELD(timestep) MJ_LAYOUT_FIELD(actions) MJ_LAYOUT_FIELD(scatter_mode)
+  MJ_LAYOUT_FIELD(gather) MJ_LAYOUT_FIELD(obs) MJ_LAYOUT_FIELD(trunc) MJ_LAYOUT_FIELD(n_env) MJ_LAYOUT_FIELD(more_frames)
+  MJ_LAYOUT_FIELD(dbg) MJ_LAYOUT_FIELD(forward_only) MJ_LAYOUT_FIELD(reset_mask) MJ_LAYOUT_FIELD(auto_mask)
+  MJ_LAYOUT_FIELD(reset_sens) MJ_LAYOUT_FIELD(rk) MJ_LAYOUT_FIELD(stats) MJ_LAYOUT_FIELD(stamps) MJ_LAYOUT_FIELD(prog_i)
+  MJ_LAYOUT_FIELD(n_slot) MJ_LAYOUT_FIELD(store) MJ_LAYOUT_FIELD(tag_ref) MJ_LAYOUT_FIELD(env_base) MJ_LAYOUT_FIELD(variant)
+  MJ_LAYOUT_FIELD(variant_seed) MJ_LAYOUT_FIELD(frames) MJ_LAYOUT_FIELD(scene) MJ_LAYOUT_FIELD(few)
+  MJ_LAYOUT_FIELD(lpt_count_in) MJ_LAYOUT_FIELD(lpt_mask_clear) MJ_LAYOUT_FIELD(lpt_words) MJ_LAYOUT_FIELD(overflow)
+  MJ_LAYOUT_FIELD(timeline) MJ_LAYOUT_FIELD(stop_after)
+#undef MJ_LAYOUT_FIELD
+  return (h ^ (unsigned long long)sizeof(StepArgs)) * 1099511628211ull;
+}
+enum { SPEC_ABI_WORDS = 3 };
+#define MJRL_SPEC_ABI_INIT { mj::step_args_layout(), (unsigned long long)(MJRL_SOURCE_DIGEST), (unsigned long long)mj::STEP_ARGS_KERNARG_OFFSET }
+
+#if defined(__HIPCC__)
+// The check the production kernels do not carry: are the arguments where kernarg_step_args looks for them?  Run once per
+// kernel (mjrl_create for the library's, mjrl_load_kernel for a code object's) by a kernel of the same signature plus a
+// result word; compares fields spread over the struct with the by-value copy the compiler hands out.
+__device__ __forceinline__ void kernarg_selfcheck(const StepArgs& by_value, int* ok) {
+  const StepArgs* k = kernarg_step_args(STEP_ARGS_KERNARG_OFFSET);
+  const bool same = k->qpos == by_value.qpos && k->timestep == by_value.timestep && k->obs == by_value.obs &&
+                    k->n_env == by_value.n_env && k->max_steps == by_value.max_steps && k->stats == by_value.stats &&
+                    k->few == by_value.few && k->lpt_words == by_value.lpt_words && k->overflow == by_value.overflow &&
+                    k->stop_after == by_value.stop_after;
+  if (threadIdx.x == 0) *ok = same ? 1 : 0;
+}
+#endif
+
 // the diagnostic build under its historical name (the CPU emulation under tests/emu steps copies through this one)
 __device__ inline void env_step(const DevModel& m, const StepArgs& a, real* S) { env_step_t<true>(m, a, S); }
 

@@ -93,7 +93,9 @@ def code_object(blob: bytes, build: bool = True, few: bool = False) -> str | Non
         with open(hdr, "w") as f:
             f.write(spec_header(sizes))
         out = os.path.join(tmp, "step.hsaco")
-        cmd = [cc, "--genco", *FLAGS, *(FEW_FLAGS if few else ()), f'-DMJRL_SPEC_HEADER="{hdr}"', "-I", CSRC,
+        # (the digest of the kernel sources goes into the object: mjrl_load_kernel compares it with the library's)
+        cmd = [cc, "--genco", *FLAGS, *(FEW_FLAGS if few else ()), f'-DMJRL_SPEC_HEADER="{hdr}"',
+               f"-DMJRL_SOURCE_DIGEST=0x{_source_digest()}ull", "-I", CSRC,
                os.path.join(CSRC, "mjrl_spec_kernel.hip"), "-o", out]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:

@@ -126,8 +126,12 @@ class DataView:
 class MuJoCoParent:
     def __init__(self, xml_paths, export_path: str = None, render: bool = False, free_joint: bool = False,
                  agent_cameras: bool = False, sensor_resolution=(64, 64), n_env: int = 1, device_id: int = 0,
-                 nconmax: int = None, njmax: int = None, first_env_id: int = 0, variant_seed: int = 0):
+                 nconmax: int = None, njmax: int = None, first_env_id: int = 0, variant_seed: int = 0,
+                 shares_device: bool = False):
         self.xml_paths = xml_paths
+        # (other env objects step on this GPU at the same time: a small batch must not pick the step kernel's build that
+        # assumes it has every SIMD to itself, _capi.Handle(few=False))
+        self._shares_device = bool(shares_device)
         self.export_path = export_path
         self.render = render
         self.free_joint = free_joint
@@ -183,7 +187,7 @@ class MuJoCoParent:
         self._blob = blob.pack(self._compiled)
         if self._handle is not None:
             self._handle.close()
-        self._handle = _capi.Handle(self._blob, self.n_env, self.device_id)
+        self._handle = _capi.Handle(self._blob, self.n_env, self.device_id, few=False if self._shares_device else None)
         if self._stream is not None:
             self._handle.set_stream(self._stream)
         if self.first_env_id:

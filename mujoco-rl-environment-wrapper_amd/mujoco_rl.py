@@ -69,7 +69,8 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
                               sensor_resolution=sensor_resolution, n_env=config_dict.get("numEnvs", 1),
                               device_id=config_dict.get("deviceId", 0), nconmax=config_dict.get("nconmax"),
                               njmax=config_dict.get("njmax"), first_env_id=config_dict.get("firstEnvId", 0),
-                              variant_seed=config_dict.get("variantSeed", 0))
+                              variant_seed=config_dict.get("variantSeed", 0),
+                              shares_device=config_dict.get("sharesDevice", False))
         self._handle.set_max_steps(self.max_steps)
         self._load_info_json()
 

@@ -96,6 +96,9 @@ class EmuBatch:
             self.last_stats[e] = (img.ncon, img.nefc, img.niter, img.warn)
         return obs, reward, term, trunc
 
+    def timesteps(self):
+        return np.array([int(env.timestep[0]) for env in self.envs], np.int64)
+
     def solver_stats(self):
         return self.last_stats
 

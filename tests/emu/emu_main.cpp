@@ -164,6 +164,10 @@ void emu_set_tags(const int32_t* adr, const int32_t* num, const int32_t* ref, in
   g_tag_adr = adr; g_tag_num = num; g_tag_ref = ref; g_env_base = env_base;
 }
 
+// StepArgs::few of the following emu_step calls: the solver forms of the build for batches of at most one wave per SIMD
+static int g_few = 0;
+void emu_set_few(int few) { g_few = few; }
+
 // longest-first dispatch tables of the following emu_step calls (launch_step's lpt_count_in / lpt_list_in); null: identity
 static const int* g_lpt_count = nullptr;
 static const unsigned* g_lpt_mask = nullptr;
@@ -203,7 +207,7 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.agent_body = agent_body; a.agent_obs_len = agent_obs_len; a.store = store;
   a.lpt_count_in = g_lpt_count; a.lpt_mask_in = g_lpt_mask; a.lpt_words = g_lpt_words;
   a.tag_adr = g_tag_adr; a.tag_num = g_tag_num; a.tag_ref = g_tag_ref; a.env_base = g_env_base;
-  a.max_steps = max_steps; a.n_env = 1;
+  a.max_steps = max_steps; a.n_env = 1; a.few = g_few;
   a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;
   emu::cur_env = 0;
   // one frame per wave run, like the launches of launch_step in mjrl_capi.hip

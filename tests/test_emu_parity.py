@@ -84,7 +84,7 @@ def test_constraint_rows_match_before_projection():
 
 @pytest.mark.parametrize("level,steps", [("two_agent.xml", 400), ("single_agent.xml", 300), ("two_agent_3sensors.xml", 250),
                                          ("four_agent.xml", 260)])
-def test_trajectory_parity(level, steps):
+def test_trajectory_parity(level, steps, emu_few):
     model, ora, emu = pair(level)
     rng = np.random.default_rng(3)
     saw_contact = False
@@ -170,7 +170,7 @@ def test_contact_cap_drops_in_order_and_flags():
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-10)
 
 
-def test_fused_plugin_ops_follow_the_reference_loop_order():
+def test_fused_plugin_ops_follow_the_reference_loop_order(emu_few):
     """Language channel + distance reward / done as ops of the step kernel, against a direct transcription of the
     reference's plugin loop (dynamic-major, agent-minor, each call seeing the earlier calls' data-store writes;
     README.md:109-136, mujoco_rl.py:215-241, 276-286)."""
@@ -326,7 +326,7 @@ def _pose_with_many_rows_in_one_tree(model, packed):
     return None
 
 
-def test_wide_register_solver_for_17_to_32_rows_per_tree():
+def test_wide_register_solver_for_17_to_32_rows_per_tree(emu_few):
     """More than 16 constraint rows in a tree (an ant on its four feet with joints at their limits): the solver then
     keeps 32 rows per tree in registers (pgs_wide_registers).  Sweep counts must still be the oracle's, step for
     step."""
@@ -349,7 +349,7 @@ def test_wide_register_solver_for_17_to_32_rows_per_tree():
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
 
 
-def test_coupling_rows_in_several_tree_pairs_at_once():
+def test_coupling_rows_in_several_tree_pairs_at_once(emu_few):
     """Four agents, stacked in two pairs and one pair leaning on a third agent: rows that couple trees (0,1), (2,3)
     and (1,2) in the same step.  The trees sweep side by side with the coupling rows aligned in their lists
     (pgs_coupled_schedule); sweep counts and trajectories must match the oracle's plain serial sweep."""
@@ -378,7 +378,7 @@ def test_coupling_rows_in_several_tree_pairs_at_once():
     assert np.allclose(emu.qpos, ora.qpos, atol=1e-9) and np.allclose(emu.qvel, ora.qvel, atol=1e-8)
 
 
-def test_more_than_sixteen_rows_per_tree_in_a_four_tree_model():
+def test_more_than_sixteen_rows_per_tree_in_a_four_tree_model(emu_few):
     """17..32 rows in a tree of the 4-agent level: no idle lanes to spread a tree over, so a lane owns two rows of its
     tree (pgs_tall_registers, round 3; before: the sweep on the aligned schedule).  One agent is lowered onto the floor with bent legs (four
     foot contacts plus active joint limits) while the others fall; sweep counts and trajectories must be the
@@ -631,7 +631,7 @@ def test_skipping_the_blocks_of_trees_out_of_reach_changes_nothing():
     assert between > 10
 
 
-def test_in_launch_reset_with_several_frames_per_step():
+def test_in_launch_reset_with_several_frames_per_step(emu_few):
     """skipFrames > 1: only the first launch of the step loads the reset image; the later frames continue from it, and
     the step counter, the data store and the fused program see a fresh episode."""
     model, ora, emu = pair("two_agent.xml")
@@ -670,7 +670,7 @@ def test_in_launch_reset_with_several_frames_per_step():
     assert obs[0, 59] == 0 and obs[1, 59] == 2         # a fresh episode: the sender has heard nothing yet
 
 
-def test_reset_without_a_step_and_the_autoreset_kept_by_the_step():
+def test_reset_without_a_step_and_the_autoreset_kept_by_the_step(emu_few):
     """Round 3: a reset-mask byte of 2 resets a copy without stepping it (its outputs are the reset observation), and
     with mjrl_set_autoreset the step itself records that a copy's episode ended and resets it in the next step -- mode 1
     without a step (Gymnasium's next-step convention), mode 2 reset-then-step.  Device source on the CPU emulation

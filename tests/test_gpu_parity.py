@@ -43,7 +43,7 @@ def test_reset_state_and_forward_pass():
 @pytest.mark.parametrize("level,steps", [("two_agent.xml", 400), ("single_agent.xml", 300), ("two_agent_3sensors.xml", 300),
                                          ("four_agent.xml", 300), ("sensor_touch.xml", 150), ("sensor_accelerometer.xml", 150),
                                          ("sensor_rangefinder.xml", 150), ("sensor_framexaxis.xml", 150)])
-def test_trajectory_parity_through_the_c_abi(level, steps):
+def test_trajectory_parity_through_the_c_abi(level, steps, few_build):
     n_env = 6
     model, packed, h = make(level, n_env)
     oras = [OracleEnv(packed) for _ in range(n_env)]
@@ -71,7 +71,7 @@ def OracleFwd(o):
     return o.ncon
 
 
-def test_thousand_step_drift_stays_inside_the_north_star_tolerance():
+def test_thousand_step_drift_stays_inside_the_north_star_tolerance(few_build):
     """qpos/qvel within 1e-5 relative over 1000 steps of the 2-agent level with random actions (the drift curve is
     printed; it is the evidence DESIGN.md quotes)."""
     n_env = 4
@@ -126,7 +126,7 @@ def test_scatter_gather_flags_through_the_env_class():
     env.close()
 
 
-def test_single_copy_has_the_reference_shapes_and_runs_host_plugins():
+def test_single_copy_has_the_reference_shapes_and_runs_host_plugins(few_build):
     calls = []
 
     class Language:
@@ -210,6 +210,42 @@ def test_full_batch_properties():
     assert np.array_equal(q4[keep], q3[keep])      # the last run on this handle was the permuted one
 
 
+def test_config_two_batch_runs_the_few_copies_build_and_follows_the_oracle(monkeypatch):
+    """1024 copies of the 2-agent level (BASELINE config 2; a quarter of the chip's wave slots): left to itself the
+    library attaches the build for batches of at most one wave per SIMD.  Finite, deterministic, identical action
+    streams give identical bits wherever they sit in the batch, eight copies against their oracles with the same
+    per-copy contact / row / sweep counts."""
+    monkeypatch.delenv("MJRL_FEW", raising=False)
+    n_env, steps = 1024, 300
+    model, packed, h = make("two_agent.xml", n_env)
+    assert h.size("few") == 1 and h.kernel == "specialised"
+    rng = np.random.default_rng(11)
+    base = rng.uniform(-1, 1, (steps, 8, model.nu))
+    oras = [OracleEnv(packed) for _ in range(8)]
+    def run():
+        h.reset()
+        counts = []
+        for t in range(steps):
+            h.set_field("ctrl", np.tile(base[t], (n_env // 8, 1)))
+            h.step_device(None, 0, 1)
+            counts.append(h.get_field("solver_stats")[:8, :3].copy())
+        return h.get_field("qpos"), h.get_field("qvel"), counts
+    q1, v1, counts = run()
+    assert np.isfinite(q1).all() and np.isfinite(v1).all()
+    assert np.array_equal(q1[:8], q1[8:16]) and np.array_equal(q1[:8], q1[-8:])
+    q2, v2, _ = run()
+    assert np.array_equal(q1, q2) and np.array_equal(v1, v2)
+    for t in range(steps):
+        for e, o in enumerate(oras):
+            o.ctrl[:] = base[t, e]
+            o.step()
+            assert tuple(counts[t][e]) == (o.ncon, o.nefc, o.niter), (t, e)
+    assert max(o.ncon for o in oras) > 0
+    assert rel(q1[:8], np.stack([o.qpos for o in oras])) < 1e-9
+    assert rel(v1[:8], np.stack([o.qvel for o in oras])) < 1e-9
+    assert h.cap_overflows() == (0, 0)
+
+
 def test_step_batched_with_torch_tensors_stays_on_device():
     import torch
     env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 64})
@@ -229,7 +265,7 @@ def test_step_batched_with_torch_tensors_stays_on_device():
     env.close()
 
 
-def test_fused_vocabulary_equals_the_host_plugin_loop():
+def test_fused_vocabulary_equals_the_host_plugin_loop(few_build):
     """Config 3: Language channel + rangefinder obs, with a target-distance reward and done.  The same plugins run
     once as ops of the step kernel and once through the host plugin loop (fusedPlugins False); both sit on the
     same GPU physics, so every output must agree (utterances exactly)."""
@@ -266,7 +302,7 @@ def test_fused_vocabulary_equals_the_host_plugin_loop():
     host.close()
 
 
-def test_agent_cameras_match_the_oracle_ray_caster():
+def test_agent_cameras_match_the_oracle_ray_caster(few_build):
     """Config 5: body-mounted cameras, 64x64x3 uint8 (the input contract of vision/autoencoder.py:13).  Pixel parity
     with the reference's OpenGL output is unpinned; the device ray caster is checked against the
     oracle's on the same states, allowing isolated one-level differences on silhouette edges."""

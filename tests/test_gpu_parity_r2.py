@@ -32,7 +32,7 @@ def make(level, n_env, **kw):
 
 # --------------------------------------------------------------------------- (i) freeJoint scatter
 @pytest.mark.parametrize("level,agents,steps", [("two_agent.xml", AGENTS, 300), ("sensor_touch.xml", ["receiver"], 200)])
-def test_free_joint_mode_against_the_oracle(level, agents, steps):
+def test_free_joint_mode_against_the_oracle(level, agents, steps, few_build):
     """freeJoint=True -- the configuration of the reference's fps_benchmark.py:20 and Testing/sensor_test.py:20: the
     action overwrites qvel[dof, dof+1, dof+5] of the agent's free joint before the physics (mujoco_parent.py:325)."""
     n_env = 5
@@ -137,7 +137,7 @@ def test_env_class_queries_match_the_oracle():
 
 
 # --------------------------------------------------------------------------- reset image, masked and in-launch reset
-def test_masked_reset_leaves_the_other_copies_alone():
+def test_masked_reset_leaves_the_other_copies_alone(few_build):
     """mjrl_reset(mask): the flagged copies get the reset image (state, warm start, sensordata as mj_forward leaves them
     at the reset state), every other copy keeps every bit -- also its warm start -- and its later trajectory."""
     n_env = 64
@@ -175,7 +175,7 @@ def test_masked_reset_leaves_the_other_copies_alone():
     assert rel(h.get_field("qpos")[e], ora.qpos) < 1e-9
 
 
-def test_in_launch_reset_equals_reset_then_step():
+def test_in_launch_reset_equals_reset_then_step(few_build):
     """mjrl_set_step_reset_mask: flagged copies are reset inside the step launch; bit for bit the result of mjrl_reset on
     those copies followed by the same step.  Also with the mask in device memory for mjrl_reset_device, and at the
     full batch size."""
@@ -284,7 +284,7 @@ def test_full_batch_properties_fused_config_three():
 
 
 # --------------------------------------------------------------------------- (iv) cameras at config 5's size
-def test_camera_batch_properties_at_512_copies():
+def test_camera_batch_properties_at_512_copies(few_build):
     """Config 5's batch: 512 copies x 2 cameras x 64x64x3.  Copies in the same state render the same bytes wherever
     they sit in the batch, runs repeat bit for bit, and sampled copies match the oracle's ray caster."""
     n_env = 512
@@ -384,7 +384,7 @@ def test_step_batched_rejects_buffers_that_would_fault():
 INFO_JSON = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "two_agent_info.json")
 
 
-def test_tag_ops_fused_equal_the_host_plugin_loop():
+def test_tag_ops_fused_equal_the_host_plugin_loop(few_build):
     """the info JSON's tags as device tables.  PickUpDynamic (Testing/Pick_Up_Dynamic.py:15-41) with a
     distance-decrease reward and a done on the agent's current target, once as ops of the step kernel and once through
     the host plugin loop on the same GPU physics; the host side goes through filter_by_tag / get_data."""
@@ -537,7 +537,7 @@ def test_box_box_contacts_on_the_device():
 
 
 # --------------------------------------------------------------------------- Runge-Kutta integrator
-def test_rk4_level_through_the_c_abi():
+def test_rk4_level_through_the_c_abi(few_build):
     """benchmarking/levels/Ant.xml (RK4, dt 0.01): four launches per physics frame, against the oracle's RK4 step; through
     the env class with skipFrames 2."""
     n_env = 5
@@ -563,7 +563,7 @@ def test_rk4_level_through_the_c_abi():
 
 
 # --------------------------------------------------------------------------- random scenes on the hardware
-def test_random_scenes_on_the_device():
+def test_random_scenes_on_the_device(few_build):
     """The scenes of tests/test_fuzz_scenes.py (mixed geoms, one to four trees, hinge / slide / free joints) through the
     C-ABI with the generic kernel (one code object for every shape), against the oracle: contact, row and sweep counts
     every 20 steps, trajectories at the end."""

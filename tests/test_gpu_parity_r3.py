@@ -200,7 +200,7 @@ def _oracle_obs(o):
 
 @pytest.mark.parametrize("mode", ["next_step", "reset_then_step", "same_step"])
 @pytest.mark.parametrize("path", ["numpy", "torch"])
-def test_batched_vector_env_follows_the_oracle_through_autoresets(mode, path):
+def test_batched_vector_env_follows_the_oracle_through_autoresets(mode, path, few_build):
     """SURVEY 8f rank 1 (MuJoCo_Gym/wrappers.py:12-82 as a vector env): ``BatchedVectorEnv`` over ``mjrl_step_pinned``
     (numpy in / out) and ``mjrl_step_device`` (torch in / out), the autoreset kept by the kernel (mjrl_set_autoreset).  Every
     copy follows its own CPU oracle through three episodes; the three autoreset conventions return what their
@@ -257,7 +257,7 @@ def test_batched_vector_env_follows_the_oracle_through_autoresets(mode, path):
     vec.close()
 
 
-def test_vector_env_autoreset_is_per_copy_and_runs_the_fused_channel():
+def test_vector_env_autoreset_is_per_copy_and_runs_the_fused_channel(few_build):
     """Copies that end their episodes at different steps are reset one by one (next-step convention) while the others
     keep stepping, on the 2-agent level with the fused Language channel driven through the adapter: the ended copy's
     row is the reset observation with the channel's slot at 0, its data store is empty, and it matches a fresh oracle
@@ -361,7 +361,7 @@ def test_arena_with_73_geoms_on_the_device(tmp_path):
     env.close()
 
 
-def test_autoreset_with_several_frames_per_step_and_runge_kutta():
+def test_autoreset_with_several_frames_per_step_and_runge_kutta(few_build):
     """A reset-without-step has to hold through every launch of a step: two physics frames per step on the 2-agent level
     (two launches) and the Runge-Kutta level (`ant.xml`: four launches per frame, eight per step).  Next-step autoreset
     through the adapter, every copy against its oracle."""
@@ -402,7 +402,7 @@ def test_autoreset_with_several_frames_per_step_and_runge_kutta():
 
 
 # --------------------------------------------------------------------------- which frames the cameras draw
-def test_render_draws_the_frames_of_the_last_forward_pass():
+def test_render_draws_the_frames_of_the_last_forward_pass(few_build):
     """mjv_updateScene(model, data, ...) (mujoco_parent.py:533) reads the geom / camera / light frames out of MjData as the
     last forward pass left them: after mj_step they are one integration older than qpos.  With the scene cache on
     (agentCameras turns it on) the device images are those of the step's own frames -- the oracle's after the same
