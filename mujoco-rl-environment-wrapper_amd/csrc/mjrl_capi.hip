@@ -387,6 +387,7 @@ struct mjrl_env {
   bool few = false;                      // the batch leaves every SIMD at most one wave (StepArgs::few)
   void* d_blob = nullptr;
   DevModel* d_model = nullptr;     // device copy of `dm`
+  int32_t* d_lane_rec = nullptr;   // the lanes' records of the model (mj::build_lane_records), StepArgs::lane_rec
   int n_env = 0, device = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   double *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr, *sens = nullptr, *dbg = nullptr;
@@ -496,7 +497,7 @@ const char* mjrl_last_error(const mjrl_env* env) { return env ? env->err.c_str()
 void mjrl_destroy(mjrl_env* e) {
   if (!e) return;
   DeviceGuard guard(e->device);
-  void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_part, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
+  void* ptrs[] = {e->scene, e->rk, e->enc_w1, e->enc_w2, e->enc_wd, e->enc_b1, e->enc_b2, e->enc_bd, e->enc_a2, e->enc_part, e->enc_rgb, e->enc_obs_row, e->d_tag_adr, e->d_tag_num, e->d_tag_ref, e->variant, e->episode, e->variant_rgba, e->stats, e->reset_warm, e->reset_sens, e->d_blob, e->d_model, e->d_lane_rec, e->qpos, e->qvel, e->ctrl, e->warm, e->sens, e->dbg, e->timestep, e->d_mask, e->d_gather,
                   e->d_scatter, e->s_act, e->s_obs, e->s_rew, e->s_term, e->s_trunc, e->d_prog_i, e->d_agent_body,
                   e->d_obs_len, e->d_prog_f, e->store, e->frames, e->lpt_count[0], e->lpt_count[1], e->lpt_count[2],
                   e->lpt_mask[0], e->lpt_mask[1], e->lpt_mask[2], e->overflow, e->auto_mask, e->reset_scene, e->render_consts};
@@ -565,6 +566,14 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   mjrl_model_from_blob(&e->dm, e->h_blob.data(), nbytes, e->d_blob);
   CK(hipMalloc(&e->d_model, sizeof(DevModel)));
   CK(hipMemcpy(e->d_model, &e->dm, sizeof(DevModel), hipMemcpyHostToDevice));
+  {
+    // what a lane reads from the model for itself, as records (mjrl_step.h, lane records): the loader functions of the
+    // kernel run here, once, on the host copy of the model
+    std::vector<int32_t> rec((size_t)mj::LANE_REC_INTS, 0);
+    mj::build_lane_records(e->hm, e->lay, rec.data());
+    CK(hipMalloc(&e->d_lane_rec, sizeof(int32_t) * rec.size()));
+    CK(hipMemcpy(e->d_lane_rec, rec.data(), sizeof(int32_t) * rec.size(), hipMemcpyHostToDevice));
+  }
   CK(hipMalloc(&e->qpos, sizeof(double) * n_env * m.nq));
   CK(hipMalloc(&e->qvel, sizeof(double) * n_env * m.nv));
   CK(hipMalloc(&e->ctrl, sizeof(double) * n_env * (m.nu > 0 ? m.nu : 1)));
@@ -1133,6 +1142,7 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.reset_sens = e->reset_sens;
   a.reset_scene = e->reset_scene;
   a.few = e->few ? 1 : 0;
+  a.lane_rec = e->d_lane_rec;
   a.auto_mask = forward_only ? nullptr : e->auto_mask;
   a.auto_mode = e->auto_mode;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;

@@ -19,8 +19,8 @@ struct V3 {
   real x, y, z;
 };
 
-__device__ __forceinline__ V3 v3(real x, real y, real z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 ld3(const real* p) { return v3(p[0], p[1], p[2]); }
+__host__ __device__ __forceinline__ V3 v3(real x, real y, real z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__host__ __device__ __forceinline__ V3 ld3(const real* p) { return v3(p[0], p[1], p[2]); }
 __device__ __forceinline__ void st3(real* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -41,7 +41,7 @@ __device__ __forceinline__ V3 normalized(V3 a, real* len) {
 struct Quat {
   real w, x, y, z;
 };
-__device__ __forceinline__ Quat ldq(const real* p) { Quat q; q.w = p[0]; q.x = p[1]; q.y = p[2]; q.z = p[3]; return q; }
+__host__ __device__ __forceinline__ Quat ldq(const real* p) { Quat q; q.w = p[0]; q.x = p[1]; q.y = p[2]; q.z = p[3]; return q; }
 __device__ __forceinline__ void stq(real* p, Quat q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 __device__ __forceinline__ Quat qmul(Quat a, Quat b) {
   Quat r;

@@ -196,6 +196,8 @@ struct StepArgs {
   // qpos.  reset_scene [scene_doubles] is the row of the reset image, for copies that are reset without a physics frame.
   real* scene;
   const real* reset_scene;
+  // The lanes' records of the model (build_lane_records: LANE_REC_INTS ints, built once per handle by mjrl_create)
+  const int32_t* lane_rec;
   // The batch leaves every SIMD at most one wave (n_env <= 4 x the CUs, mjrl_create): the solver forms that need more
   // than 256 registers cost no residency then (stage_pgs: `few`).  Read by the generic kernels; a specialised kernel
   // is built for one case or the other (-DMJRL_FEW=1, kernel_cache.code_object(..., few=True)).
@@ -278,7 +280,7 @@ struct LaneK {
   real d_damping, d_armature;
 };
 
-__device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
+__host__ __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
   bool isb = L < m.nbody, isd = L < m.nv;
   int b = isb ? L : 0, d = isd ? L : 0;
   // (kinematic parent and depth: bodies welded to a jointless parent hang off the nearest ancestor that moves, mjcf.py)
@@ -325,7 +327,7 @@ __device__ inline Tab make_tab(const DevModel& m, const Lay& l, const real* S) {
 // the copy's id -- and written by stage_constants(); a longer table takes a loop of batched loads for the rest.
 enum { TAB_EARLY = 8 };
 struct TabRegs { int v[TAB_EARLY]; };
-__device__ __forceinline__ void tab_issue(const DevModel& m, int L, TabRegs& r) {
+__host__ __device__ __forceinline__ void tab_issue(const DevModel& m, int L, TabRegs& r) {
 #pragma unroll
   for (int u = 0; u < TAB_EARLY; u++) {
     const int i = 64 * u + L;
@@ -382,7 +384,7 @@ __device__ __forceinline__ int row_slot(int chain, unsigned long long below, int
   return in_p ? dp - depth : (in_q ? MAX_DOF_DEPTH + dq - depth : -1);
 }
 
-__device__ inline void load_row_constants(const DevModel& m, const Lay& l, int L, RowK& r) {
+__host__ __device__ inline void load_row_constants(const DevModel& m, const Lay& l, int L, RowK& r) {
   r.dof = m.rowmap ? m.row_dof[L] : (L < m.nv ? L : -1);
   int d = r.dof >= 0 ? r.dof : 0;
   r.depth = m.dof_depth[d];
@@ -407,7 +409,7 @@ struct KinK {
   V3 ipos; Quat iquat;         // inertial frame, principal inertias (centre-of-mass stage)
   real inertia[3];
 };
-__device__ __forceinline__ void load_kin_constants(const DevModel& m, int L, const LaneK& K, KinK& k) {
+__host__ __device__ __forceinline__ void load_kin_constants(const DevModel& m, int L, const LaneK& K, KinK& k) {
   const int b = L < m.nbody ? L : 0;
   k.bpos = ld3(m.body_kpos + 3 * b);
   k.bquat = ldq(m.body_kquat + 4 * b);
@@ -503,7 +505,7 @@ __device__ inline void stage_kinematics(const DevModel& m, const Lay& l, const L
 
 // (lane as one coordinate of a tree's centre of mass, lane as joint: fetched while the kinematics run)
 struct ComK { int root, n; real mass; int j_body, j_dofadr, j_type; };
-__device__ __forceinline__ void load_com_constants(const DevModel& m, int L, ComK& c) {
+__host__ __device__ __forceinline__ void load_com_constants(const DevModel& m, int L, ComK& c) {
   const int t = L < 3 * m.ntree ? L / 3 : 0;
   c.root = m.tree_rootbody[t];
   c.n = m.body_subtreenum[c.root];
@@ -625,7 +627,7 @@ __device__ inline void stage_crb(const DevModel& m, const Lay& l, const LaneK& K
 enum { FACTOR_AHEAD = 4 };
 // (q / adr0 / num: the lane's tree in pass 0; q1 / adr1 / num1: in pass 1, when the model has more than two trees)
 struct FactorRing { unsigned q[FACTOR_AHEAD], q1[FACTOR_AHEAD]; int adr0, num, adr1, num1; };
-__device__ __forceinline__ void factor_ring_load(const DevModel& m, int L, int ps, unsigned* q, int& adr0, int& num) {
+__host__ __device__ __forceinline__ void factor_ring_load(const DevModel& m, int L, int ps, unsigned* q, int& adr0, int& num) {
   const int groups = m.ntree > 1 ? 2 : 1, tree = ps * groups + L / (64 / groups);
   adr0 = m.tree_dofadr[tree < m.ntree ? tree : 0];
   num = tree < m.ntree ? m.tree_dofnum[tree] : 0;
@@ -636,7 +638,7 @@ __device__ __forceinline__ void factor_ring_load(const DevModel& m, int L, int p
     q[u] = kk >= 0 ? (unsigned)sched[kk * 64] : 0u;
   }
 }
-__device__ __forceinline__ void factor_prefetch(const DevModel& m, int L, FactorRing& r) {
+__host__ __device__ __forceinline__ void factor_prefetch(const DevModel& m, int L, FactorRing& r) {
   factor_ring_load(m, L, 0, r.q, r.adr0, r.num);
   if (m.npass > 1) factor_ring_load(m, L, 1, r.q1, r.adr1, r.num1);
   else {
@@ -814,7 +816,7 @@ struct GeomK {
   int chunk_info;                         // lane c: kind and tree pair of chunk c of the pair list
   int tp_a, tp_b; real tp_reach;          // lane k: root bodies and reach of tree pair k
 };
-__device__ __forceinline__ void load_geom_constants(const DevModel& m, int L, GeomK& g) {
+__host__ __device__ __forceinline__ void load_geom_constants(const DevModel& m, int L, GeomK& g) {
   const int i = L < m.ngeom ? L : 0;
   g.body = m.geom_bodyid[i];
   g.pos = ld3(m.geom_pos + 3 * i);
@@ -1101,7 +1103,7 @@ struct ActK {
   int limited; real lo, hi, gear;                       // the lane's dof's actuator (K.d_act >= 0)
   int j_limited, j_type, j_qposadr; real j_range, j_margin;   // limit item L: joint L >> 1, lower side first
 };
-__device__ __forceinline__ void load_act_constants(const DevModel& m, int L, const LaneK& K, ActK& A) {
+__host__ __device__ __forceinline__ void load_act_constants(const DevModel& m, int L, const LaneK& K, ActK& A) {
   const int u = K.d_act >= 0 ? K.d_act : 0;
   A.limited = m.nu > 0 ? m.act_ctrllimited[u] : 0;
   A.lo = m.nu > 0 ? m.act_ctrlrange[2 * u] : 0.0;
@@ -1113,6 +1115,74 @@ __device__ __forceinline__ void load_act_constants(const DevModel& m, int L, con
   A.j_qposadr = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
   A.j_range = m.njnt > 0 ? m.jnt_range[2 * j + (side + 1) / 2] : 0.0;
   A.j_margin = m.njnt > 0 ? m.jnt_margin[j] : 0.0;
+}
+
+// ------------------------------------------------------------------ lane records
+// Everything above that a lane reads from the MODEL for itself -- its body's, dof's, joint's, geom's records, its rows of
+// the solve / factor schedules, its slice of the structure tables -- depends on the lane id alone, never on the copy.
+// Fetched field by field it was ninety loads per wave and launch with three to five vector instructions of address
+// arithmetic each (a 64-bit base + constant + 4 x lane per table), a quarter of them behind another load (joint of the
+// body -> type of that joint -> reference position of its coordinate): 740 vector instructions of the prologue, a tenth
+// of them doing anything.  mjrl_create runs the same loader functions on the host, once, for lanes 0..63 and lays the
+// results out as records: quad q of a group of lane L at int4[(first quad of the group + q) * 64 + L] -- a wave's fetch of
+// one quad is 1 KB of consecutive bytes, the address one shift of the lane id, and one group costs ceil(bytes / 16)
+// 16-byte loads.  Groups are fetched where their fields used to be (the prologue; ahead of the geom / factor / smooth /
+// integrator stages).
+struct EulerJ { int qa, da, jtype; };                  // lane as joint: what the integrator reads (load_euler_constants)
+struct RecA { LaneK K; RowK RK; TabRegs TR; KinK KK; ComK CK; };
+struct RecG { GeomK GK; };
+struct RecR { FactorRing ring; };
+struct RecC { ActK AK; };
+struct RecE { EulerJ EJ; };
+template <typename T> constexpr int rec_quads() { return (int)((sizeof(T) + 15) / 16); }
+enum { REC_A = 0, REC_G = REC_A + rec_quads<RecA>(), REC_R = REC_G + rec_quads<RecG>(), REC_C = REC_R + rec_quads<RecR>(),
+       REC_E = REC_C + rec_quads<RecC>(), REC_QUADS = REC_E + rec_quads<RecE>() };
+enum { LANE_REC_INTS = REC_QUADS * 64 * 4 };
+
+// host: the table of a model (LANE_REC_INTS ints, zero-filled by the caller)
+inline void build_lane_records(const DevModel& m, const Lay& l, int32_t* out) {
+  auto put = [&](int first, const void* rec, size_t nbytes, int L) {
+    const int32_t* w = (const int32_t*)rec;
+    for (size_t i = 0; i < nbytes / 4; i++) out[((size_t)(first + i / 4) * 64 + L) * 4 + i % 4] = w[i];
+  };
+  for (int L = 0; L < 64; L++) {
+    // (zero-filled first: padding bytes of the structs must not differ from run to run)
+    RecA A; __builtin_memset(&A, 0, sizeof(A));
+    load_lane_constants(m, L, A.K);
+    load_row_constants(m, l, L, A.RK);
+    tab_issue(m, L, A.TR);
+    load_kin_constants(m, L, A.K, A.KK);
+    load_com_constants(m, L, A.CK);
+    put(REC_A, &A, sizeof(A), L);
+    RecG G; __builtin_memset(&G, 0, sizeof(G));
+    load_geom_constants(m, L, G.GK);
+    put(REC_G, &G, sizeof(G), L);
+    RecR R; __builtin_memset(&R, 0, sizeof(R));
+    factor_prefetch(m, L, R.ring);
+    put(REC_R, &R, sizeof(R), L);
+    RecC C; __builtin_memset(&C, 0, sizeof(C));
+    load_act_constants(m, L, A.K, C.AK);
+    put(REC_C, &C, sizeof(C), L);
+    RecE E; __builtin_memset(&E, 0, sizeof(E));
+    const int j = L < m.njnt ? L : 0;
+    E.EJ.qa = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
+    E.EJ.da = m.njnt > 0 ? m.jnt_dofadr[j] : 0;
+    E.EJ.jtype = m.njnt > 0 ? m.jnt_type[j] : -1;
+    put(REC_E, &E, sizeof(E), L);
+  }
+}
+
+// device: one group of the lane's records into registers
+typedef int rec_quad __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ void fetch_lane_record(const int32_t* table, int first, int L, T& out) {
+  static_assert(sizeof(T) % 4 == 0, "records are whole words");
+  constexpr int N = rec_quads<T>();
+  const rec_quad MJRL_GLOBAL* t = (const rec_quad MJRL_GLOBAL*)table + (size_t)first * 64 + L;
+  rec_quad q[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) q[k] = t[64 * k];
+  __builtin_memcpy(&out, q, sizeof(T));
 }
 
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
@@ -2784,11 +2854,12 @@ struct EulerK {
 __device__ __forceinline__ void load_euler_constants(const DevModel& m, const StepArgs& a, int L, EulerK& E) {
   // (fetched whether or not this launch integrates: filled in one branch and zeroed in the other, the ring became an
   // object on the stack addressed through a per-branch offset)
-  factor_prefetch(m, L, E.ring);
-  const int j = L < m.njnt ? L : 0;
-  E.qa = m.njnt > 0 ? m.jnt_qposadr[j] : 0;
-  E.da = m.njnt > 0 ? m.jnt_dofadr[j] : 0;
-  E.jtype = m.njnt > 0 ? m.jnt_type[j] : -1;
+  RecR RR;
+  fetch_lane_record(a.lane_rec, REC_R, L, RR);
+  E.ring = RR.ring;
+  RecE RE;
+  fetch_lane_record(a.lane_rec, REC_E, L, RE);
+  E.qa = RE.EJ.qa; E.da = RE.EJ.da; E.jtype = RE.EJ.jtype;
   const int nobs = a.n_agent * a.obs_dim;
 #pragma unroll
   for (int u = 0; u < 2; u++) E.gcode[u] = (a.obs && 64 * u < nobs) ? a.gather[64 * u + L < nobs ? 64 * u + L : 0] : -1;
@@ -2948,16 +3019,14 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
   if (a.lpt_count_in) my_count = a.lpt_count_in[L & (LPT_BUCKETS - 1)];
   Lay l;
   make_layout(m, l);
-  LaneK K;
-  load_lane_constants(m, L, K);
-  RowK RK;
-  load_row_constants(m, l, L, RK);
-  TabRegs TR;
-  tab_issue(m, L, TR);
-  KinK KK;
-  load_kin_constants(m, L, K, KK);
-  ComK CK;
-  load_com_constants(m, L, CK);
+  // the lane's own records of the model (lane records: one group of 16-byte loads instead of ninety table reads)
+  RecA RA;
+  fetch_lane_record(a.lane_rec, REC_A, L, RA);
+  const LaneK& K = RA.K;
+  RowK RK = RA.RK;
+  const TabRegs& TR = RA.TR;
+  const KinK& KK = RA.KK;
+  const ComK& CK = RA.CK;
   // (the dispatch tables of the launch after next are cleared here, before a workgroup without a copy can leave)
   if (a.lpt_count_clear && wv::env_index() == 0 && L < LPT_BUCKETS) a.lpt_count_clear[L] = 0;
   if (a.lpt_mask_clear && wv::env_index() < a.lpt_words && L < LPT_BUCKETS)
@@ -3091,10 +3160,12 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
     MJ_STAMP(ST_COM)
     // (model constants of a stage are fetched a stage or two ahead of it: with two waves on a SIMD nothing else hides a
     // round trip to L2 at the head of a stage)
-    GeomK GK;
-    load_geom_constants(m, MJ_L, GK);
-    FactorRing ring;
-    factor_prefetch(m, MJ_L, ring);
+    RecG RG;
+    fetch_lane_record(a.lane_rec, REC_G, MJ_L, RG);
+    const GeomK& GK = RG.GK;
+    RecR RR;
+    fetch_lane_record(a.lane_rec, REC_R, MJ_L, RR);
+    const FactorRing& ring = RR.ring;
     MKeep Mk;
     stage_crb(m, l, K, S, MJ_L);
     mkeep_take(m, l, S, MJ_L, Mk);
@@ -3103,8 +3174,9 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
     MJ_STAMP(ST_FACTOR)
     stage_geoms(m, l, GK, S, MJ_L);
     MJ_STAMP(ST_GEOM)
-    ActK AK;
-    load_act_constants(m, MJ_L, K, AK);
+    RecC RC;
+    fetch_lane_record(a.lane_rec, REC_C, MJ_L, RC);
+    const ActK& AK = RC.AK;
     stage_collision(m, l, GK, S, MJ_L);
     MJ_STAMP(ST_COLLIDE)
     stage_velocity(m, l, K, S, MJ_L, false);
@@ -3538,7 +3610,7 @@ constexpr unsigned long long step_args_layout() {
   MJ_LAYOUT_FIELD(dbg) MJ_LAYOUT_FIELD(forward_only) MJ_LAYOUT_FIELD(reset_mask) MJ_LAYOUT_FIELD(auto_mask)
   MJ_LAYOUT_FIELD(reset_sens) MJ_LAYOUT_FIELD(rk) MJ_LAYOUT_FIELD(stats) MJ_LAYOUT_FIELD(stamps) MJ_LAYOUT_FIELD(prog_i)
   MJ_LAYOUT_FIELD(n_slot) MJ_LAYOUT_FIELD(store) MJ_LAYOUT_FIELD(tag_ref) MJ_LAYOUT_FIELD(env_base) MJ_LAYOUT_FIELD(variant)
-  MJ_LAYOUT_FIELD(variant_seed) MJ_LAYOUT_FIELD(frames) MJ_LAYOUT_FIELD(scene) MJ_LAYOUT_FIELD(few)
+  MJ_LAYOUT_FIELD(variant_seed) MJ_LAYOUT_FIELD(frames) MJ_LAYOUT_FIELD(scene) MJ_LAYOUT_FIELD(few) MJ_LAYOUT_FIELD(lane_rec)
   MJ_LAYOUT_FIELD(lpt_count_in) MJ_LAYOUT_FIELD(lpt_mask_clear) MJ_LAYOUT_FIELD(lpt_words) MJ_LAYOUT_FIELD(overflow)
   MJ_LAYOUT_FIELD(timeline) MJ_LAYOUT_FIELD(stop_after)
 #undef MJ_LAYOUT_FIELD

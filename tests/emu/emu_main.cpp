@@ -208,6 +208,9 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.lpt_count_in = g_lpt_count; a.lpt_mask_in = g_lpt_mask; a.lpt_words = g_lpt_words;
   a.tag_adr = g_tag_adr; a.tag_num = g_tag_num; a.tag_ref = g_tag_ref; a.env_base = g_env_base;
   a.max_steps = max_steps; a.n_env = 1; a.few = g_few;
+  std::vector<int32_t> lane_rec((size_t)mj::LANE_REC_INTS, 0);        // (mjrl_create builds this table once per handle)
+  mj::build_lane_records(m, l, lane_rec.data());
+  a.lane_rec = lane_rec.data();
   a.dbg = dbg; a.dbg_stage = dbg_stage; a.forward_only = forward_only;
   emu::cur_env = 0;
   // one frame per wave run, like the launches of launch_step in mjrl_capi.hip
