@@ -106,7 +106,8 @@ def cpu_share(limit=None):
     return max(1, min(n, limit or 16))
 
 
-def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seconds=8.0, language=False, workers=None):
+def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seconds=8.0, language=False, workers=None,
+                 single_only=False):
     """The step on the host cores, on a bounded sample of the same workload: worker w steps GLOBAL env id w with the
     action stream the GPU feeds that copy (same Philox key and counter), episodes of 1024 steps from reset, for
     `seconds` of wall time; once on one core, once with one process per core of this job's CPU share (cpu_share).  kind "reference": the box has the
@@ -170,6 +171,12 @@ def cpu_baseline(level_file, blob_bytes, scatter, n_agent, act_dim, n_phys, seco
         error, have_mujoco = repr(exc), False
         run_one(q, 0, seconds)
     n1, t1 = q.get()
+    if single_only:              # config 1: the reference's own shape -- one env, one thread
+        found = importlib.util.find_spec("mujoco") is not None
+        return {"value": n1 / t1, "unit": "env-steps/s", "cores": 1, "kind": "reference" if have_mujoco else "port",
+                "sample": f"{'mujoco' if have_mujoco else 'CPU oracle (oracle/ora_step.c)'}; 1 process x 1 env copy x "
+                          f"{seconds:.0f} s of {os.path.basename(level_file)}, episodes of {EPISODE} steps from reset, "
+                          "step + numpy obs gather", "mujoco_found": found}
     cores = cpu_share(workers)
     procs = [ctx.Process(target=run_one, args=(q, i, seconds)) for i in range(cores)]
     for p in procs:
@@ -332,6 +339,12 @@ def launch_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the CPU baseline of the line: measured HERE, in the parent that never touches a GPU, before the ranks exist (so that
+    # it has the host cores to itself), and handed to rank 0 through the environment
+    args = parse_args()
+    if not args.no_cpu_baseline and os.environ.get("MJRL_BENCH_REHEARSAL", "") != "cpu":
+        entry.load_package()
+        env["MJRL_BENCH_CPU_BASELINE"] = json.dumps(host_cpu_baseline(args))
     return subprocess.call(cmd, env=env)
 
 
@@ -346,6 +359,56 @@ def host_tables(level_file, agents):
         tables.get_action_space_mujoco(a)
         index[a] = list(tables.agents_action_index[a])
     return blob_mod.pack(mjcf.compile_mjcf(level_file)), index
+
+
+def host_cpu_baseline(args):
+    """The `cpu_baseline` object of the bench line for the workload `args` names.  Touches no GPU."""
+    from mjrl_amd import levels
+    work = WORKLOADS[args.level]
+    agents, level_file = work["agents"], levels.level_path(work["level"])
+    n_agent = len(agents)
+    language = n_agent == 2 and not args.no_language and not work.get("cameras")
+    packed, index = host_tables(level_file, agents)
+    n_phys0 = max(len(index[a]) for a in agents)
+    act_dim0 = n_phys0 + (1 if language else 0)
+    scatter = np.full((n_agent, act_dim0), -1, np.int64)
+    for k, a in enumerate(agents):
+        scatter[k, :len(index[a])] = index[a]
+    return cpu_baseline(level_file, packed, scatter, n_agent, act_dim0, n_phys0, language=language, workers=args.cpu_workers)
+
+
+def config_one_cpu(seconds=4.0):
+    """BASELINE configs[0], CPU side: single_agent.xml, 1 env copy, one thread."""
+    from mjrl_amd import levels
+    level_file = levels.level_path("single_agent.xml")
+    packed, index = host_tables(level_file, ["sender"])
+    n_phys = len(index["sender"])
+    scatter = np.array([index["sender"]], np.int64)
+    return cpu_baseline(level_file, packed, scatter, 1, n_phys, n_phys, seconds=seconds, single_only=True)
+
+
+def config_one_product(episodes=3):
+    """BASELINE configs[0], product side: the drop-in at numEnvs = 1 through the reference's own loop
+    (benchmarking/different_env_configs/fps_benchmark.py:52-62: reset, then 1024 x step({agent: action_space.sample()}),
+    FPS = 1024 / elapsed; skipFrames = 1 so that the physics runs): dict API, one launch and one synchronous
+    copy back per step."""
+    from mjrl_amd import levels
+    from mjrl_amd.mujoco_rl import MuJoCoRL
+    env = MuJoCoRL({"xmlPath": levels.level_path("single_agent.xml"), "agents": ["sender"], "rewardFunctions": [],
+                    "doneFunctions": [], "skipFrames": 1, "environmentDynamics": [], "freeJoint": False,
+                    "renderMode": False, "maxSteps": EPISODE})
+    fps = []
+    for _ in range(episodes):
+        env.reset()
+        t0 = time.perf_counter()
+        for _ in range(EPISODE):
+            env.step({"sender": env.action_space("sender").sample()})
+        fps.append(EPISODE / (time.perf_counter() - t0))
+    kernel = env._handle.kernel
+    few = env._handle.size("few")
+    env.close()
+    return {"value": float(np.median(fps)), "unit": "env-steps/s", "episodes": episodes, "api": "MuJoCoRL.step (dict of agents)",
+            "kernel": kernel, "few_copies_build": bool(few)}
 
 
 def main():
@@ -377,16 +440,16 @@ def main():
 
     # The CPU baseline runs FIRST, before this process makes its first GPU call: its workers are forked from a process
     # without HIP state (round 2 forked them from one whose runtime was live).
-    cpu_line = None
-    if world == 1 and not args.no_cpu_baseline and not on_cpu:
-        packed, index = host_tables(level_file, agents)
-        n_phys0 = max(len(index[a]) for a in agents)
-        act_dim0 = n_phys0 + (1 if language else 0)
-        scatter = np.full((n_agent, act_dim0), -1, np.int64)
-        for k, a in enumerate(agents):
-            scatter[k, :len(index[a])] = index[a]
-        cpu_line = cpu_baseline(level_file, packed, scatter, n_agent, act_dim0, n_phys0, language=language,
-                                workers=args.cpu_workers)
+    # (N > 1: the launcher parent of `python bench.py --gpus N` has measured it before it started the ranks; under an
+    # external launcher rank 0 measures it here, before it joins the rendezvous, while the other ranks wait there)
+    cpu_line, config_one = None, None
+    if rank == 0 and not args.no_cpu_baseline and not on_cpu:
+        if os.environ.get("MJRL_BENCH_CPU_BASELINE"):
+            cpu_line = json.loads(os.environ["MJRL_BENCH_CPU_BASELINE"])
+        else:
+            cpu_line = host_cpu_baseline(args)
+        if world == 1 and args.level == "two_agent" and not args.no_extra_configs:
+            config_one = {"cpu": config_one_cpu()}
 
     import torch
     dev = None
@@ -588,6 +651,14 @@ def main():
                 "mean_solver_sweeps": float(stats_x[:, 2].mean()), "cap_overflow_frames": over,
                 "roofline": roofline_of(w, level_name, b, lang, envs, args.extra_steps, wall_x, kms_x)})
             b.close()
+        if config_one is not None:
+            # BASELINE configs[0]: what the drop-in costs at numEnvs = 1 (one lone wave per step, a synchronous launch, the
+            # dict API) next to one CPU core running the same level
+            config_one["product"] = config_one_product()
+            extra.insert(0, {"name": "config 1", "workload": "single_agent.xml (benchmarking/levels/SingleAgentModel.xml), "
+                             "agents [sender], 1 env copy, skipFrames=1, the loop of fps_benchmark.py:52-62",
+                             "level": "single_agent", "envs_per_gpu": 1, **config_one,
+                             "value": config_one["product"]["value"], "unit": "env-steps/s"})
         line["configs"] = extra
     if rank == 0:
         print(json.dumps(line), flush=True)

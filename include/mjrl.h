@@ -114,6 +114,15 @@ int mjrl_reset_device(mjrl_env* env, const uint8_t* d_mask, double* d_obs);
  * (typically the done flags of the previous step); NULL turns it off.  The reset observation is not produced: the
  * step returns the observation after the first step of the new episode. */
 int mjrl_set_step_reset_mask(mjrl_env* env, const uint8_t* d_mask);
+/* I/O layout of the step entries for single-agent consumers (the vector-env adapter over wrappers.py:12-82's use
+ * case: one driven agent).  agent >= 0: `actions` holds that agent's row only, [n_env][act_dim] -- the other agents act
+ * with 0 --, and `obs` receives only its row, [n_env][obs_dim]; obs_f32 != 0: observations are written as float (half
+ * the bytes a host caller pulls over PCIe through the pinned buffers).  reward / term / trunc stay [n_env][n_agent].
+ * Holds for mjrl_step_device, mjrl_step_pinned (the pinned buffers keep their size; the layout's rows come first) and the
+ * reset observations of mjrl_reset / mjrl_reset_device; mjrl_step_host refuses a non-default layout.  agent -1,
+ * obs_f32 0 restores the layouts documented at those entries. */
+int mjrl_set_io_layout(mjrl_env* env, int agent, int obs_f32);
+
 /* (round 3) A mask byte of 2 resets the copy WITHOUT stepping it: no physics frame runs for it in that step, its rows of
  * the step's outputs hold the reset observation (what reset() returns, mujoco_rl.py:314; slots owned by fused dynamics and
  * camera latents: 0 / the encoding of the reset state's image), reward 0, termination and truncation clear; its step

@@ -22,7 +22,7 @@ SYMBOLS = [
     "mjrl_render_device", "mjrl_render_host", "mjrl_load_kernel", "mjrl_cap_overflows", "mjrl_step_timeline",
     "mjrl_step_truncated", "mjrl_host_buffers", "mjrl_step_pinned", "mjrl_set_autoreset",
     "mjrl_reset_device", "mjrl_set_step_reset_mask", "mjrl_set_tag_tables", "mjrl_set_env_base", "mjrl_set_variants",
-    "mjrl_encoder_load", "mjrl_encode_device", "mjrl_encode_host", "mjrl_set_camera_obs",
+    "mjrl_encoder_load", "mjrl_encode_device", "mjrl_encode_host", "mjrl_set_camera_obs", "mjrl_set_io_layout",
 ]
 
 _lib = None
@@ -83,6 +83,7 @@ def load():
     L.mjrl_host_buffers.argtypes = [vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_void_p)] * 5
     L.mjrl_step_pinned.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.mjrl_set_autoreset.argtypes = [vp, ctypes.c_int]
+    L.mjrl_set_io_layout.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     _lib = L
     return L
 
@@ -116,6 +117,7 @@ class Handle:
         if rc:
             raise Exception(f"mjrl_create failed ({rc}): {self._lib.mjrl_last_error(None).decode()}")
         self.n_env = int(n_env)
+        self.io_agent, self.obs_f32 = -1, False
         self.kernel = "generic"
         if specialize is None:
             specialize = os.environ.get("MJRL_SPECIALIZE", "1") != "0"
@@ -284,6 +286,12 @@ class Handle:
         autoreset); 2: it is reset and stepped in that launch (the reference's ``env.reset(); env.step(a)``)."""
         self._check(self._lib.mjrl_set_autoreset(self._h, int(mode)))
 
+    def set_io_layout(self, agent: int = -1, obs_f32: bool = False):
+        """One agent's rows only (``actions [n_env, act_dim]``, ``obs [n_env, obs_dim]``) and / or float32 observations
+        for the device and pinned step entries (mjrl_set_io_layout); ``(-1, False)`` is the default layout."""
+        self._check(self._lib.mjrl_set_io_layout(self._h, int(agent), int(bool(obs_f32))))
+        self.io_agent, self.obs_f32 = int(agent), bool(obs_f32)
+
     def step_device(self, d_actions, act_dim, skip_frames, d_obs=None, d_reward=None, d_term=None, d_trunc=None):
         """All pointers are integer device addresses (e.g. ``tensor.data_ptr()``) or None."""
         c = lambda p: ctypes.c_void_p(p or 0)
@@ -304,8 +312,11 @@ class Handle:
         def view(ptr, ctype, shape):
             n = int(np.prod(shape))
             return np.ctypeslib.as_array((ctype * n).from_address(ptr.value)).reshape(shape)
-        return (view(ptrs[0], ctypes.c_double, (self.n_env, n_agent, max(int(act_dim), 1))),
-                view(ptrs[1], ctypes.c_double, (self.n_env, n_agent, obs_dim)),
+        # (with a one-agent / float32 layout the kernel uses the head of the same buffers: the views have the layout's shape)
+        act_shape = (self.n_env, n_agent, max(int(act_dim), 1)) if self.io_agent < 0 else (self.n_env, max(int(act_dim), 1))
+        obs_shape = (self.n_env, n_agent, obs_dim) if self.io_agent < 0 else (self.n_env, obs_dim)
+        return (view(ptrs[0], ctypes.c_double, act_shape),
+                view(ptrs[1], ctypes.c_float if self.obs_f32 else ctypes.c_double, obs_shape),
                 view(ptrs[2], ctypes.c_double, (self.n_env, n_agent)),
                 view(ptrs[3], ctypes.c_uint8, (self.n_env, n_agent)),
                 view(ptrs[4], ctypes.c_uint8, (self.n_env, n_agent)))

@@ -63,7 +63,8 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
                                   int* timestep, const unsigned char* mask, int n_env, double* store, int store_per_env,
                                   const double* warm0, const double* sens0, const int32_t* gather, int n_agent, int obs_dim,
                                   double* obs, int* variant, int* episode, int n_variant, unsigned long long variant_seed,
-                                  int env_base, unsigned char* auto_mask, double* scene, const double* scene0) {
+                                  int env_base, unsigned char* auto_mask, double* scene, const double* scene0, int io_agent,
+                                  int obs_f32) {
   int env = blockIdx.x;
   if (env >= n_env || (mask && !mask[env])) return;
   // (the ray caster's scene row: the frames mj_forward leaves at the reset state)
@@ -87,14 +88,17 @@ __global__ void mjrl_reset_kernel(DevModel m, double* qpos, double* qvel, double
   if (sens0) for (int i = threadIdx.x; i < m.nsensordata; i += blockDim.x) sens[(size_t)env * m.nsensordata + i] = sens0[i];
   if (threadIdx.x == 0) timestep[env] = 0;
   if (obs && gather) {
-    for (int it = threadIdx.x; it < n_agent * obs_dim; it += blockDim.x) {
-      int code = gather[it];
+    // (rows in the layout of the step's: every agent's as float64, or one agent's / as float -- mjrl_set_io_layout)
+    const int row = io_agent < 0 ? n_agent * obs_dim : obs_dim, g0 = io_agent < 0 ? 0 : io_agent * obs_dim;
+    for (int it = threadIdx.x; it < row; it += blockDim.x) {
+      int code = gather[g0 + it];
       double v = 0;
       if (code >= 0) {
         int kind = code >> 24, idx = code & 0xFFFFFF;
         v = kind == 0 ? (sens0 ? sens0[idx] : 0.0) : (kind == 1 ? m.qpos0[idx] : 0.0);
       }
-      obs[(size_t)env * n_agent * obs_dim + it] = v;
+      if (obs_f32) ((float*)obs)[(size_t)env * row + it] = (float)v;
+      else obs[(size_t)env * row + it] = v;
     }
   }
 }
@@ -424,6 +428,7 @@ struct mjrl_env {
   const unsigned char* step_reset_mask = nullptr;   // caller-owned device mask of the in-launch reset (mjrl_set_step_reset_mask)
   unsigned char* auto_mask = nullptr;               // [n_env] "the copy's episode ended in its last step" (mjrl_set_autoreset)
   int auto_mode = 0;
+  int io_agent = -1, obs_f32 = 0;   // mjrl_set_io_layout
   // tables
   int n_agent = 0, obs_dim = 0, scatter_mode = 0, max_steps = 1024;
   std::vector<int32_t> h_gather;                 // [n_agent][obs_dim]
@@ -514,7 +519,7 @@ static int launch_reset(mjrl_env* e, const unsigned char* d_mask, double* d_obs 
   hipLaunchKernelGGL(mjrl_reset_kernel, dim3(e->n_env), dim3(64), 0, e->stream, e->dm, e->qpos, e->qvel, e->ctrl, e->warm,
                      e->sens, e->timestep, d_mask, e->n_env, e->store, e->n_agent * e->n_slot, e->reset_warm, e->reset_sens,
                      e->d_gather, e->n_agent, e->obs_dim, d_obs, e->variant, e->episode, e->n_variant, e->variant_seed,
-                     e->env_base, e->auto_mask, e->scene_on ? e->scene : nullptr, e->reset_scene);
+                     e->env_base, e->auto_mask, e->scene_on ? e->scene : nullptr, e->reset_scene, e->io_agent, e->obs_f32);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }
@@ -1143,6 +1148,18 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
   a.reset_scene = e->reset_scene;
   a.few = e->few ? 1 : 0;
   a.lane_rec = e->d_lane_rec;
+  a.io_agent1 = e->io_agent + 1; a.obs_f32 = e->obs_f32;
+  if (e->io_agent >= 0 || e->obs_f32) {
+    if (e->n_cam_obs) MJRL_FAIL(e, 3, "step: camera latents in the observation need the default I/O layout (mjrl_set_io_layout)");
+    if (e->io_agent >= e->n_agent) MJRL_FAIL(e, 3, "step: I/O layout names agent %d of %d", e->io_agent, e->n_agent);
+    if (e->io_agent >= 0) {
+      // (the one-agent action row is read lane by lane; a fused program must be one the kernel stages in LDS)
+      const int n_act_row = e->n_agent * act_dim, n_store_row = e->n_agent * e->n_slot, n_op = forward_only ? 0 : e->n_op;
+      const bool staged = n_op == 0 || (n_act_row + n_store_row + 8 * n_op + e->n_agent <= 4 * e->hm.nv && 8 * n_op <= 64);
+      if (n_act_row > 64 || !staged)
+        MJRL_FAIL(e, 3, "step: the one-agent I/O layout needs n_agent x act_dim <= 64 and a fused program small enough to be staged");
+    }
+  }
   a.auto_mask = forward_only ? nullptr : e->auto_mask;
   a.auto_mode = e->auto_mode;
   a.prog_i = e->d_prog_i; a.prog_f = e->d_prog_f; a.n_op = forward_only ? 0 : e->n_op; a.n_slot = e->n_slot;
@@ -1205,6 +1222,17 @@ static int launch_step(mjrl_env* e, const double* d_actions, int act_dim, int sk
     if (int rc = mjrl_render_device(e, enc::IMG, enc::IMG, e->enc_rgb)) return rc;
     if (int rc = launch_encoder(e, e->enc_rgb, e->n_env * e->hm.ncam, nullptr, d_obs, e->enc_obs_row)) return rc;
   }
+  return 0;
+}
+
+int mjrl_set_io_layout(mjrl_env* e, int agent, int obs_f32) {
+  MJRL_ENTER(e);
+  if (agent < -1 || (e->n_agent && agent >= e->n_agent)) MJRL_FAIL(e, 2, "set_io_layout: agent %d out of range", agent);
+  if ((agent >= 0 || obs_f32) && e->n_cam_obs)
+    MJRL_FAIL(e, 3, "set_io_layout: camera latents in the observation need the default layout");
+  MJRL_HIP(e, hipStreamSynchronize(e->stream));
+  e->io_agent = agent;
+  e->obs_f32 = obs_f32 ? 1 : 0;
   return 0;
 }
 
@@ -1352,6 +1380,8 @@ static int ensure_staging(mjrl_env* e, int act_dim) {
 int mjrl_step_host(mjrl_env* e, const double* h_actions, int act_dim, int skip_frames, double* h_obs, double* h_reward,
                    uint8_t* h_term, uint8_t* h_trunc) {
   MJRL_ENTER(e);
+  if (e->io_agent >= 0 || e->obs_f32)
+    MJRL_FAIL(e, 3, "step_host copies buffers of the default layout; with mjrl_set_io_layout use mjrl_step_pinned / mjrl_step_device");
   if (int rc = ensure_staging(e, act_dim)) return rc;
   size_t na = (size_t)e->n_env * std::max(e->n_agent, 1);
   if (h_actions)

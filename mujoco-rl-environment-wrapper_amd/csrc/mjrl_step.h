@@ -196,6 +196,12 @@ struct StepArgs {
   // qpos.  reset_scene [scene_doubles] is the row of the reset image, for copies that are reset without a physics frame.
   real* scene;
   const real* reset_scene;
+  // I/O layout for single-agent consumers (mjrl_set_io_layout; the vector-env adapter): io_agent >= 0 -- the action buffer
+  // holds that agent's row only, [n_env][act_dim] (the other agents' slots read 0), and only its observation row is
+  // written, [n_env][obs_dim]; obs_f32 -- observations are stored as float (half the bytes a host caller pulls over
+  // PCIe).  Rewards and flags stay [n_env][n_agent].  (io_agent1 = agent + 1: a zero-filled StepArgs has the layouts
+  // documented at the fields above.)
+  int io_agent1, obs_f32;
   // The lanes' records of the model (build_lane_records: LANE_REC_INTS ints, built once per handle by mjrl_create)
   const int32_t* lane_rec;
   // The batch leaves every SIMD at most one wave (n_env <= 4 x the CUs, mjrl_create): the solver forms that need more
@@ -1117,6 +1123,34 @@ __host__ __device__ __forceinline__ void load_act_constants(const DevModel& m, i
   A.j_margin = m.njnt > 0 ? m.jnt_margin[j] : 0.0;
 }
 
+// What the sensor stage reads from the model for the lane: as sensor (lane s: the sensor's record, its site's, the
+// site's body) and as ray target (lane g: geom g's record for the rangefinders).
+struct SensK {
+  int site, adr, type, body;          // sensor s0 + L: its site, its address in sensordata, its type, the site's body
+  real cut, size;                     // its cutoff, the site's size[0] (touch sensors)
+  V3 pos; Quat quat;                  // the site's frame in its body
+  int g_body, g_type;                 // geom L as a ray target
+  real g_alpha, g_rb;
+  V3 g_size, g_pos; Quat g_quat;
+};
+__host__ __device__ __forceinline__ void load_sensor_constants(const DevModel& m, int s0, int L, SensK& k) {
+  const int sl = s0 + L < m.nsensor ? s0 + L : 0;
+  k.site = m.nsensor > 0 ? m.sensor_objid[sl] : 0; k.adr = m.nsensor > 0 ? m.sensor_adr[sl] : 0;
+  k.type = m.nsensor > 0 ? m.sensor_type[sl] : -1;
+  k.cut = m.nsensor > 0 ? m.sensor_cutoff[sl] : 0.0;
+  const int gl = L < m.ngeom ? L : 0;
+  k.g_alpha = m.geom_rgba[4 * gl + 3];
+  k.g_body = m.geom_bodyid[gl]; k.g_type = m.geom_type[gl];
+  k.g_rb = m.geom_rbound[gl];
+  k.g_size = ld3(m.geom_size + 3 * gl); k.g_pos = ld3(m.geom_pos + 3 * gl);
+  k.g_quat = ldq(m.geom_quat + 4 * gl);
+  k.body = m.nsite > 0 ? m.site_bodyid[k.site] : 0;
+  k.pos = m.nsite > 0 ? ld3(m.site_pos + 3 * k.site) : v3(0, 0, 0);
+  if (m.nsite > 0) k.quat = ldq(m.site_quat + 4 * k.site);
+  else { k.quat.w = 1; k.quat.x = k.quat.y = k.quat.z = 0; }
+  k.size = m.nsite > 0 ? m.site_size[3 * k.site] : 0.0;
+}
+
 // ------------------------------------------------------------------ lane records
 // Everything above that a lane reads from the MODEL for itself -- its body's, dof's, joint's, geom's records, its rows of
 // the solve / factor schedules, its slice of the structure tables -- depends on the lane id alone, never on the copy.
@@ -1134,9 +1168,10 @@ struct RecG { GeomK GK; };
 struct RecR { FactorRing ring; };
 struct RecC { ActK AK; };
 struct RecE { EulerJ EJ; };
+struct RecS { SensK SK; };                             // (sensors 0..63 and geoms 0..63; later chunks read the model)
 template <typename T> constexpr int rec_quads() { return (int)((sizeof(T) + 15) / 16); }
 enum { REC_A = 0, REC_G = REC_A + rec_quads<RecA>(), REC_R = REC_G + rec_quads<RecG>(), REC_C = REC_R + rec_quads<RecR>(),
-       REC_E = REC_C + rec_quads<RecC>(), REC_QUADS = REC_E + rec_quads<RecE>() };
+       REC_E = REC_C + rec_quads<RecC>(), REC_S = REC_E + rec_quads<RecE>(), REC_QUADS = REC_S + rec_quads<RecS>() };
 enum { LANE_REC_INTS = REC_QUADS * 64 * 4 };
 
 // host: the table of a model (LANE_REC_INTS ints, zero-filled by the caller)
@@ -1169,6 +1204,9 @@ inline void build_lane_records(const DevModel& m, const Lay& l, int32_t* out) {
     E.EJ.da = m.njnt > 0 ? m.jnt_dofadr[j] : 0;
     E.EJ.jtype = m.njnt > 0 ? m.jnt_type[j] : -1;
     put(REC_E, &E, sizeof(E), L);
+    RecS SS; __builtin_memset(&SS, 0, sizeof(SS));
+    load_sensor_constants(m, 0, L, SS.SK);
+    put(REC_S, &SS, sizeof(SS), L);
   }
 }
 
@@ -2714,28 +2752,28 @@ __device__ inline void stage_pgs(const DevModel& m, const Lay& l, const LaneK& K
 }
 
 // ------------------------------------------------------------------ sensors (mj_forward's sensor stage)
-__device__ inline void stage_sensors(const DevModel& m, const Lay& l, const LaneK& K, real* S, int L) {
+__device__ inline void stage_sensors(const DevModel& m, const Lay& l, const LaneK& K, const SensK& SK0, real* S, int L) {
   int* I = (int*)(S + l.ints);
   const Tab T = make_tab(m, l, S);
   if (m.has_accel) stage_velocity(m, l, K, S, L, true);
-  // Sensor s's record lives in lane s (64 sensors per pass): the chain sensor -> site -> body is followed by all
-  // sensors at once, two round trips to L2 for the stage instead of two per sensor, and the loop over the sensors reads
-  // lane s with v_readlane.
+  // Sensor s's record lives in lane s (64 sensors per pass): the chain sensor -> site -> body was followed for all
+  // sensors at once on the host (lane records, SensK; a model with more than 64 sensors reads the later chunks' here),
+  // and the loop over the sensors reads lane s with v_readlane.
   for (int s0 = 0; s0 < m.nsensor; s0 += 64) {
-    const int sl = s0 + L < m.nsensor ? s0 + L : 0;
-    const int k_site = m.sensor_objid[sl], k_adr = m.sensor_adr[sl], k_type = m.sensor_type[sl];
-    const real k_cut = m.sensor_cutoff[sl];
-    // the lane's geom as a ray target, fetched once for all rangefinders (with the sensor records: one round trip)
-    const int gl = L < m.ngeom ? L : 0;
-    const real rg_alpha = m.geom_rgba[4 * gl + 3];
-    const int rg_body0 = m.geom_bodyid[gl], rg_type0 = m.geom_type[gl];
-    const real rg_rb0 = m.geom_rbound[gl];
-    const V3 rg_size0 = ld3(m.geom_size + 3 * gl), rg_gpos = ld3(m.geom_pos + 3 * gl);
-    const Quat rg_gquat = ldq(m.geom_quat + 4 * gl);
-    const int k_body = m.site_bodyid[k_site];
-    const V3 k_pos = ld3(m.site_pos + 3 * k_site);
-    const Quat k_quat = ldq(m.site_quat + 4 * k_site);
-    const real k_size = m.site_size[3 * k_site];
+    SensK SK = SK0;
+    if (s0 > 0) load_sensor_constants(m, s0, L, SK);
+    const int k_adr = SK.adr, k_type = SK.type;
+    const real k_cut = SK.cut;
+    // the lane's geom as a ray target, once for all rangefinders
+    const real rg_alpha = SK.g_alpha;
+    const int rg_body0 = SK.g_body, rg_type0 = SK.g_type;
+    const real rg_rb0 = SK.g_rb;
+    const V3 rg_size0 = SK.g_size, rg_gpos = SK.g_pos;
+    const Quat rg_gquat = SK.g_quat;
+    const int k_body = SK.body;
+    const V3 k_pos = SK.pos;
+    const Quat k_quat = SK.quat;
+    const real k_size = SK.size;
     const bool any_ray = wv::ballot(s0 + L < m.nsensor && k_type == SENS_RANGEFINDER) != 0ull;
     int rg_body = -1, rg_type = -1;
     real rg_rb = 0;
@@ -2771,7 +2809,11 @@ __device__ inline void stage_sensors(const DevModel& m, const Lay& l, const Lane
             real t = dot(rel, vec), d2 = dot(rel, rel) - t * t;
             if (d2 > rg_rb * rg_rb * (1.0 + 1e-9) + 1e-12 || t + rg_rb < -1e-9) gt = -1;
           }
+#ifdef MJRL_EXP_NORAY
+          real x = gt >= 0 ? rg_pos.x : -1.0;
+#else
           real x = ray_geom(gt, rg_pos, rg_mat, rg_size, sp, vec);
+#endif
           if (x >= 0) best = x;
         }
         for (int g = 64 + L; g < m.ngeom; g += 64) {      // (targets past the 64th geom: the same tests, records from the model)
@@ -2860,9 +2902,10 @@ __device__ __forceinline__ void load_euler_constants(const DevModel& m, const St
   RecE RE;
   fetch_lane_record(a.lane_rec, REC_E, L, RE);
   E.qa = RE.EJ.qa; E.da = RE.EJ.da; E.jtype = RE.EJ.jtype;
-  const int nobs = a.n_agent * a.obs_dim;
+  // (the codes of the rows this launch writes: every agent's, or one agent's -- StepArgs::io_agent)
+  const int nobs = a.io_agent1 == 0 ? a.n_agent * a.obs_dim : a.obs_dim, g0 = a.io_agent1 == 0 ? 0 : (a.io_agent1 - 1) * a.obs_dim;
 #pragma unroll
-  for (int u = 0; u < 2; u++) E.gcode[u] = (a.obs && 64 * u < nobs) ? a.gather[64 * u + L < nobs ? 64 * u + L : 0] : -1;
+  for (int u = 0; u < 2; u++) E.gcode[u] = (a.obs && 64 * u < nobs) ? a.gather[g0 + (64 * u + L < nobs ? 64 * u + L : 0)] : -1;
 }
 
 // (the caller has put the unfactorised inertia matrix back at S[l.LD..]: mkeep_put)
@@ -3095,7 +3138,14 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
   int sc_reg = -1;
   if (act_in_lanes && n_act_row > 0) {
     const int i = L < n_act_row ? L : 0;
-    act_reg = a.actions[(size_t)env * n_act_row + i];
+    if (a.io_agent1 == 0) {
+      act_reg = a.actions[(size_t)env * n_act_row + i];
+    } else {                                      // (one agent's row in the buffer: the other agents act with 0)
+      const int j = i - (a.io_agent1 - 1) * a.act_dim;
+      const bool mine = j >= 0 && j < a.act_dim;
+      const real v = a.actions[(size_t)env * a.act_dim + (mine ? j : 0)];
+      act_reg = mine ? v : 0.0;
+    }
     if (a.scatter) sc_reg = a.scatter[i];         // (lanes past the row hold entry 0: masked where it is used)
   }
   if (ops_staged) {
@@ -3196,7 +3246,11 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
     MJ_STAMP(ST_PGS)
     load_euler_constants(m, a, MJ_L, EK);
     // (sensors belong to a Runge-Kutta frame's first pass, the step's own mj_forward; the later passes skip them)
-    if (m.integrator == 0 || a.rk_stage == 0) stage_sensors(m, l, K, S, MJ_L);
+    if (m.integrator == 0 || a.rk_stage == 0) {
+      RecS RS;
+      fetch_lane_record(a.lane_rec, REC_S, MJ_L, RS);
+      stage_sensors(m, l, K, RS.SK, S, MJ_L);
+    }
     MJ_STAMP(ST_SENSORS)
     if constexpr (DIAG)
       if (a.dbg && a.dbg_stage == 0) {
@@ -3264,10 +3318,22 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
   }
   // per-agent observation gather: sensordata | qpos | qvel (sensordata is the pre-integration forward pass,
   // qpos/qvel are post-integration, exactly as the reference reads them after mj_step)
+  // (observation rows: all agents' [n_env][n_agent][obs_dim] float64, or -- mjrl_set_io_layout -- one agent's
+  // [n_env][obs_dim], as float when obs_f32)
+  const int io_agent = a.io_agent1 - 1;
+  const int obs_row = io_agent < 0 ? a.n_agent * a.obs_dim : a.obs_dim, obs_g0 = io_agent < 0 ? 0 : io_agent * a.obs_dim;
+  auto obs_put = [&](size_t idx, real v) {
+    if (a.obs_f32) ((float*)a.obs)[idx] = (float)v; else a.obs[idx] = v;
+  };
+  // slot j of agent ag's row (an agent that has no row in the buffer: nothing is written)
+  auto obs_put_agent = [&](int ag, int j, real v) {
+    if (io_agent < 0) obs_put(((size_t)env * a.n_agent + ag) * a.obs_dim + j, v);
+    else if (ag == io_agent) obs_put((size_t)env * a.obs_dim + j, v);
+  };
   if (a.obs) {
-    MJ_FOR(it, a.n_agent * a.obs_dim) {
+    MJ_FOR(it, obs_row) {
       int code = it < 64 ? EK.gcode[0] : (it < 128 ? EK.gcode[1] : -3);
-      if (code == -3) code = a.gather[it];
+      if (code == -3) code = a.gather[obs_g0 + it];
       // slot owned by a fused dynamics op (written below) or by the camera encoder; a reset without a step runs no op:
       // the slot reads 0 like in the reset observation of the array path (camera latents are written behind the step)
       if (code == -2 && !reset_only) continue;
@@ -3276,7 +3342,7 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
         int kind = code >> 24, idx = code & 0xFFFFFF;
         v = kind == 0 ? S[l.sens + idx] : (kind == 1 ? S[l.qpos + idx] : S[l.qvel + idx]);
       }
-      a.obs[(size_t)env * a.n_agent * a.obs_dim + it] = v;
+      obs_put((size_t)env * obs_row + it, v);
     }
   }
   MJ_STAMP_ONLY(ST_STORE)
@@ -3385,7 +3451,7 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
           const real after = other < a.n_agent ? store[other * a.n_slot + pi[2]] : 0.0;
           real heard = other < me ? after : before;
           if (heard != heard) heard = 0.0;
-          if (on && a.obs) a.obs[((size_t)env * a.n_agent + me) * a.obs_dim + obs_len[me] + pi[3]] = heard;
+          if (on && a.obs) obs_put_agent(me, obs_len[me] + pi[3], heard);
         } else if (kind == OP_TARGET) {
           if (on) {
             const int body = agent_body[me];
@@ -3411,9 +3477,9 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
               if (pi[5] >= 0) { V3 e3 = p - t; store[me * a.n_slot + pi[5]] = sqrt(dot(e3, e3)); }
             }
             if (a.obs) {
-              real* o = a.obs + ((size_t)env * a.n_agent + me) * a.obs_dim + obs_len[me] + pi[4];
-              o[0] = t.x; o[1] = t.y; o[2] = t.z;
-              if (inv_slot) o[3] = *inv_slot;
+              const int o = obs_len[me] + pi[4];
+              obs_put_agent(me, o, t.x); obs_put_agent(me, o + 1, t.y); obs_put_agent(me, o + 2, t.z);
+              if (inv_slot) obs_put_agent(me, o + 3, *inv_slot);
             }
           }
         } else if (on) {
@@ -3486,7 +3552,7 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
           int other = ag == 0 ? 1 : 0;
           real heard = other < a.n_agent ? store[other * a.n_slot + pi[2]] : 0.0;
           if (heard != heard) heard = 0.0;
-          if (a.obs) a.obs[((size_t)env * a.n_agent + ag) * a.obs_dim + obs_len[ag] + pi[3]] = heard;
+          if (a.obs) obs_put_agent(ag, obs_len[ag] + pi[3], heard);
         } else if (pi[0] == OP_TARGET) {
           const int body = agent_body[ag];
           const int adr = a.tag_adr[pi[1]], num = a.tag_num[pi[1]];
@@ -3511,9 +3577,9 @@ __device__ __forceinline__ void env_step_t(const DevModel& m, const StepArgs& a_
             if (pi[5] >= 0) { V3 e3 = p - t; store[ag * a.n_slot + pi[5]] = sqrt(dot(e3, e3)); }
           }
           if (a.obs) {
-            real* o = a.obs + ((size_t)env * a.n_agent + ag) * a.obs_dim + obs_len[ag] + pi[4];
-            o[0] = t.x; o[1] = t.y; o[2] = t.z;
-            if (inv_slot) o[3] = *inv_slot;
+            const int o = obs_len[ag] + pi[4];
+            obs_put_agent(ag, o, t.x); obs_put_agent(ag, o + 1, t.y); obs_put_agent(ag, o + 2, t.z);
+            if (inv_slot) obs_put_agent(ag, o + 3, *inv_slot);
           }
         } else {
           int body = agent_body[ag];
@@ -3610,7 +3676,7 @@ constexpr unsigned long long step_args_layout() {
   MJ_LAYOUT_FIELD(dbg) MJ_LAYOUT_FIELD(forward_only) MJ_LAYOUT_FIELD(reset_mask) MJ_LAYOUT_FIELD(auto_mask)
   MJ_LAYOUT_FIELD(reset_sens) MJ_LAYOUT_FIELD(rk) MJ_LAYOUT_FIELD(stats) MJ_LAYOUT_FIELD(stamps) MJ_LAYOUT_FIELD(prog_i)
   MJ_LAYOUT_FIELD(n_slot) MJ_LAYOUT_FIELD(store) MJ_LAYOUT_FIELD(tag_ref) MJ_LAYOUT_FIELD(env_base) MJ_LAYOUT_FIELD(variant)
-  MJ_LAYOUT_FIELD(variant_seed) MJ_LAYOUT_FIELD(frames) MJ_LAYOUT_FIELD(scene) MJ_LAYOUT_FIELD(few) MJ_LAYOUT_FIELD(lane_rec)
+  MJ_LAYOUT_FIELD(variant_seed) MJ_LAYOUT_FIELD(frames) MJ_LAYOUT_FIELD(scene) MJ_LAYOUT_FIELD(few) MJ_LAYOUT_FIELD(io_agent1) MJ_LAYOUT_FIELD(obs_f32) MJ_LAYOUT_FIELD(lane_rec)
   MJ_LAYOUT_FIELD(lpt_count_in) MJ_LAYOUT_FIELD(lpt_mask_clear) MJ_LAYOUT_FIELD(lpt_words) MJ_LAYOUT_FIELD(overflow)
   MJ_LAYOUT_FIELD(timeline) MJ_LAYOUT_FIELD(stop_after)
 #undef MJ_LAYOUT_FIELD

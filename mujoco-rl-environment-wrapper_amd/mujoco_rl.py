@@ -39,6 +39,8 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
     metadata = {"name": "mjrl_amd_v0", "render_modes": ["none"]}
 
     _pinned = None          # (handle, actions, obs, reward, term, trunc): the handle's pinned host buffers, step_batched
+    _checked_buffers = None  # output buffers of step_batched that have passed _check_device_buffers, by address
+    _act_need = None         # action slots step_batched needs per agent
 
     def __init__(self, config_dict: dict):
         self.agents = config_dict.get("agents", [])
@@ -60,6 +62,7 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
         self.camera_encoder = config_dict.get("cameraEncoder")
 
         self.timestep = 0
+        self._checked_buffers = {}
         self.start_time = time.time()
         self.action_routing = {"physical": [], "dynamic": {}}
         self.data_store = {agent: {} for agent in self.agents}
@@ -123,6 +126,9 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
         loop (mujoco_parent.py:351-356)."""
         MuJoCoParent._after_init_environment(self)
         self._handle.set_max_steps(self.max_steps)
+        if getattr(self, "_io_layout", None):            # (a vector-env adapter's one-agent layout and autoreset mode)
+            self._handle.set_io_layout(*self._io_layout[:2])
+            self._handle.set_autoreset(self._io_layout[2])
         if hasattr(self, "_fused_allowed"):
             self._setup_fused_program(self._fused_allowed)
             if self.camera_encoder:
@@ -135,6 +141,7 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
         """When every configured plugin belongs to the device vocabulary (dynamics.py) the plugin loop runs inside
         the step kernel; otherwise (or with ``fusedPlugins: False``) it stays the host loop below."""
         self._program = fused_vocabulary.build_program(self) if allowed else None
+        self._act_need = None            # (what step_batched checks the action tensors against)
         if self._program is None:
             # host plugins read body / geom frames and contacts after every step: have the kernel keep them
             if self.environment_dynamics or self.reward_functions or self.done_functions:
@@ -427,6 +434,7 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
         parent: where pettingzoo is installed ``ParallelEnv.close`` -- a no-op -- comes first in the method resolution
         order and would shadow it (the reference's parent has no close at all; this port's owns HBM)."""
         self._pinned = None
+        self._checked_buffers = {}
         MuJoCoParent.close(self)
 
     # ------------------------------------------------------------------ array path
@@ -439,11 +447,29 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
         self._obs_cache = None
 
     def _check_device_buffers(self, actions, obs, reward, term, trunc):
+        """The kernel gets raw addresses: a tensor of the wrong shape, type, layout or device would be an out-of-bounds
+        device access.  The output buffers are checked once per set (``_checked_buffers``), the actions on every call
+        (a sampler hands over a different action tensor every step; the test is a handful of attribute reads)."""
         import torch
-        n_agent, obs_dim = len(self.agents), self._handle.size("obs_dim")
-        routed = max((len(self.agents_action_index[a]) for a in self.agents), default=0)
-        need = max(routed, self._first_action_space.shape[0] if self._program is not None else 0)
-        expect = {"actions": (actions, torch.float64, None), "obs": (obs, torch.float64, (self.n_env, n_agent, obs_dim)),
+        n_agent = len(self.agents)
+        if self._act_need is None:
+            routed = max((len(self.agents_action_index[a]) for a in self.agents), default=0)
+            self._act_need = max(routed, self._first_action_space.shape[0] if self._program is not None else 0, 1)
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.device.index == self.device_id
+                and actions.dtype == torch.float64 and actions.is_contiguous() and actions.dim() == 3
+                and actions.shape[0] == self.n_env and actions.shape[1] == n_agent and actions.shape[2] >= self._act_need):
+            what = tuple(actions.shape) if isinstance(actions, torch.Tensor) else type(actions).__name__
+            raise Exception(f"step_batched: actions ({what}, {getattr(actions, 'dtype', None)}, {getattr(actions, 'device', None)}) "
+                            f"must be a contiguous float64 tensor of shape ({self.n_env}, {n_agent}, >= {self._act_need}) on "
+                            f"cuda:{self.device_id}")
+        key = (self._handle, obs.data_ptr() if isinstance(obs, torch.Tensor) else None,
+               reward.data_ptr() if isinstance(reward, torch.Tensor) else None,
+               term.data_ptr() if isinstance(term, torch.Tensor) else None,
+               trunc.data_ptr() if isinstance(trunc, torch.Tensor) else None)
+        if key in self._checked_buffers:
+            return
+        obs_dim = self._handle.size("obs_dim")
+        expect = {"obs": (obs, torch.float64, (self.n_env, n_agent, obs_dim)),
                   "reward": (reward, torch.float64, (self.n_env, n_agent)), "term": (term, torch.uint8, (self.n_env, n_agent)),
                   "trunc": (trunc, torch.uint8, (self.n_env, n_agent))}
         for name, (tensor, dtype, shape) in expect.items():
@@ -453,11 +479,12 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
                 raise Exception(f"step_batched: {name} lives on {tensor.device}, the env batch on cuda:{self.device_id}")
             if tensor.dtype != dtype or not tensor.is_contiguous():
                 raise Exception(f"step_batched: {name} must be a contiguous {dtype} tensor")
-            if shape is not None and tuple(tensor.shape) != shape:
+            if tuple(tensor.shape) != shape:
                 raise Exception(f"step_batched: {name} has shape {tuple(tensor.shape)}, expected {shape}")
-        if actions.dim() != 3 or tuple(actions.shape[:2]) != (self.n_env, n_agent) or actions.shape[2] < max(need, 1):
-            raise Exception(f"step_batched: actions have shape {tuple(actions.shape)}, expected ({self.n_env}, {n_agent}, "
-                            f">= {max(need, 1)})")
+        if len(self._checked_buffers) > 64:
+            self._checked_buffers.clear()
+        # (the tensors are kept alive with their key: an address must not pass for another tensor's later)
+        self._checked_buffers[key] = (obs, reward, term, trunc)
 
     def step_batched(self, actions, obs=None, reward=None, term=None, trunc=None):
         """One step of every copy without per-agent dicts and without host plugins.
@@ -495,10 +522,10 @@ class MuJoCoRL(_ParallelBase, MuJoCoParent):
             reward = torch.empty((self.n_env, n_agent), dtype=torch.float64, device=dev) if reward is None else reward
             term = torch.empty((self.n_env, n_agent), dtype=torch.uint8, device=dev) if term is None else term
             trunc = torch.empty((self.n_env, n_agent), dtype=torch.uint8, device=dev) if trunc is None else trunc
-            # the kernel gets raw addresses: a tensor of the wrong shape, type, layout or device would be an out-of-bounds
-            # device access, so every buffer is checked here
             self._check_device_buffers(actions, obs, reward, term, trunc)
-            self.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if stream != self._stream:
+                self.set_stream(stream)
             self._handle.step_device(actions.data_ptr(), actions.shape[-1], self.skip_frames, obs.data_ptr(),
                                      reward.data_ptr(), term.data_ptr(), trunc.data_ptr())
         self.timestep += 1

@@ -52,9 +52,21 @@ class BatchedVectorEnv(_VecBase):
     """``num_envs`` copies of a level behind the Gymnasium ``VectorEnv`` calling convention, one driven agent.
 
     ``reset() -> (obs[num_envs, obs_dim], infos)``; ``step(actions[num_envs, act_dim]) -> (obs, rewards, terminations,
-    truncations, infos)``.  ``actions`` is a numpy array (outputs: numpy views of the handle's pinned host buffers, which
-    the next step overwrites -- copy what has to survive it) or a torch CUDA tensor (outputs: torch tensors in HBM, the
-    launch asynchronous on the current torch stream).  It is a ``gymnasium.vector.VectorEnv`` where gymnasium exists.
+    truncations, infos)``.  ``actions`` is a numpy array or a torch CUDA tensor (outputs: torch tensors in HBM, the launch
+    asynchronous on the current torch stream).  It is a ``gymnasium.vector.VectorEnv`` where gymnasium exists.
+
+    ``copy`` (default True, like Gymnasium's own vector envs): what ``step`` returns is the caller's to keep.  numpy:
+    fresh arrays, copied out of the handle's pinned host buffers; torch: tensors of a ring of ``ring`` preallocated
+    output sets, so a result stays valid until ``ring`` further steps have been taken (rollout code that keeps
+    ``last_obs`` across a step, a replay buffer that copies on insert) without an allocation per step.  ``copy=False``
+    is the zero-copy contract: numpy views of the pinned buffers / one set of torch tensors, overwritten in place by the
+    next step and gone after ``close()`` -- for samplers that consume a step's results before taking the next.
+
+    The adapter puts the handle into the one-agent I/O layout (``mjrl_set_io_layout``): the kernel reads the driven
+    agent's action row straight from the caller's ``[num_envs, act_dim]`` array / tensor (no padded copy; the other
+    agents act with 0) and writes only its observation row.  ``obs_dtype=np.float32`` makes the kernel store the
+    observations as float -- what a policy network consumes, and half the bytes a numpy caller pulls over PCIe.  The env
+    object's own array path (``step_batched`` with all agents' rows) is unavailable while the adapter holds it.
 
     Autoreset (``autoreset=``), kept on the device by ``mjrl_set_autoreset`` -- no mask is computed or moved by the host:
 
@@ -74,7 +86,8 @@ class BatchedVectorEnv(_VecBase):
 
     MODES = {"next_step": 1, "reset_then_step": 2, "same_step": 0}
 
-    def __init__(self, environment, agent: str | None = None, autoreset: str = "next_step"):
+    def __init__(self, environment, agent: str | None = None, autoreset: str = "next_step", copy: bool = True,
+                 ring: int = 4, obs_dtype=np.float64):
         if len(environment.agents) != 1 and agent is None:
             raise Exception("BatchedVectorEnv drives one agent; pass `agent` for a multi-agent level")
         if autoreset not in self.MODES:
@@ -95,36 +108,36 @@ class BatchedVectorEnv(_VecBase):
         self._n_agent = len(environment.agents)
         self._act_dim = max(environment.action_space(a).shape[0] for a in environment.agents)
         self._width = self.single_observation_space.shape[0]
+        if np.dtype(obs_dtype) not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise Exception("obs_dtype must be float64 or float32")
+        self._f32 = np.dtype(obs_dtype) == np.dtype(np.float32)
+        self._obs_dim = environment._handle.size("obs_dim")
+        if getattr(environment, "_latent_dim", 0):
+            raise Exception("BatchedVectorEnv: camera latents in the observation use the all-agent layout; step the env "
+                            "through MuJoCoRL.step_batched")
+        environment._handle.set_io_layout(self._k, self._f32)
+        environment._io_layout = (self._k, self._f32, self.MODES[autoreset])       # (kept across a level switch on reset)
+        environment._pinned = None                 # (views of the old layout)
         self._torch_act = None
+        self._copy = bool(copy)
+        self._ring, self._ring_at = [], 0
+        self._ring_len = max(int(ring), 2) if copy else 1
         environment._handle.set_autoreset(self.MODES[autoreset])
 
     # -- helpers
-    def _numpy_actions(self, actions):
-        """The driven agent's rows inside the pinned action buffer [num_envs, n_agent, act_dim]; the others stay 0."""
+    def _pinned_buffers(self):
         env = self.environment
         if env._pinned is None or env._pinned[0] is not env._handle or env._pinned[1].shape[-1] != self._act_dim:
             env._pinned = (env._handle,) + env._handle.host_buffers(self._act_dim)
             env._pinned[1][:] = 0.0
-        p_act = env._pinned[1]
-        act = np.asarray(actions, dtype=np.float64).reshape(self.num_envs, -1)
-        p_act[:, self._k, :act.shape[1]] = act
-        return p_act
-
-    def _torch_actions(self, actions):
-        import torch
-        if self._n_agent == 1 and actions.dim() == 2 and actions.shape[1] == self._act_dim and actions.dtype == torch.float64:
-            return actions.reshape(self.num_envs, 1, self._act_dim)
-        if self._torch_act is None or self._torch_act.device != actions.device:
-            self._torch_act = torch.zeros((self.num_envs, self._n_agent, self._act_dim), dtype=torch.float64, device=actions.device)
-        self._torch_act[:, self._k, :actions.shape[-1]] = actions.reshape(self.num_envs, -1)
-        return self._torch_act
+        return env._pinned
 
     # -- VectorEnv
     def reset(self, *, seed=None, options=None):
         env = self.environment
         env.reset_batched()
         obs = np.atleast_2d(env.get_observations(self.agent))
-        full = np.zeros((self.num_envs, self._width))
+        full = np.zeros((self.num_envs, self._width), np.float32 if self._f32 else np.float64)
         full[:, :obs.shape[1]] = obs              # (slots of fused dynamics read 0 after a reset, like the array path's)
         return full, {}
 
@@ -132,12 +145,15 @@ class BatchedVectorEnv(_VecBase):
         env = self.environment
         k = self._k
         if isinstance(actions, np.ndarray) or not hasattr(actions, "data_ptr"):
-            p_act = self._numpy_actions(actions)
+            _, p_act, obs, reward, term, trunc = self._pinned_buffers()
+            act = np.asarray(actions, dtype=np.float64).reshape(self.num_envs, -1)
+            p_act[:, :act.shape[1]] = act
             env._handle.step_pinned(self._act_dim, env.skip_frames)
             env.timestep += 1
             env._obs_cache = None
-            _, _, obs, reward, term, trunc = env._pinned
-            obs, reward, term, trunc = obs[:, k, :self._width], reward[:, k], term[:, k].view(np.bool_), trunc[:, k].view(np.bool_)
+            obs, reward, term, trunc = obs[:, :self._width], reward[:, k], term[:, k].view(np.bool_), trunc[:, k].view(np.bool_)
+            if self._copy:              # (the pinned buffers are the next step's too, and close() frees them)
+                obs, reward, term, trunc = obs.copy(), reward.copy(), term.copy(), trunc.copy()
             info = {}
             if self.autoreset == "same_step":
                 done = term | trunc
@@ -150,19 +166,53 @@ class BatchedVectorEnv(_VecBase):
                     obs[done, fresh.shape[1]:] = 0.0
             return obs, reward, term, trunc, info
         import torch
-        full = env.step_batched(self._torch_actions(actions))
-        obs, reward, term, trunc = full[0][:, k, :self._width], full[1][:, k], full[2][:, k].bool(), full[3][:, k].bool()
+        if len(self._ring) < self._ring_len or self._ring[0][0].device != actions.device:
+            if self._ring and self._ring[0][0].device != actions.device:
+                self._ring = []
+            n, na, dev = self.num_envs, self._n_agent, actions.device
+            self._ring.append((torch.empty((n, self._obs_dim), dtype=torch.float32 if self._f32 else torch.float64, device=dev),
+                               torch.empty((n, na), dtype=torch.float64, device=dev),
+                               torch.empty((n, na), dtype=torch.uint8, device=dev),
+                               torch.empty((n, na), dtype=torch.uint8, device=dev)))
+            self._ring_at = len(self._ring) - 1
+        else:
+            self._ring_at = (self._ring_at + 1) % self._ring_len
+        o_obs, o_rew, o_term, o_trunc = self._ring[self._ring_at]
+        # (raw addresses go to the kernel: the action tensor is checked on every call, the ring was made here)
+        if not (actions.is_cuda and actions.device.index == env.device_id and actions.dtype == torch.float64
+                and actions.is_contiguous() and actions.dim() == 2 and actions.shape[0] == self.num_envs
+                and actions.shape[1] == self._act_dim):
+            if actions.is_cuda and actions.dim() == 2 and actions.shape[0] == self.num_envs and actions.shape[1] <= self._act_dim:
+                # another dtype / a narrower row: through a staging tensor of the layout's shape
+                if self._torch_act is None or self._torch_act.device != actions.device:
+                    self._torch_act = torch.zeros((self.num_envs, self._act_dim), dtype=torch.float64, device=actions.device)
+                self._torch_act[:, :actions.shape[1]] = actions
+                actions = self._torch_act
+            else:
+                raise Exception(f"BatchedVectorEnv.step: actions {tuple(actions.shape)} {actions.dtype} on {actions.device}; "
+                                f"expected ({self.num_envs}, {self._act_dim}) float64 on cuda:{env.device_id}")
+        stream = torch.cuda.current_stream(actions.device).cuda_stream
+        if stream != env._stream:
+            env.set_stream(stream)
+        env._handle.step_device(actions.data_ptr(), self._act_dim, env.skip_frames, o_obs.data_ptr(), o_rew.data_ptr(),
+                                o_term.data_ptr(), o_trunc.data_ptr())
+        env.timestep += 1
+        env._obs_cache = None
+        # (flags as bool views of the kernel's bytes: no conversion kernel)
+        obs, reward, term, trunc = o_obs[:, :self._width], o_rew[:, k], o_term[:, k].view(torch.bool), o_trunc[:, k].view(torch.bool)
         info = {}
         if self.autoreset == "same_step":
             done = term | trunc
             if bool(done.any()):              # (a host look at the flags: this mode's price)
                 info = {"final_observation": obs[done].clone(), "_final_observation": done.clone()}
-                fresh = torch.empty_like(full[0])
+                fresh = torch.empty_like(o_obs)
                 env._handle.reset_device(done.to(torch.uint8).contiguous().data_ptr(), fresh.data_ptr())
-                obs = torch.where(done[:, None], fresh[:, k, :self._width], obs)
+                obs = torch.where(done[:, None], fresh[:, :self._width], obs)
         return obs, reward, term, trunc, info
 
     def close(self, **kwargs):
+        self._ring = []
+        self._torch_act = None
         self.environment.close()
 
 

@@ -288,6 +288,95 @@ def test_vector_env_autoreset_is_per_copy_and_runs_the_fused_channel(few_build):
     vec.close()
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_one_agent_io_layout_gives_the_default_layouts_rows(f32, few_build):
+    """mjrl_set_io_layout (what the vector-env adapter runs on): with the driven agent's action row alone in the buffer
+    and the other agent at 0, the kernel writes exactly the driven agent's row of the default layout -- the same bits as
+    float64, the same values rounded to float with obs_f32 -- through the device entry and the pinned entry, with the
+    fused Language channel's slot in the row, and through the reset observations."""
+    import torch
+    from mjrl_amd.dynamics import Language
+    n_env, steps = 7, 40
+    cfg = {"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": n_env, "maxSteps": 15,
+           "environmentDynamics": [Language]}
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(-1, 1, (steps, n_env, 9)); acts[:, :, 8] = rng.integers(0, 3, (steps, n_env)) + 0.5
+    for driven in (0, 1):
+        ref, dev, pin = MuJoCoRL(cfg), MuJoCoRL(cfg), MuJoCoRL(cfg)
+        for env in (ref, dev, pin):
+            env.reset_batched()
+            env._handle.set_autoreset(2)
+        for env in (dev, pin):
+            env._handle.set_io_layout(driven, f32)
+        p_act, p_obs, p_rew, p_term, p_trunc = pin._handle.host_buffers(9)
+        assert p_act.shape == (n_env, 9) and p_obs.shape == (n_env, 60) and p_obs.dtype == (np.float32 if f32 else np.float64)
+        d_obs = torch.empty((n_env, 60), dtype=torch.float32 if f32 else torch.float64, device="cuda")
+        d_rew = torch.empty((n_env, 2), dtype=torch.float64, device="cuda")
+        d_term = torch.empty((n_env, 2), dtype=torch.uint8, device="cuda")
+        d_trunc = torch.empty((n_env, 2), dtype=torch.uint8, device="cuda")
+        for t in range(steps):
+            full = np.zeros((n_env, 2, 9))
+            full[:, driven] = acts[t]
+            obs, rew, term, trunc = ref.step_batched(torch.from_numpy(full).cuda())
+            want = obs[:, driven].cpu().numpy()
+            d_act = torch.from_numpy(acts[t]).cuda()
+            dev._handle.step_device(d_act.data_ptr(), 9, 1, d_obs.data_ptr(), d_rew.data_ptr(), d_term.data_ptr(), d_trunc.data_ptr())
+            p_act[:] = acts[t]
+            pin._handle.step_pinned(9, 1)
+            for got in (d_obs.cpu().numpy(), p_obs):
+                assert np.array_equal(got, want.astype(np.float32) if f32 else want), (driven, t)
+            assert np.array_equal(d_trunc.cpu().numpy(), trunc.cpu().numpy()) and np.array_equal(p_trunc, trunc.cpu().numpy())
+            assert np.array_equal(d_rew.cpu().numpy(), rew.cpu().numpy())
+        assert trunc.cpu().numpy().any() or steps > 15                 # (episodes ended and restarted on the way)
+        # reset observations in the same layout
+        r_full = torch.empty((n_env, 2, 60), dtype=torch.float64, device="cuda")
+        ref._handle.reset_device(None, r_full.data_ptr())
+        dev._handle.reset_device(None, d_obs.data_ptr())
+        want = r_full[:, driven].cpu().numpy()
+        assert np.array_equal(d_obs.cpu().numpy(), want.astype(np.float32) if f32 else want)
+        with pytest.raises(Exception, match="default layout"):
+            dev._handle.step_host(np.zeros((n_env, 2, 9)), 1, np.zeros((n_env, 2, 60)))
+        dev._handle.set_io_layout(-1, False)
+        dev._handle.step_host(np.zeros((n_env, 2, 9)), 1, np.zeros((n_env, 2, 60)))
+        for env in (ref, dev, pin):
+            env.close()
+
+
+def test_vector_env_results_are_the_callers_to_keep_unless_asked_otherwise():
+    """copy=True (the default, Gymnasium's own convention): what step() returned is unchanged by later steps -- fresh numpy
+    arrays, torch tensors of a ring; copy=False hands out views of the buffers the next step overwrites.  float32
+    observations are the float64 ones rounded."""
+    import torch
+    from mjrl_amd.wrappers import BatchedVectorEnv
+    n_env = 9
+    make = lambda **kw: BatchedVectorEnv(MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS,
+                                                   "numEnvs": n_env, "maxSteps": 50}), agent="receiver", **kw)
+    rng = np.random.default_rng(1)
+    acts = rng.uniform(-1, 1, (6, n_env, 8))
+    keep, view, f32 = make(), make(copy=False), make(obs_dtype=np.float32)
+    for v in (keep, view, f32):
+        v.reset()
+    held = []
+    for t in range(6):
+        o_keep = keep.step(acts[t])[0]
+        o_view = view.step(acts[t])[0]
+        o_f32 = f32.step(acts[t])[0]
+        assert o_f32.dtype == np.float32 and np.array_equal(o_f32, o_keep.astype(np.float32))
+        assert np.array_equal(o_keep, o_view)
+        held.append((o_keep, o_keep.copy(), o_view))
+    assert all(np.array_equal(a, b) for a, b, _ in held)              # copies stay what they were
+    assert np.array_equal(held[0][2], held[-1][2]) and not np.array_equal(held[0][1], held[-1][1])   # views alias one buffer
+    for v in (keep, view, f32):
+        v.close()
+    tk = make()
+    tk.reset()
+    outs = [tk.step(torch.from_numpy(acts[t]).cuda())[0] for t in range(3)]
+    snap = [o.clone() for o in outs]
+    assert outs[0].dtype == torch.float64 and all(torch.equal(a, b) for a, b in zip(outs, snap))     # ring of 4: all valid
+    assert outs[0].data_ptr() != outs[1].data_ptr()
+    tk.close()
+
+
 # --------------------------------------------------------------------------- camera shading (row a14)
 def test_render_kernel_shades_like_the_oracle(tmp_path):
     """The ray kernel evaluates the fixed-function lighting equation in single precision, the oracle in double

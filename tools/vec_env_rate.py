@@ -14,9 +14,11 @@ from mjrl_amd.wrappers import BatchedVectorEnv
 level = sys.argv[1] if len(sys.argv) > 1 else "two_agent.xml"
 n_env = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 agents = {"two_agent.xml": ["sender", "receiver"], "single_agent.xml": ["sender"]}[level]
-for path in ("numpy", "torch"):
+for path, copy, dtype in (("numpy", True, np.float64), ("numpy", False, np.float64), ("numpy", True, np.float32),
+                          ("numpy", False, np.float32), ("torch", True, np.float64), ("torch", False, np.float64),
+                          ("torch", True, np.float32)):
     vec = BatchedVectorEnv(MuJoCoRL({"xmlPath": levels.level_path(level), "agents": agents, "numEnvs": n_env, "maxSteps": 1024}),
-                           agent="sender")
+                           agent="sender", copy=copy, obs_dtype=dtype)
     vec.reset()
     rng = np.random.default_rng(0)
     ring = rng.uniform(-1, 1, (64, n_env, 8))
@@ -35,6 +37,6 @@ for path in ("numpy", "torch"):
     if path == "torch":
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{path:6s} {level} {n_env} copies: {n_env * steps / dt / 1e6:.2f} M env-steps/s ({dt / steps * 1e3:.3f} ms per step), "
+    print(f"{path:6s} copy={copy!s:5s} {level} {n_env} copies: {n_env * steps / dt / 1e6:.2f} M env-steps/s ({dt / steps * 1e3:.3f} ms per step), "
           f"obs {tuple(obs.shape)} {obs.dtype}")
     vec.close()
