@@ -18,7 +18,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 16
+VERSION = 17
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
@@ -73,6 +73,7 @@ I32_FIELDS = [
     ("lds_tab", "ntab"), ("pair_word", "npair"), ("pair_reach", "npair"), ("dof_descmask", "nv*2"),
     ("body_kparent", "nbody"), ("body_kdepth", "nbody"), ("chunk_info", "nchunk"), ("tp_root", "ntp*2"),
     ("light_bodyid", "nlight"), ("light_directional", "nlight"),
+    ("light_castshadow", "nlight"),          # layout 17: the light's shadow is drawn (body/light castshadow, default true)
 ]
 
 

@@ -123,8 +123,19 @@ __device__ __forceinline__ float fast_pow(float x, float y) {
 #define MJRL_RENDER_VARIANT 0        // (experiments: 1 = round 2's shading, 2 = byte stores, 3 = no type-specific tests, 4 = one candidate)
 #endif
 // one light of the ray kernel in LDS (floats): camera-relative position 3 | direction 3 | attenuation 3 | cos(cutoff) |
-// exponent | ambient 3 | diffuse 3 | specular 3 | directional
-enum { LIGHT_FLOATS = 21 };
+// exponent | ambient 3 | diffuse 3 | specular 3 | directional | casts a shadow
+enum { LIGHT_FLOATS = 22 };
+// minimum / maximum of a float over the wave, in every lane (DPP inside the rows of 16, v_readlane across them)
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_minf(float v) {
+  v = fminf(v, dppf<0xB1>(v)); v = fminf(v, dppf<0x4E>(v)); v = fminf(v, dppf<0x141>(v)); v = fminf(v, dppf<0x140>(v));
+  auto at = [&](int l) { return __int_as_float(wv::lane_int(__float_as_int(v), l)); };
+  return fminf(fminf(at(0), at(16)), fminf(at(32), at(48)));
+}
+__device__ __forceinline__ float wave_maxf(float v) { return -wave_minf(-v); }
 
 __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, const double* qpos, int n_env, double* scene) {
   extern __shared__ double lds[];
@@ -193,6 +204,7 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
     T[6] = 1.0f; T[7] = T[8] = 0.0f; T[9] = -2.0f; T[10] = 0.0f;
     for (int k = 0; k < 9; k++) T[11 + k] = on * (float)m.headlight[1 + k];
     T[20] = 1.0f;
+    T[21] = 0.0f;                 // (the headlight casts no shadow)
   }
   for (int li = tid; li < m.nlight; li += nthr) {   // the level's lights, camera-relative
     float* T = LT + LIGHT_FLOATS * (li + 1);
@@ -209,6 +221,7 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
     T[9] = consts[m.ncam + li];
     T[10] = (float)m.light_exponent[li];
     T[20] = m.light_directional[li] ? 1.0f : 0.0f;
+    T[21] = m.light_castshadow[li] ? 1.0f : 0.0f;
   }
   barrier();
   const F3 origin = f3(0, 0, 0);
@@ -296,14 +309,18 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
             on ? ldf3(GP + 3 * g) : origin);
     }
     unsigned char out[3] = {0, 0, 0};
-    if (hit >= 0) {
+    // (the shading runs for the whole wave, lanes without a hit computing on geom 0 and storing nothing: the shadow pass
+    // below needs every lane in its role as a GEOM, whatever its pixel saw)
+    if (wv::ballot(hit >= 0)) {
       // OpenGL's fixed-function lighting equation with the parameters MuJoCo documents (oracle/ora_step.c ora_shade, the
       // same arithmetic in double): emission + per light att * spot * (ambient + max(n.L, 0) diffuse + (n.H)^shininess
       // specular), the geom's rgba as ambient and diffuse material colour, clamped once at the end
-      const F3 P = vec * best;
-      const F3 n = geom_normalf(m.geom_type[hit], ldf3(GP + 3 * hit), GM + 9 * hit, ldf3(GS + 3 * hit), P);
-      const float spec_m = MP[3 * hit], shin = MP[3 * hit + 1], emis = MP[3 * hit + 2];
-      const F3 mat = ldf3(GC + 3 * hit);
+      const bool shaded = hit >= 0;
+      const int hs = shaded ? hit : 0;
+      const F3 P = vec * (shaded ? best : 1.0f);
+      const F3 n = geom_normalf(m.geom_type[hs], ldf3(GP + 3 * hs), GM + 9 * hs, ldf3(GS + 3 * hs), P);
+      const float spec_m = MP[3 * hs], shin = MP[3 * hs + 1], emis = MP[3 * hs + 2];
+      const F3 mat = ldf3(GC + 3 * hs);
       const F3 V = f3(-LT[3], -LT[4], -LT[5]);               // towards the viewer (at infinity): the camera's +z axis
       float col[3] = {emis * mat.x, emis * mat.y, emis * mat.z};
 #if MJRL_RENDER_VARIANT == 1
@@ -315,19 +332,83 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
 #endif
         const float* T = LT + LIGHT_FLOATS * li;
         const F3 dir = ldf3(T + 3);
+        const bool directional = wv::first_int(__float_as_int(T[20])) != 0, casts = wv::first_int(__float_as_int(T[21])) != 0;
         F3 Ld = dir * -1.0f;
-        float scale = 1.0f;
-        if (T[20] == 0.0f) {
+        float scale = 1.0f, light_dist = 3.0e38f;
+        if (!directional) {
           Ld = ldf3(T) - P;
-          const float d2 = dotf(Ld, Ld);
-          if (d2 < 1e-30f) continue;
+          const float d2 = fmaxf(dotf(Ld, Ld), 1e-30f);      // (a point AT the light: the terms below come out 0 / finite)
           const float inv = rsqrtf(d2), dist = d2 * inv;
+          light_dist = dist;
           Ld = Ld * inv;
           scale = frcp(T[6] + T[7] * dist + T[8] * d2);
           const float c = -dotf(Ld, dir);
           if (T[9] > -1.5f) scale = c < T[9] ? 0.0f : scale * fast_pow(fmaxf(c, 0.0f), T[10]);
+          if (dotf(ldf3(T) - P, ldf3(T) - P) < 1e-30f) scale = 0.0f;
         }
         float nl = dotf(n, Ld), sp = 0.0f;
+        // The light's shadow (MuJoCo draws it for every light with castshadow; oracle/ora_step.c ora_shade): a ray from the
+        // surface point towards the light, and if another opaque geom lies on it the diffuse and specular terms go.
+        // Which geoms can lie on ANY of the block's shadow rays is decided once per block and light, lane g for geom g:
+        // the block's lit points lie in a ball B (on the block's cone between the nearest and the farthest hit), their
+        // rays in the hull of B and the light, and a geom whose bounding sphere stays clear of that hull is no candidate.
+        bool lit = shaded && nl > 0.0f && scale > 0.0f;
+        if (casts && wv::ballot(lit)) {
+          const float tmin = wave_minf(lit ? best : 3.0e38f), tmax = wave_maxf(lit ? best : 0.0f);
+          const F3 bc = axis * (0.5f * (tmin + tmax));
+          const float br = 0.5f * (tmax - tmin) + tmax * sin_t * frcp(fmaxf(cos_t, 0.1f)) + 1e-4f * (1.0f + tmax);
+          F3 toward = dir * -1.0f;
+          float reach = 3.0e38f;
+          if (!directional) {
+            const F3 e = ldf3(T) - bc;
+            const float e2 = fmaxf(dotf(e, e), 1e-30f), inv = rsqrtf(e2);
+            toward = e * inv;
+            reach = e2 * inv;
+          }
+          auto shadow_pass = [&](int base, bool geom_on, int type_v, float rb_v, F3 rel_v) {
+            bool cand = geom_on;
+            if (geom_on) {
+              if (type_v == GEOM_PLANE) {
+                // a ray reaches a plane's front only travelling against its normal; a positional light must lie behind it
+                const F3 pn = colf(GM + 9 * (base + L), 2);
+                cand = directional ? dotf(toward, pn) < 0.0f : dotf(ldf3(T) - rel_v, pn) < br;
+              } else {
+                const F3 w = rel_v - bc;
+                const float along = fminf(fmaxf(dotf(w, toward), 0.0f), reach);
+                const F3 off = w - toward * along;
+                const float lim = rb_v + br;
+                cand = dotf(off, off) <= lim * lim + 1e-5f * (1.0f + dotf(w, w));
+              }
+            }
+            unsigned long long todo = wv::ballot(cand);
+            while (todo) {
+              const int g = __builtin_ctzll(todo);
+              todo &= todo - 1;
+              int gt = wv::lane_int(type_v, g);
+              const F3 rel = f3(__int_as_float(wv::lane_int(__float_as_int(rel_v.x), g)), __int_as_float(wv::lane_int(__float_as_int(rel_v.y), g)),
+                                __int_as_float(wv::lane_int(__float_as_int(rel_v.z), g)));
+              // (the geom the point lies on is convex: it hides the light only where n.L <= 0)
+              if (!lit || base + g == hs) gt = -1;
+              else if (gt != GEOM_PLANE) {
+                const float rb = __int_as_float(wv::lane_int(__float_as_int(rb_v), g));
+                const F3 w = rel - P;
+                const float along = dotf(w, Ld), d2 = dotf(w, w) - along * along;
+                if (d2 > rb * rb + 1e-5f * (1.0f + dotf(w, w)) || along + rb < 0.0f || along - rb > light_dist) gt = -1;
+              }
+              if (!wv::ballot(gt >= 0)) continue;
+              const float x = ray_geomf(gt, rel, GM + 9 * (base + g), ldf3(GS + 3 * (base + g)), P, Ld);
+              if (x >= 0.0f && x < light_dist) lit = false;
+            }
+          };
+          shadow_pass(0, my_geom, my_type, my_rb, my_rel);
+          for (int base = 64; base < m.ngeom; base += 64) {
+            const int g = base + L;
+            const bool on = g < m.ngeom && rgba_of(g < m.ngeom ? g : 0, 3) != 0;
+            shadow_pass(base, on, on ? m.geom_type[g] : -1, on ? (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f : 0.0f,
+                        on ? ldf3(GP + 3 * g) : origin);
+          }
+          if (!lit) nl = 0.0f;
+        }
         if (nl > 0.0f) {
           const F3 H = Ld + V;
           const float hh = dotf(H, H), nh = hh > 1e-30f ? dotf(n, H) * rsqrtf(hh) : 0.0f;
@@ -339,7 +420,8 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
         col[1] += scale * (T[12] * mat.y + nl * T[15] * mat.y + sp * T[18]);
         col[2] += scale * (T[13] * mat.z + nl * T[16] * mat.z + sp * T[19]);
       }
-      for (int k = 0; k < 3; k++) out[k] = (unsigned char)(255.0f * fminf(fmaxf(col[k], 0.0f), 1.0f) + 0.5f);
+      if (shaded)
+        for (int k = 0; k < 3; k++) out[k] = (unsigned char)(255.0f * fminf(fmaxf(col[k], 0.0f), 1.0f) + 0.5f);
     }
     // A block's 8 rows of 8 pixels are 8 x 24 bytes: written as 48 dwords, 6 per row, each put together from two
     // neighbouring lanes' pixels (round 2 stored 3 single bytes per lane: 192 byte stores per block, and four times the

@@ -418,7 +418,7 @@ class _Compiler:
                                       fovy=float(a.get("fovy", 45.0)), mode=a.get("mode", "fixed")))
             elif child.tag == "light":
                 # XML reference, body/light: directional false, active true, pos 0 0 0, dir 0 0 -1, attenuation 1 0 0,
-                # cutoff 45, exponent 10, ambient 0 0 0, diffuse 0.7 0.7 0.7, specular 0.3 0.3 0.3 (castshadow: ignored)
+                # cutoff 45, exponent 10, ambient 0 0 0, diffuse 0.7 0.7 0.7, specular 0.3 0.3 0.3, castshadow true
                 a = self.defaults.apply(child, childclass)
                 if a.get("active", "true") == "false":
                     continue
@@ -427,6 +427,7 @@ class _Compiler:
                 self.lights.append(dict(name=a.get("name", ""), body=body_id, pos=_vec(a.get("pos"), 3, [0, 0, 0]),
                                         dir=d / n if n > MINVAL else np.array([0.0, 0, -1]),
                                         directional=int(a.get("directional", "false") == "true"),
+                                        castshadow=int(a.get("castshadow", "true") == "true"),
                                         attenuation=_vec(a.get("attenuation"), 3, [1, 0, 0]),
                                         cutoff=float(a.get("cutoff", 45.0)), exponent=float(a.get("exponent", 10.0)),
                                         ambient=_vec(a.get("ambient"), 3, [0, 0, 0]),
@@ -874,6 +875,7 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     nl = m.nlight = len(c.lights)
     A["light_bodyid"] = np.array([s["body"] for s in c.lights], np.int32)
     A["light_directional"] = np.array([s["directional"] for s in c.lights], np.int32)
+    A["light_castshadow"] = np.array([s["castshadow"] for s in c.lights], np.int32)
     for key, width in (("pos", 3), ("dir", 3), ("attenuation", 3), ("ambient", 3), ("diffuse", 3), ("specular", 3)):
         A["light_" + key] = np.array([s[key] for s in c.lights], np.float64).reshape(nl, width)
     A["light_cutoff"] = np.array([s["cutoff"] for s in c.lights], np.float64)

@@ -910,7 +910,14 @@ void ora_reset(const ora_model* m, ora_data* d) {
  * surface point to the light, att = 1 / (k0 + k1 d + k2 d^2), and for cutoff < 180 the OpenGL spot factor
  * (-L . dir)^exponent inside the cone, 0 outside.  H = normalize(L + V) with V = the camera's +z axis (OpenGL's default
  * viewer at infinity), the scene's global ambient is 0.
- * What is NOT reproduced: shadows (MuJoCo draws them for lights with castshadow), textures and
+ * Shadows (round 4): MuJoCo draws the shadow of every light with castshadow (body/light, default true; the headlight
+ * casts none).  mjr_render does it with a depth map rendered from the light; the exact form of the same statement is a
+ * shadow ray: from the surface point towards the light (for a positional light up to the light's position), and if any
+ * other opaque geom lies on it the light's diffuse and specular terms are dropped for that point -- its ambient term
+ * stays.  The geom the point lies on is not tested against its own point: all primitives here are convex, so it can only
+ * hide the light where n.L <= 0, and there the two terms are zero anyway.  (What a depth map adds -- soft, resolution-
+ * dependent edges -- is not reproduced.)
+ * What is NOT reproduced: textures and
  * reflectance (the checker floor of Ant.xml), the skybox, anti-aliasing, fog / haze, transparency blending; OpenGL
  * evaluates the equation per vertex of the tessellated geoms and interpolates, this evaluates it per pixel; the viewer
  * model (local / at infinity) and the zero global ambient are read off OpenGL's defaults, not off MuJoCo's source. */
@@ -921,7 +928,7 @@ static void ora_shade(const ora_model* m, const ora_data* d, const double* cm, i
   const double V[3] = {cm[2], cm[5], cm[8]};        /* the camera's +z axis: towards the viewer */
   double col[3] = {emis * rgba[0], emis * rgba[1], emis * rgba[2]};
   for (int li = -1; li < m->nlight; li++) {
-    double L[3], scale = 1.0;
+    double L[3], scale = 1.0, light_dist = 0.0;
     const double *amb, *dif, *spc;
     if (li < 0) {
       if (m->headlight[0] == 0) continue;
@@ -940,6 +947,7 @@ static void ora_shade(const ora_model* m, const ora_data* d, const double* cm, i
         v3_sub(L, pos, p);
         double dist = sqrt(v3_dot(L, L));
         if (dist < ORA_MINVAL) continue;
+        light_dist = dist;
         L[0] /= dist; L[1] /= dist; L[2] /= dist;
         const double* k = m->light_attenuation + 3 * li;
         scale = 1.0 / (k[0] + k[1] * dist + k[2] * dist * dist);
@@ -950,6 +958,14 @@ static void ora_shade(const ora_model* m, const ora_data* d, const double* cm, i
       }
     }
     double nl = v3_dot(n, L), sp = 0;
+    if (nl > 0 && scale > 0 && li >= 0 && m->light_castshadow[li]) {
+      /* the shadow ray: is another opaque geom between the point and the light? */
+      for (int g = 0; g < m->ngeom && nl > 0; g++) {
+        if (g == hit || m->geom_rgba[4 * g + 3] == 0) continue;
+        double x = ora_ray_geom(m->geom_type[g], d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, p, L);
+        if (x >= 0 && (m->light_directional[li] || x < light_dist)) nl = 0;
+      }
+    }
     if (nl > 0) {
       double H[3] = {L[0] + V[0], L[1] + V[1], L[2] + V[2]};
       double hn = sqrt(v3_dot(H, H));

@@ -404,6 +404,42 @@ def test_render_kernel_shades_like_the_oracle(tmp_path):
         h.close(); ora.close()
 
 
+def test_render_kernel_casts_the_oracles_shadows(tmp_path):
+    """Row a14, shadows: the lights' shadow rays in the ray kernel (fp32, occluders culled once per block and light)
+    against the oracle's (fp64, every geom): a sphere over the floor on and off the spot light's axis, a box and a capsule
+    between light and floor, a directional light, castshadow off.  Away from the shadows' and the silhouettes' edges
+    (where an fp32 ray may fall on the other side) the images agree to one level; the shadow itself is there (the floor
+    under the sphere is as dark as the floor outside the light's cone)."""
+    from tests.test_render_shading import SHADOW_SCENE
+    scenes = [SHADOW_SCENE.format(x=0.0, h=1.5, r=0.3, light=""), SHADOW_SCENE.format(x=1.0, h=1.5, r=0.3, light=""),
+              SHADOW_SCENE.format(x=0.0, h=1.5, r=0.3, light='castshadow="false"'),
+              SHADOW_SCENE.format(x=0.4, h=1.0, r=0.2, light='directional="true"').replace('dir="0 0 -1"', 'dir="0.3 0.1 -1"'),
+              SHADOW_SCENE.format(x=-0.8, h=0.7, r=0.25, light="").replace(
+                  "</worldbody>", '<body pos="0.9 0.5 1.2" euler="20 30 0"><freejoint/><geom type="box" size="0.3 0.15 0.1" '
+                  'rgba="0 1 0 1"/></body><body pos="0.2 -1.0 0.9" euler="0 70 20"><freejoint/><geom type="capsule" '
+                  'size="0.08 0.4" rgba="0 0 1 1"/></body></worldbody>')]
+    for k, text in enumerate(scenes):
+        path = tmp_path / f"shadow{k}.xml"
+        path.write_text(text)
+        packed = blob.pack(mjcf.compile_mjcf(str(path)))
+        h = _capi.Handle(packed, 2)
+        h.reset()
+        ora = OracleEnv(packed)
+        for size in (129, 64):
+            got = h.render(size, size).astype(int)[1, 0]
+            ref = ora.render(0, size, size).reshape(size, size, 3).astype(int)
+            differ = np.abs(got - ref).max(axis=-1)
+            assert (differ > 1).mean() < 0.004, (k, size, (differ > 1).mean())        # edge pixels only
+            assert (differ > 0).mean() < 0.015, (k, size)
+            if k == 0:
+                mid = size // 2
+                col = mid + int(round(0.5 / (2 * np.tan(np.radians(22.5)) * 10 / size)))
+                assert np.array_equal(got[mid, col], [89, 102, 115]) and np.array_equal(ref[mid, col], [89, 102, 115])
+            if k == 2:
+                assert (differ > 1).sum() <= 8
+        h.close(); ora.close()
+
+
 # --------------------------------------------------------------------------- levels with more bodies / geoms than lanes
 def test_arena_with_73_geoms_on_the_device(tmp_path):
     """74 bodies, 73 geoms: the compiler folds the static bodies into the world (53 bodies left), the kernels take geoms

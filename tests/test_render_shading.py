@@ -104,3 +104,91 @@ def test_shipped_levels_carry_their_light_and_the_default_headlight():
     assert ant.light_directional[0] == 1 and ant.light_cutoff[0] == 100 and np.allclose(ant.light_specular, 0.1)
     assert np.allclose(ant.geom_matprop[0], [1.0, 1.0, 0.0]) and np.allclose(ant.geom_rgba[0], [0.8, 0.9, 0.8, 1])
     assert np.allclose(ant.light_dir[0], [0, 0, -1])                   # "-0 0 -1.3" normalised
+
+
+# ---------------------------------------------------------------------------------------- shadows (round 4)
+SHADOW_SCENE = """<mujoco>
+  <worldbody>
+    <light diffuse=".5 .5 .5" pos="0 0 3" dir="0 0 -1" {light}/>
+    <geom type="plane" size="20 20 1" rgba="0.2 0.3 0.4 1"/>
+    <camera name="down" pos="0 0 10"/>
+    <body pos="{x} 0 {h}"><freejoint/><geom type="sphere" size="{r}" rgba="1 0 0 1"/></body>
+  </worldbody>
+</mujoco>"""
+
+
+def shadow_image(tmp_path, x, h, r, size, light=""):
+    path = tmp_path / "shadow.xml"
+    path.write_text(SHADOW_SCENE.format(x=x, h=h, r=r, light=light))
+    model = mjcf.compile_mjcf(str(path))
+    ora = OracleEnv(blob.pack(model))
+    img = ora.render(0, size, size).reshape(size, size, 3).astype(int)
+    ora.close()
+    return model, img
+
+
+def test_a_sphere_under_the_spot_light_darkens_exactly_its_projection(tmp_path):
+    """body/light castshadow (default true): a sphere of radius r at height h on the light's axis (the level's light:
+    pos 0 0 3, pointing down) shadows the floor disc of radius 3 tan(asin(r / (3 - h))) -- there the light's diffuse and
+    specular terms are gone and what is left is the headlight's part, the colour the floor has OUTSIDE the light's cone;
+    beyond the disc the floor is lit as before.  Seen from straight above (camera at height 10) the sphere itself hides
+    the inner part of its shadow."""
+    r, h, size = 0.3, 1.5, 129
+    model, img = shadow_image(tmp_path, 0.0, h, r, size)
+    assert list(model.light_castshadow) == [1]
+    rgba, mid = (0.2, 0.3, 0.4), size // 2
+    shadow_radius = 3.0 * np.tan(np.arcsin(r / (3.0 - h)))                 # 0.612
+    hidden_radius = 10.0 * np.tan(np.arcsin(r / (10.0 - h)))               # 0.353: the camera sees the sphere there
+    assert 0.61 < shadow_radius < 0.62 and 0.35 < hidden_radius < 0.36
+    dark = expected(floor_x(size - 1, size), rgba)                         # the headlight alone
+    assert np.array_equal(dark, [89, 102, 115])
+    seen_dark = seen_lit = 0
+    for col in range(mid, size):
+        x = floor_x(col, size)
+        pitch = floor_x(1, size) - floor_x(0, size)
+        if hidden_radius + pitch < x < shadow_radius - pitch:
+            assert np.array_equal(img[mid, col], dark), (col, x)
+            assert np.array_equal(img[col, mid], dark) and np.array_equal(img[mid, size - 1 - col], dark)      # a disc
+            seen_dark += 1
+        elif shadow_radius + pitch < x < 2.9:
+            assert np.abs(img[mid, col] - expected(x, rgba)).max() <= 1, (col, x)
+            seen_lit += 1
+    assert seen_dark >= 2 and seen_lit >= 20
+    assert img[mid, mid][0] == 255 and img[mid, mid][0] > img[mid, mid][1] + 100      # the (red) sphere itself, lit from above
+    # the same scene with castshadow="false": no disc
+    model, flat = shadow_image(tmp_path, 0.0, h, r, size, light='castshadow="false"')
+    assert list(model.light_castshadow) == [0]
+    col = mid + int(round(0.5 / (floor_x(1, size) - floor_x(0, size))))     # a floor point 0.5 from the axis
+    assert np.abs(flat[mid, col] - expected(floor_x(col, size), rgba)).max() <= 1
+    assert np.array_equal(img[mid, col], dark)
+
+
+def test_the_shadow_of_a_sphere_off_the_axis_lies_where_the_lights_rays_put_it(tmp_path):
+    """The projection is from the light's POSITION: a sphere at (1, 0, 1.5) shadows the floor between
+    x = 3 tan(theta - alpha) and 3 tan(theta + alpha), theta = atan(1 / 1.5) the direction of its centre from the light,
+    alpha = asin(r / distance) its angular radius -- 1.343 .. 2.824, centred (its centre's ray) on x = 2."""
+    r, size = 0.3, 129
+    model, img = shadow_image(tmp_path, 1.0, 1.5, r, size)
+    rgba, mid = (0.2, 0.3, 0.4), size // 2
+    theta, alpha = np.arctan(1.0 / 1.5), np.arcsin(r / np.hypot(1.0, 1.5))
+    x_near, x_far = 3.0 * np.tan(theta - alpha), 3.0 * np.tan(theta + alpha)
+    assert abs(x_near - 1.343) < 2e-3 and abs(x_far - 2.824) < 2e-3
+    dark = np.array([89, 102, 115])
+    pitch = floor_x(1, size) - floor_x(0, size)
+    checked = 0
+    for col in range(mid, size):
+        x = floor_x(col, size)
+        if 1.6 < x < x_far - pitch:                      # (the sphere hides the floor up to x = 1.53 from the camera)
+            assert np.array_equal(img[mid, col], dark), (col, x)
+            checked += 1
+        elif x_far + pitch < x < 2.95:
+            assert np.abs(img[mid, col] - expected(x, rgba)).max() <= 1, (col, x)
+            checked += 100
+    assert checked % 100 >= 8 and checked >= 100
+    # nothing of the kind on the other side of the axis
+    for col in range(0, mid - 8):
+        x = floor_x(col, size)
+        if -2.9 < x:
+            assert np.abs(img[mid, col] - expected(x, rgba)).max() <= 1
+    # the shadow is symmetric about the plane y = 0 the sphere's centre lies in
+    assert np.array_equal(img[mid - 3], img[mid + 3])
