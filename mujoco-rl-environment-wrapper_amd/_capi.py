@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmjrl_hip.so")
+LIB_PATH = os.environ.get("MJRL_LIB") or os.path.join(_HERE, "csrc", "libmjrl_hip.so")     # (MJRL_LIB: experiments, A/B of two builds)
 
 # every symbol include/mjrl.h declares
 SYMBOLS = [

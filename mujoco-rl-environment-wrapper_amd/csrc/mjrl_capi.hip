@@ -229,13 +229,19 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
   // device they were 600 of a wave's 5 k instructions)
   const float t = consts[cam], aspect = (float)width / (float)height;
   const float inv_w = 2.0f / (float)width, inv_h = 2.0f / (float)height;
-  // The wave's 64 rays cover an 8x8 block of pixels at a time.  Lane g first tests geom g's bounding sphere against the
-  // block's bounding cone (all geoms at once); the rays then visit only the geoms that passed, each ray with its own
-  // bounding-sphere test before the type-specific one.  Both tests are conservative (they may pass a geom the ray misses).
-  const int bw = (width + 7) / 8, nblock = bw * ((height + 7) / 8);
-  (void)nblock;
+  // TWO RAYS PER LANE (round 4).  The wave's 128 rays cover a block of 16 x 8 pixels at a time, lane L the pixels
+  // (r0 + L / 8, c0 + L % 8) and the one 8 columns to its right: a pair's arithmetic runs in packed fp32 (mjrl_rayf.h,
+  // "two rays per lane"), and what a block costs per candidate geom whatever the rays do -- five v_readlane for its
+  // record, the ballots, the loop -- is paid once for 128 rays instead of once for 64.  Lane g first tests geom g's
+  // bounding sphere against the block's bounding cone (all geoms at once); the rays then visit only the geoms that passed,
+  // each ray with its own bounding-sphere test before the type-specific one.  Both tests are conservative.
+  const int bw = (width + 15) / 16;
   auto pixel_ray = [&](float px, float py) {        // px, py in pixel units, pixel centres at +0.5
     return normalizedf(mulf(cm, f3((px * inv_w - 1.0f) * t * aspect, (py * inv_h - 1.0f) * t, -1.0f)));
+  };
+  auto pixel_rays = [&](f2 px, float py) {
+    return normalized2(mul2(cm, p3((px * splat2(inv_w) - splat2(1.0f)) * splat2(t) * splat2(aspect), splat2((py * inv_h - 1.0f) * t),
+                                   splat2(-1.0f))));
   };
   const bool my_geom = L < m.ngeom && rgba_of(L < m.ngeom ? L : 0, 3) != 0;
   const int my_type = my_geom ? m.geom_type[L] : -1;
@@ -243,29 +249,30 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
   const F3 my_rel = my_geom ? ldf3(GP + 3 * L) : origin;
   // The bounding cones of the wave's blocks -- axis through the block's centre, half-angle from its corner rays: five
   // rays per block -- are computed 64 blocks at a time, lane j the cone of the j-th block to come, and handed out
-  // through scalar registers (every lane computing every block's cone was 85 of a block's 800 instructions).
+  // through scalar registers.
   F3 cone_axis = origin;
   float cone_cos = 1.0f, cone_sin = 0.0f;
   int ahead = 0;
+  auto lane_f = [&](float v, int src) { return __int_as_float(wv::lane_int(__float_as_int(v), src)); };
   for (int blk = blk0; blk < blk1; blk += blk_step, ahead++) {
     if ((ahead & 63) == 0) {
-      const int mine = blk + L * blk_step, mr0 = (mine / bw) * 8, mc0 = (mine % bw) * 8;
-      cone_axis = pixel_ray(mc0 + 4.0f, mr0 + 4.0f);
+      const int mine = blk + L * blk_step, mr0 = (mine / bw) * 8, mc0 = (mine % bw) * 16;
+      cone_axis = pixel_ray(mc0 + 8.0f, mr0 + 4.0f);
       float cosmin = 1.0f;
       for (int k = 0; k < 4; k++)
-        cosmin = fminf(cosmin, dotf(cone_axis, pixel_ray(mc0 + ((k & 1) ? 7.5f : 0.5f), mr0 + ((k & 2) ? 7.5f : 0.5f))));
+        cosmin = fminf(cosmin, dotf(cone_axis, pixel_ray(mc0 + ((k & 1) ? 15.5f : 0.5f), mr0 + ((k & 2) ? 7.5f : 0.5f))));
       cone_cos = cosmin * (1.0f - 1e-5f) - 1e-6f;
       cone_sin = fsqrt(fmaxf(1.0f - cone_cos * cone_cos, 0.0f));
     }
-    const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 8, from = ahead & 63;
-    auto pick = [&](float v) { return __int_as_float(wv::lane_int(__float_as_int(v), from)); };
-    const F3 axis = f3(pick(cone_axis.x), pick(cone_axis.y), pick(cone_axis.z));
-    const float cos_t = pick(cone_cos), sin_t = pick(cone_sin);
+    const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 16, from = ahead & 63;
+    const F3 axis = f3(lane_f(cone_axis.x, from), lane_f(cone_axis.y, from), lane_f(cone_axis.z, from));
+    const float cos_t = lane_f(cone_cos, from), sin_t = lane_f(cone_sin, from);
     const int r = r0 + (L >> 3), c = c0 + (L & 7);
-    const bool inside = r < height && c < width;
-    const F3 vec = pixel_ray(c + 0.5f, r + 0.5f);
-    float best = -1;
-    int hit = -1;
+    B2 inside; inside.x = r < height && c < width; inside.y = r < height && c + 8 < width;
+    const P3 vec = pixel_rays(mk2(c + 0.5f, c + 8.5f), r + 0.5f);
+    const P3 at_eye = splat3(origin);
+    f2 best = splat2(-1.0f);
+    int hit0 = -1, hit1 = -1;
     // the geoms in chunks of 64, lane g of a chunk standing for geom base + g (one chunk unless the level has more than
     // 64 geoms; the first chunk's records live in registers for the whole kernel, a later chunk's are fetched per block)
     auto visit = [&](int base, bool geom_on, int type_v, float rb_v, F3 rel_v) {
@@ -276,29 +283,23 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
         cand = !(along + rb_v < 0.0f) && perp * cos_t - along * sin_t <= rb_v + 1e-5f * (1.0f + perp);
       }
       unsigned long long todo = wv::ballot(cand);
-#if MJRL_RENDER_VARIANT == 4       // (experiment: no candidates at all)
-      todo &= 1ull;
-#endif
       while (todo) {
         const int g = __builtin_ctzll(todo);
         todo &= todo - 1;
         // (geom g's type, bounding radius and position come from lane g's registers: no memory latency per candidate)
-        int gt = wv::lane_int(type_v, g);
-        const F3 rel = f3(__int_as_float(wv::lane_int(__float_as_int(rel_v.x), g)), __int_as_float(wv::lane_int(__float_as_int(rel_v.y), g)),
-                          __int_as_float(wv::lane_int(__float_as_int(rel_v.z), g)));
-        if (!inside) gt = -1;
-        else if (gt != GEOM_PLANE) {
-          const float rb = __int_as_float(wv::lane_int(__float_as_int(rb_v), g));
-          const float along = dotf(rel, vec), d2 = dotf(rel, rel) - along * along;
-          if (d2 > rb * rb + 1e-5f * (1.0f + dotf(rel, rel)) || along + rb < 0.0f) gt = -1;
+        const int gt = wv::lane_int(type_v, g);
+        const F3 rel = f3(lane_f(rel_v.x, g), lane_f(rel_v.y, g), lane_f(rel_v.z, g));
+        B2 on = inside;
+        if (gt != GEOM_PLANE) {
+          const float rb = lane_f(rb_v, g), rr = dotf(rel, rel);
+          const f2 along = dot2(splat3(rel), vec), d2 = splat2(rr) - along * along;
+          const float lim = rb * rb + 1e-5f * (1.0f + rr);
+          on = and2(on, not2(or2(gt2(d2, splat2(lim)), lt2(along + splat2(rb), splat2(0.0f)))));
         }
-        if (!wv::ballot(gt >= 0)) continue;           // no ray of the wave comes near this geom
-#if MJRL_RENDER_VARIANT == 3       // (experiment: the candidate loop without the type-specific tests)
-        const float x = gt >= 0 ? dotf(rel, vec) : -1.0f;
-#else
-        const float x = ray_geomf(gt, rel, GM + 9 * (base + g), ldf3(GS + 3 * (base + g)), origin, vec);
-#endif
-        if (x >= 0 && (best < 0 || x < best)) { best = x; hit = base + g; }
+        if (!wv::ballot(on.x || on.y)) continue;           // no ray of the wave comes near this geom
+        const f2 x = ray_geom2(gt, on, rel, GM + 9 * (base + g), ldf3(GS + 3 * (base + g)), at_eye, vec);
+        if (x.x >= 0 && (best.x < 0 || x.x < best.x)) { best.x = x.x; hit0 = base + g; }
+        if (x.y >= 0 && (best.y < 0 || x.y < best.y)) { best.y = x.y; hit1 = base + g; }
       }
     };
     visit(0, my_geom, my_type, my_rb, my_rel);
@@ -308,147 +309,184 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
       visit(base, on, on ? m.geom_type[g] : -1, on ? (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f : 0.0f,
             on ? ldf3(GP + 3 * g) : origin);
     }
-    unsigned char out[3] = {0, 0, 0};
-    // (the shading runs for the whole wave, lanes without a hit computing on geom 0 and storing nothing: the shadow pass
-    // below needs every lane in its role as a GEOM, whatever its pixel saw)
-    if (wv::ballot(hit >= 0)) {
+    unsigned packed0 = 0u, packed1 = 0u;
+    // (the shading runs for the whole wave, rays without a hit computing on geom 0 and storing nothing: the shadow pass
+    // below needs every lane in its role as a GEOM, whatever its pixels saw)
+    if (wv::ballot(hit0 >= 0 || hit1 >= 0)) {
       // OpenGL's fixed-function lighting equation with the parameters MuJoCo documents (oracle/ora_step.c ora_shade, the
       // same arithmetic in double): emission + per light att * spot * (ambient + max(n.L, 0) diffuse + (n.H)^shininess
       // specular), the geom's rgba as ambient and diffuse material colour, clamped once at the end
-      const bool shaded = hit >= 0;
-      const int hs = shaded ? hit : 0;
-      const F3 P = vec * (shaded ? best : 1.0f);
-      const F3 n = geom_normalf(m.geom_type[hs], ldf3(GP + 3 * hs), GM + 9 * hs, ldf3(GS + 3 * hs), P);
-      const float spec_m = MP[3 * hs], shin = MP[3 * hs + 1], emis = MP[3 * hs + 2];
-      const F3 mat = ldf3(GC + 3 * hs);
-      const F3 V = f3(-LT[3], -LT[4], -LT[5]);               // towards the viewer (at infinity): the camera's +z axis
-      float col[3] = {emis * mat.x, emis * mat.y, emis * mat.z};
-#if MJRL_RENDER_VARIANT == 1
-      { const float shade = 0.4f + 0.6f * fmaxf(-dotf(n, vec), 0.0f); col[0] = mat.x * shade; col[1] = mat.y * shade; col[2] = mat.z * shade; }
-      for (int li = 0; li < 0; li++) {
-#else
+      B2 shaded; shaded.x = hit0 >= 0; shaded.y = hit1 >= 0;
+      const int hs0 = shaded.x ? hit0 : 0, hs1 = shaded.y ? hit1 : 0;
+      const P3 P = vec * sel2(shaded, best, splat2(1.0f));
+      const P3 n = pair3(geom_normalf(m.geom_type[hs0], ldf3(GP + 3 * hs0), GM + 9 * hs0, ldf3(GS + 3 * hs0), first3(P)),
+                         geom_normalf(m.geom_type[hs1], ldf3(GP + 3 * hs1), GM + 9 * hs1, ldf3(GS + 3 * hs1), second3(P)));
+      // the direction and distance of light li from the pair's surface points, and whether they lie in its cone at all
+      auto light_geometry = [&](const float* T, bool directional, P3& Ld, f2& light_dist, f2& d2raw, f2& cc) {
+        const F3 dir = ldf3(T + 3);
+        Ld = splat3(dir * -1.0f);
+        light_dist = splat2(3.0e38f); d2raw = splat2(1.0f); cc = splat2(1.0f);
+        if (!directional) {
+          const P3 to_light = splat3(ldf3(T)) - P;
+          d2raw = dot2(to_light, to_light);
+          const f2 d2 = fmax2(d2raw, splat2(1e-30f));          // (a point AT the light: its terms come out finite, then 0)
+          const f2 inv = frsq2(d2);
+          light_dist = d2 * inv;
+          Ld = to_light * inv;
+          cc = -dot2(Ld, splat3(dir));
+        }
+      };
+      // The lights' shadows FIRST (MuJoCo draws them for every light with castshadow; oracle/ora_step.c ora_shade), as one
+      // bit per light and ray, before the shading proper loads its materials and colours: a ray from the surface point
+      // towards the light, and if another opaque geom lies on it the light's diffuse and specular terms go.  Which geoms can
+      // lie on ANY of the block's shadow rays is decided once per block and light, lane g for geom g: the block's lit
+      // points lie in a ball B (on the block's cone between the nearest and the farthest hit), their rays in the hull of
+      // B and the light, and a geom whose bounding sphere stays clear of that hull is no candidate.
+      unsigned dark0 = 0u, dark1 = 0u;
+#pragma unroll 1
+      for (int li = 1; li <= m.nlight && li < 32; li++) {
+        const float* T = LT + LIGHT_FLOATS * li;
+        if (wv::first_int(__float_as_int(T[21])) == 0) continue;
+        const bool directional = wv::first_int(__float_as_int(T[20])) != 0;
+        P3 Ld; f2 light_dist, d2raw, cc;
+        light_geometry(T, directional, Ld, light_dist, d2raw, cc);
+        B2 lit = and2(shaded, gt2(dot2(n, Ld), splat2(0.0f)));
+        if (!directional) {
+          lit = and2(lit, not2(lt2(d2raw, splat2(1e-30f))));
+          if (T[9] > -1.5f) lit = and2(lit, not2(lt2(cc, splat2(T[9]))));
+        }
+        if (!wv::ballot(lit.x || lit.y)) continue;
+        const B2 was_lit = lit;
+        const F3 dir = ldf3(T + 3);
+        const float tmin = wave_minf(fminf(lit.x ? best.x : 3.0e38f, lit.y ? best.y : 3.0e38f));
+        const float tmax = wave_maxf(fmaxf(lit.x ? best.x : 0.0f, lit.y ? best.y : 0.0f));
+        const F3 bc = axis * (0.5f * (tmin + tmax));
+        const float br = 0.5f * (tmax - tmin) + tmax * sin_t * frcp(fmaxf(cos_t, 0.1f)) + 1e-4f * (1.0f + tmax);
+        F3 toward = dir * -1.0f;
+        float reach = 3.0e38f;
+        if (!directional) {
+          const F3 e = ldf3(T) - bc;
+          const float e2 = fmaxf(dotf(e, e), 1e-30f), inv = rsqrtf(e2);
+          toward = e * inv;
+          reach = e2 * inv;
+        }
+        auto shadow_pass = [&](int base, bool geom_on, int type_v, float rb_v, F3 rel_v) {
+          bool cand = geom_on;
+          if (geom_on) {
+            if (type_v == GEOM_PLANE) {
+              // a ray reaches a plane's front only travelling against its normal; a positional light must lie behind it
+              const F3 pn = colf(GM + 9 * (base + L), 2);
+              cand = directional ? dotf(toward, pn) < 0.0f : dotf(ldf3(T) - rel_v, pn) < br;
+            } else {
+              const F3 w = rel_v - bc;
+              const float along = fminf(fmaxf(dotf(w, toward), 0.0f), reach);
+              const F3 off = w - toward * along;
+              const float lim = rb_v + br;
+              cand = dotf(off, off) <= lim * lim + 1e-5f * (1.0f + dotf(w, w));
+            }
+          }
+          unsigned long long todo = wv::ballot(cand);
+          while (todo) {
+            const int g = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int gt = wv::lane_int(type_v, g);
+            const F3 rel = f3(lane_f(rel_v.x, g), lane_f(rel_v.y, g), lane_f(rel_v.z, g));
+            // (the geom a point lies on is convex: it hides the light only where n.L <= 0)
+            B2 on = lit;
+            on.x = on.x && base + g != hs0; on.y = on.y && base + g != hs1;
+            if (gt != GEOM_PLANE) {
+              const float rb = lane_f(rb_v, g);
+              const P3 w = splat3(rel) - P;
+              const f2 ww = dot2(w, w), along = dot2(w, Ld), d2 = ww - along * along;
+              const f2 lim = splat2(rb * rb) + splat2(1e-5f) * (splat2(1.0f) + ww);
+              on = and2(on, not2(or2(or2(gt2(d2, lim), lt2(along + splat2(rb), splat2(0.0f))), gt2(along - splat2(rb), light_dist))));
+            }
+            if (!wv::ballot(on.x || on.y)) continue;
+            const f2 x = ray_geom2(gt, on, rel, GM + 9 * (base + g), ldf3(GS + 3 * (base + g)), P, Ld);
+            lit = and2(lit, not2(and2(ge2(x, splat2(0.0f)), lt2(x, light_dist))));
+          }
+        };
+        shadow_pass(0, my_geom, my_type, my_rb, my_rel);
+        for (int base = 64; base < m.ngeom; base += 64) {
+          const int g = base + L;
+          const bool on = g < m.ngeom && rgba_of(g < m.ngeom ? g : 0, 3) != 0;
+          shadow_pass(base, on, on ? m.geom_type[g] : -1, on ? (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f : 0.0f,
+                      on ? ldf3(GP + 3 * g) : origin);
+        }
+        if (was_lit.x && !lit.x) dark0 |= 1u << li;
+        if (was_lit.y && !lit.y) dark1 |= 1u << li;
+      }
+      const f2 spec_m = mk2(MP[3 * hs0], MP[3 * hs1]), shin = mk2(MP[3 * hs0 + 1], MP[3 * hs1 + 1]);
+      const f2 emis = mk2(MP[3 * hs0 + 2], MP[3 * hs1 + 2]);
+      const P3 mat = pair3(ldf3(GC + 3 * hs0), ldf3(GC + 3 * hs1));
+      const P3 V = splat3(f3(-LT[3], -LT[4], -LT[5]));        // towards the viewer (at infinity): the camera's +z axis
+      P3 col = p3(emis * mat.x, emis * mat.y, emis * mat.z);
+      auto pow2 = [&](f2 x, f2 y) { return mk2(fast_pow(x.x, y.x), fast_pow(x.y, y.y)); };
 #pragma unroll 1
       for (int li = 0; li <= m.nlight; li++) {
-#endif
         const float* T = LT + LIGHT_FLOATS * li;
-        const F3 dir = ldf3(T + 3);
-        const bool directional = wv::first_int(__float_as_int(T[20])) != 0, casts = wv::first_int(__float_as_int(T[21])) != 0;
-        F3 Ld = dir * -1.0f;
-        float scale = 1.0f, light_dist = 3.0e38f;
+        const bool directional = wv::first_int(__float_as_int(T[20])) != 0;
+        P3 Ld; f2 light_dist, d2raw, cc;
+        light_geometry(T, directional, Ld, light_dist, d2raw, cc);
+        f2 scale = splat2(1.0f);
         if (!directional) {
-          Ld = ldf3(T) - P;
-          const float d2 = fmaxf(dotf(Ld, Ld), 1e-30f);      // (a point AT the light: the terms below come out 0 / finite)
-          const float inv = rsqrtf(d2), dist = d2 * inv;
-          light_dist = dist;
-          Ld = Ld * inv;
-          scale = frcp(T[6] + T[7] * dist + T[8] * d2);
-          const float c = -dotf(Ld, dir);
-          if (T[9] > -1.5f) scale = c < T[9] ? 0.0f : scale * fast_pow(fmaxf(c, 0.0f), T[10]);
-          if (dotf(ldf3(T) - P, ldf3(T) - P) < 1e-30f) scale = 0.0f;
+          const f2 d2 = fmax2(d2raw, splat2(1e-30f));
+          scale = frcp2(splat2(T[6]) + splat2(T[7]) * light_dist + splat2(T[8]) * d2);
+          if (T[9] > -1.5f) scale = sel2(lt2(cc, splat2(T[9])), splat2(0.0f), scale * pow2(fmax2(cc, splat2(0.0f)), splat2(T[10])));
+          scale = sel2(lt2(d2raw, splat2(1e-30f)), splat2(0.0f), scale);
         }
-        float nl = dotf(n, Ld), sp = 0.0f;
-        // The light's shadow (MuJoCo draws it for every light with castshadow; oracle/ora_step.c ora_shade): a ray from the
-        // surface point towards the light, and if another opaque geom lies on it the diffuse and specular terms go.
-        // Which geoms can lie on ANY of the block's shadow rays is decided once per block and light, lane g for geom g:
-        // the block's lit points lie in a ball B (on the block's cone between the nearest and the farthest hit), their
-        // rays in the hull of B and the light, and a geom whose bounding sphere stays clear of that hull is no candidate.
-        bool lit = shaded && nl > 0.0f && scale > 0.0f;
-        if (casts && wv::ballot(lit)) {
-          const float tmin = wave_minf(lit ? best : 3.0e38f), tmax = wave_maxf(lit ? best : 0.0f);
-          const F3 bc = axis * (0.5f * (tmin + tmax));
-          const float br = 0.5f * (tmax - tmin) + tmax * sin_t * frcp(fmaxf(cos_t, 0.1f)) + 1e-4f * (1.0f + tmax);
-          F3 toward = dir * -1.0f;
-          float reach = 3.0e38f;
-          if (!directional) {
-            const F3 e = ldf3(T) - bc;
-            const float e2 = fmaxf(dotf(e, e), 1e-30f), inv = rsqrtf(e2);
-            toward = e * inv;
-            reach = e2 * inv;
-          }
-          auto shadow_pass = [&](int base, bool geom_on, int type_v, float rb_v, F3 rel_v) {
-            bool cand = geom_on;
-            if (geom_on) {
-              if (type_v == GEOM_PLANE) {
-                // a ray reaches a plane's front only travelling against its normal; a positional light must lie behind it
-                const F3 pn = colf(GM + 9 * (base + L), 2);
-                cand = directional ? dotf(toward, pn) < 0.0f : dotf(ldf3(T) - rel_v, pn) < br;
-              } else {
-                const F3 w = rel_v - bc;
-                const float along = fminf(fmaxf(dotf(w, toward), 0.0f), reach);
-                const F3 off = w - toward * along;
-                const float lim = rb_v + br;
-                cand = dotf(off, off) <= lim * lim + 1e-5f * (1.0f + dotf(w, w));
-              }
-            }
-            unsigned long long todo = wv::ballot(cand);
-            while (todo) {
-              const int g = __builtin_ctzll(todo);
-              todo &= todo - 1;
-              int gt = wv::lane_int(type_v, g);
-              const F3 rel = f3(__int_as_float(wv::lane_int(__float_as_int(rel_v.x), g)), __int_as_float(wv::lane_int(__float_as_int(rel_v.y), g)),
-                                __int_as_float(wv::lane_int(__float_as_int(rel_v.z), g)));
-              // (the geom the point lies on is convex: it hides the light only where n.L <= 0)
-              if (!lit || base + g == hs) gt = -1;
-              else if (gt != GEOM_PLANE) {
-                const float rb = __int_as_float(wv::lane_int(__float_as_int(rb_v), g));
-                const F3 w = rel - P;
-                const float along = dotf(w, Ld), d2 = dotf(w, w) - along * along;
-                if (d2 > rb * rb + 1e-5f * (1.0f + dotf(w, w)) || along + rb < 0.0f || along - rb > light_dist) gt = -1;
-              }
-              if (!wv::ballot(gt >= 0)) continue;
-              const float x = ray_geomf(gt, rel, GM + 9 * (base + g), ldf3(GS + 3 * (base + g)), P, Ld);
-              if (x >= 0.0f && x < light_dist) lit = false;
-            }
-          };
-          shadow_pass(0, my_geom, my_type, my_rb, my_rel);
-          for (int base = 64; base < m.ngeom; base += 64) {
-            const int g = base + L;
-            const bool on = g < m.ngeom && rgba_of(g < m.ngeom ? g : 0, 3) != 0;
-            shadow_pass(base, on, on ? m.geom_type[g] : -1, on ? (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f : 0.0f,
-                        on ? ldf3(GP + 3 * g) : origin);
-          }
-          if (!lit) nl = 0.0f;
-        }
-        if (nl > 0.0f) {
-          const F3 H = Ld + V;
-          const float hh = dotf(H, H), nh = hh > 1e-30f ? dotf(n, H) * rsqrtf(hh) : 0.0f;
-          sp = nh > 0.0f ? fast_pow(nh, shin) * spec_m : 0.0f;
-        } else {
-          nl = 0.0f;
-        }
-        col[0] += scale * (T[11] * mat.x + nl * T[14] * mat.x + sp * T[17]);
-        col[1] += scale * (T[12] * mat.y + nl * T[15] * mat.y + sp * T[18]);
-        col[2] += scale * (T[13] * mat.z + nl * T[16] * mat.z + sp * T[19]);
+        f2 nl = dot2(n, Ld);
+        B2 facing = gt2(nl, splat2(0.0f));
+        if (li < 32) { facing.x = facing.x && !((dark0 >> li) & 1u); facing.y = facing.y && !((dark1 >> li) & 1u); }
+        nl = sel2(facing, nl, splat2(0.0f));
+        const P3 H = Ld + V;
+        const f2 hh = dot2(H, H);
+        const f2 nh = sel2(gt2(hh, splat2(1e-30f)), dot2(n, H) * frsq2(fmax2(hh, splat2(1e-30f))), splat2(0.0f));
+        const f2 sp = sel2(and2(facing, gt2(nh, splat2(0.0f))), pow2(fmax2(nh, splat2(0.0f)), shin) * spec_m, splat2(0.0f));
+        col.x = col.x + scale * (splat2(T[11]) * mat.x + nl * splat2(T[14]) * mat.x + sp * splat2(T[17]));
+        col.y = col.y + scale * (splat2(T[12]) * mat.y + nl * splat2(T[15]) * mat.y + sp * splat2(T[18]));
+        col.z = col.z + scale * (splat2(T[13]) * mat.z + nl * splat2(T[16]) * mat.z + sp * splat2(T[19]));
       }
-      if (shaded)
-        for (int k = 0; k < 3; k++) out[k] = (unsigned char)(255.0f * fminf(fmaxf(col[k], 0.0f), 1.0f) + 0.5f);
+      auto level = [&](float v) { return (unsigned)(unsigned char)(255.0f * fminf(fmaxf(v, 0.0f), 1.0f) + 0.5f); };
+      if (shaded.x) packed0 = level(col.x.x) | (level(col.y.x) << 8) | (level(col.z.x) << 16);
+      if (shaded.y) packed1 = level(col.x.y) | (level(col.y.y) << 8) | (level(col.z.y) << 16);
     }
-    // A block's 8 rows of 8 pixels are 8 x 24 bytes: written as 48 dwords, 6 per row, each put together from two
+    // A half block's 8 rows of 8 pixels are 8 x 24 bytes: written as 48 dwords, 6 per row, each put together from two
     // neighbouring lanes' pixels (round 2 stored 3 single bytes per lane: 192 byte stores per block, and four times the
     // pixels' bytes in HBM write traffic, profiles/r02_pmc_render_fp64.txt).  Needs dword-aligned rows, i.e. a width
-    // that is a multiple of 4, and a block wholly inside the image; anything else keeps the byte stores.
-    const bool whole = MJRL_RENDER_VARIANT != 2 && (row_bytes & 3) == 0 && r0 + 8 <= height && c0 + 8 <= width;
-    if (whole) {
-      const unsigned packed = (unsigned)out[0] | ((unsigned)out[1] << 8) | ((unsigned)out[2] << 16);
-      const int prow = L / 6, j = L - 6 * prow;             // lanes 0..47: dword j of the block's pixel row prow
-      const int b = 4 * j, pa = b / 3, o = b - 3 * pa;       // its first byte belongs to pixel pa of that row, byte o
-      const int src = (prow & 7) * 8 + pa;
-      const unsigned lo = (unsigned)wv::shfl((int)packed, src), hi = (unsigned)wv::shfl((int)packed, (src + 1) & 63);
-      const unsigned long long q = (unsigned long long)lo | ((unsigned long long)hi << 24);
-      if (L < 48) *(unsigned*)(img + (size_t)(r0 + prow) * row_bytes + 3 * c0 + 4 * j) = (unsigned)(q >> (8 * o));
-    } else if (inside) {
-      unsigned char* at = img + (size_t)r * row_bytes + 3 * c;
-      at[0] = out[0]; at[1] = out[1]; at[2] = out[2];
-    }
+    // that is a multiple of 4, and a half block wholly inside the image; anything else keeps the byte stores.
+    auto store_half = [&](unsigned packed, int ch0, bool in_image) {
+      const bool whole = (row_bytes & 3) == 0 && r0 + 8 <= height && ch0 + 8 <= width;
+      if (whole) {
+        const int prow = L / 6, j = L - 6 * prow;             // lanes 0..47: dword j of the block's pixel row prow
+        const int b = 4 * j, pa = b / 3, o = b - 3 * pa;       // its first byte belongs to pixel pa of that row, byte o
+        const int src = (prow & 7) * 8 + pa;
+        const unsigned lo = (unsigned)wv::shfl((int)packed, src), hi = (unsigned)wv::shfl((int)packed, (src + 1) & 63);
+        const unsigned long long q = (unsigned long long)lo | ((unsigned long long)hi << 24);
+        if (L < 48) *(unsigned*)(img + (size_t)(r0 + prow) * row_bytes + 3 * ch0 + 4 * j) = (unsigned)(q >> (8 * o));
+      } else if (in_image) {
+        unsigned char* at = img + (size_t)r * row_bytes + 3 * (ch0 + (L & 7));
+        at[0] = (unsigned char)packed; at[1] = (unsigned char)(packed >> 8); at[2] = (unsigned char)(packed >> 16);
+      }
+    };
+    store_half(packed0, c0, inside.x);
+    if (c0 + 8 < width) store_half(packed1, c0 + 8, inside.y);
   }
 }
 
-__global__ __launch_bounds__(64) void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
+// Four waves per SIMD: the pair kernel wants 137 registers (three waves); held to 128 it spills seven dwords per lane in
+// the shadow pass and runs 93 us per 512 x 2 cameras against 102 uncapped (five waves / 96 registers: 126 us, the spills
+// reach the candidate loop).  tools/render_probe.sh.
+#ifndef MJRL_RENDER_WAVES
+#define MJRL_RENDER_WAVES 4
+#endif
+#define MJRL_RENDER_OCC __attribute__((amdgpu_waves_per_eu(MJRL_RENDER_WAVES, MJRL_RENDER_WAVES)))
+__global__ __launch_bounds__(64) MJRL_RENDER_OCC void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
                                                          int tiles, unsigned char* rgb, const int* variant,
                                                          const double* variant_rgba, const float* consts) {
   extern __shared__ float ldsf[];
   const int env = blockIdx.x, cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
-  const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
+  const int nblock = ((width + 15) / 16) * ((height + 7) / 8);          // blocks of 16 x 8 pixels: two rays per lane
   const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
   const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
   render_body(m, scene + (size_t)env * scene_doubles(m), cam, width, height, blk0, blk1, 1, ldsf,
@@ -1617,9 +1655,12 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
                        e->qpos, e->n_env, e->scene);
     MJRL_HIP(e, hipGetLastError());
   }
-  // groups of 8x8 pixel blocks per camera: enough workgroups to fill the chip's wave slots a few times over
-  const int nblock = ((width + 7) / 8) * ((height + 7) / 8);
-  const int target = 8 * 2048;         // (2 / 4 / 8 / 16 x 2048 measured: 0.247 / 0.228 / 0.218 / 0.224 ms per config-5 step)
+  // groups of 16 x 8 pixel blocks per camera: enough workgroups to fill the chip's wave slots a few times over
+  const int nblock = ((width + 15) / 16) * ((height + 7) / 8);
+  // (round 3, 8 x 8 blocks: 2 / 4 / 8 / 16 x 2048 measured 0.247 / 0.228 / 0.218 / 0.224 ms per config-5 step; round 4,
+  // 16 x 8 blocks of two rays per lane: 4 x 2048 -- four blocks per wave at 512 copies -- 93 us per launch, 8 x 2048 97)
+  int target = 4 * 2048;
+  if (const char* tv = getenv("MJRL_RENDER_TARGET")) target = atoi(tv) * 2048;       // (experiments)
   int tiles = (int)((target + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
   tiles = std::max(1, std::min(tiles, std::max(1, nblock / 2)));
   hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), render_lds_bytes(e->hm), e->stream, e->dm,

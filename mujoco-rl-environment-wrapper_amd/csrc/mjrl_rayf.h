@@ -142,6 +142,129 @@ __device__ __forceinline__ F3 geom_normalf(int type, F3 gp, const float* gm, F3 
   return l >= 0 ? n : n * -1.0f;
 }
 
+// ------------------------------------------------------------------ two rays per lane
+// The same routines for TWO rays at once, the pair in the halves of 64-bit registers: multiplies, adds and fused
+// multiply-adds of a pair are one packed instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, the full-rate fp32 of
+// this chip); comparisons, selects and the transcendental unit's rcp / sqrt / rsq stay one instruction per ray.  Every
+// expression is the scalar routine's, term for term (the same products feed the same sums, so the front end contracts
+// the same multiply-adds): a pair's results are the two scalar results.  Where the scalar routine returns early the
+// pair computes on and selects, with arguments clamped where the discarded branch would leave the domain.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct B2 { bool x, y; };                                    // a condition per ray
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 splat2(float a) { return mk2(a, a); }
+__device__ __forceinline__ f2 sel2(B2 c, f2 a, f2 b) { return mk2(c.x ? a.x : b.x, c.y ? a.y : b.y); }
+__device__ __forceinline__ B2 and2(B2 a, B2 b) { B2 r; r.x = a.x && b.x; r.y = a.y && b.y; return r; }
+__device__ __forceinline__ B2 or2(B2 a, B2 b) { B2 r; r.x = a.x || b.x; r.y = a.y || b.y; return r; }
+__device__ __forceinline__ B2 not2(B2 a) { B2 r; r.x = !a.x; r.y = !a.y; return r; }
+__device__ __forceinline__ B2 lt2(f2 a, f2 b) { B2 r; r.x = a.x < b.x; r.y = a.y < b.y; return r; }
+__device__ __forceinline__ B2 le2(f2 a, f2 b) { B2 r; r.x = a.x <= b.x; r.y = a.y <= b.y; return r; }
+__device__ __forceinline__ B2 gt2(f2 a, f2 b) { B2 r; r.x = a.x > b.x; r.y = a.y > b.y; return r; }
+__device__ __forceinline__ B2 ge2(f2 a, f2 b) { B2 r; r.x = a.x >= b.x; r.y = a.y >= b.y; return r; }
+__device__ __forceinline__ f2 frcp2(f2 a) { return mk2(frcp(a.x), frcp(a.y)); }
+__device__ __forceinline__ f2 fsqrt2(f2 a) { return mk2(fsqrt(a.x), fsqrt(a.y)); }
+__device__ __forceinline__ f2 frsq2(f2 a) { return mk2(frsq(a.x), frsq(a.y)); }
+__device__ __forceinline__ f2 fabs2(f2 a) { return mk2(fabsf(a.x), fabsf(a.y)); }
+__device__ __forceinline__ f2 fmin2(f2 a, f2 b) { return mk2(fminf(a.x, b.x), fminf(a.y, b.y)); }
+__device__ __forceinline__ f2 fmax2(f2 a, f2 b) { return mk2(fmaxf(a.x, b.x), fmaxf(a.y, b.y)); }
+
+struct P3 { f2 x, y, z; };                                   // a 3-vector per ray
+__device__ __forceinline__ P3 p3(f2 x, f2 y, f2 z) { P3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ P3 splat3(F3 a) { return p3(splat2(a.x), splat2(a.y), splat2(a.z)); }
+__device__ __forceinline__ P3 pair3(F3 a, F3 b) { return p3(mk2(a.x, b.x), mk2(a.y, b.y), mk2(a.z, b.z)); }
+__device__ __forceinline__ F3 first3(P3 a) { return f3(a.x.x, a.y.x, a.z.x); }
+__device__ __forceinline__ F3 second3(P3 a) { return f3(a.x.y, a.y.y, a.z.y); }
+__device__ __forceinline__ P3 operator+(P3 a, P3 b) { return p3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ P3 operator-(P3 a, P3 b) { return p3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ P3 operator*(P3 a, f2 s) { return p3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f2 dot2(P3 a, P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ P3 normalized2(P3 a) {
+  const f2 n2 = dot2(a, a);
+  const B2 tiny = lt2(n2, splat2(1e-40f));
+  const f2 s = frsq2(fmax2(n2, splat2(1e-40f)));
+  return p3(sel2(tiny, splat2(1.0f), a.x * s), sel2(tiny, splat2(0.0f), a.y * s), sel2(tiny, splat2(0.0f), a.z * s));
+}
+__device__ __forceinline__ P3 mul2(const float* m, P3 v) {
+  return p3(splat2(m[0]) * v.x + splat2(m[1]) * v.y + splat2(m[2]) * v.z, splat2(m[3]) * v.x + splat2(m[4]) * v.y + splat2(m[5]) * v.z,
+            splat2(m[6]) * v.x + splat2(m[7]) * v.y + splat2(m[8]) * v.z);
+}
+__device__ __forceinline__ P3 mulT2(const float* m, P3 v) {
+  return p3(splat2(m[0]) * v.x + splat2(m[3]) * v.y + splat2(m[6]) * v.z, splat2(m[1]) * v.x + splat2(m[4]) * v.y + splat2(m[7]) * v.z,
+            splat2(m[2]) * v.x + splat2(m[5]) * v.y + splat2(m[8]) * v.z);
+}
+
+// ray_geomf for a pair of rays against ONE geom (type, frame and size are the pair's, the rays' origins and directions
+// their own); `on`: the ray takes part at all (its result is -1 otherwise)
+__device__ __forceinline__ f2 ray_geom2(int type, B2 on, F3 gp, const float* gm, F3 gs, P3 pnt, P3 vec) {
+  const f2 none = splat2(-1.0f), zero = splat2(0.0f);
+  const P3 rel = pnt - splat3(gp);
+  f2 res = none;
+  if (type == GEOM_PLANE) {
+    const P3 n = splat3(colf(gm, 2));
+    const f2 denom = dot2(vec, n);
+    const B2 front = not2(gt2(denom, splat2(-1e-15f)));
+    const f2 x = -dot2(rel, n) * frcp2(sel2(front, denom, splat2(-1.0f)));
+    const P3 hit = rel + vec * x;
+    B2 ok = and2(front, not2(lt2(x, zero)));
+    if (gs.x > 0) ok = and2(ok, not2(gt2(fabs2(dot2(hit, splat3(colf(gm, 0)))), splat2(gs.x))));
+    if (gs.y > 0) ok = and2(ok, not2(gt2(fabs2(dot2(hit, splat3(colf(gm, 1)))), splat2(gs.y))));
+    res = sel2(ok, x, none);
+  } else if (type == GEOM_SPHERE) {
+    const f2 b = dot2(vec, rel), cc = dot2(rel, rel) - splat2(gs.x) * splat2(gs.x);
+    const f2 det = b * b - cc;
+    const f2 sq = fsqrt2(fmax2(det, zero));
+    const f2 x0 = -b - sq, x1 = -b + sq;
+    res = sel2(lt2(det, zero), none, sel2(ge2(x0, zero), x0, sel2(ge2(x1, zero), x1, none)));
+  } else if (type == GEOM_CAPSULE) {
+    const P3 axis = splat3(colf(gm, 2));
+    const float r = gs.x, len = gs.y;
+    f2 best = none;
+    const f2 va = dot2(vec, axis), ra = dot2(rel, axis), bv = dot2(vec, rel), rr = dot2(rel, rel);
+    const f2 a = dot2(vec, vec) - va * va, b = bv - va * ra, cc = rr - ra * ra - splat2(r) * splat2(r);
+    {
+      const f2 det = b * b - a * cc;
+      const B2 side = and2(gt2(a, splat2(1e-15f)), ge2(det, zero));
+      const f2 sq = fsqrt2(fmax2(det, zero)), inv = frcp2(sel2(gt2(a, splat2(1e-15f)), a, splat2(1.0f)));
+      const f2 xs[2] = {(-b - sq) * inv, (-b + sq) * inv};
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const f2 x = xs[k];
+        const B2 take = and2(and2(side, ge2(x, zero)), and2(le2(fabs2(ra + x * va), splat2(len)), or2(lt2(best, zero), lt2(x, best))));
+        best = sel2(take, x, best);
+      }
+    }
+    const f2 cap = rr + splat2(len) * splat2(len) - splat2(r) * splat2(r), lva = splat2(len) * va, lra2 = splat2(2.0f * len) * ra;
+#pragma unroll
+    for (int s = -1; s <= 1; s += 2) {
+      const f2 sf = splat2((float)s);
+      const f2 bs = bv - sf * lva, cs = cap - sf * lra2, det = bs * bs - cs;
+      const f2 sq = fsqrt2(fmax2(det, zero)), x0 = -bs - sq, x1 = -bs + sq;
+      const f2 x = sel2(ge2(x0, zero), x0, x1);
+      const B2 take = and2(and2(ge2(det, zero), ge2(x, zero)), and2(ge2(sf * (ra + x * va), splat2(len)), or2(lt2(best, zero), lt2(x, best))));
+      best = sel2(take, x, best);
+    }
+    res = best;
+  } else if (type == GEOM_BOX) {
+    const P3 lpv = mulT2(gm, rel), lvv = mulT2(gm, vec);
+    const f2 lp[3] = {lpv.x, lpv.y, lpv.z}, lv[3] = {lvv.x, lvv.y, lvv.z};
+    const float s[3] = {gs.x, gs.y, gs.z};
+    f2 tn = splat2(-3.0e38f), tf = splat2(3.0e38f);
+    B2 miss; miss.x = false; miss.y = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const B2 par = lt2(fabs2(lv[k]), splat2(1e-15f));
+      const f2 inv = frcp2(sel2(par, splat2(1.0f), lv[k]));
+      const f2 t1 = (splat2(-s[k]) - lp[k]) * inv, t2 = (splat2(s[k]) - lp[k]) * inv;
+      miss = or2(miss, and2(par, gt2(fabs2(lp[k]), splat2(s[k]))));
+      tn = sel2(par, tn, fmax2(tn, fmin2(t1, t2)));
+      tf = sel2(par, tf, fmin2(tf, fmax2(t1, t2)));
+    }
+    const f2 x = sel2(ge2(tn, zero), tn, tf);
+    res = sel2(and2(and2(not2(miss), le2(tn, tf)), ge2(x, zero)), x, none);
+  }
+  return sel2(on, res, none);
+}
+
 }  // namespace mj
 
 #endif
