@@ -565,7 +565,7 @@ def main():
         traffic, source = None, None
         # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes of this same
         # command (profiles/, newest round first); `traffic_source` says so in the line
-        for rnd in ("r03", "r02"):
+        for rnd in ("r04", "r03", "r02"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic_{level_name}.json")
             if os.path.exists(pmc) and n_env == work.get("envs", ENVS_PER_GPU) and not on_cpu and language == (level_name == "two_agent"):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")

@@ -1211,7 +1211,7 @@ inline void build_lane_records(const DevModel& m, const Lay& l, int32_t* out) {
 }
 
 // device: one group of the lane's records into registers
-typedef int rec_quad __attribute__((ext_vector_type(4)));
+typedef int rec_quad __attribute__((vector_size(16)));       // (the GNU spelling: the sanitized emulation is built by g++)
 template <typename T>
 __device__ __forceinline__ void fetch_lane_record(const int32_t* table, int first, int L, T& out) {
   static_assert(sizeof(T) % 4 == 0, "records are whole words");

@@ -21,11 +21,16 @@ from mjrl_amd import blob, levels, mjcf
 from tests.emu.emu import EmuEnv
 from tests.emu.batch import EmuBatch
 
+from tests.emu import emu as emu_mod
 rng = np.random.default_rng(0)
 # short trajectories from just above the floor, so that contacts, limit rows, coupling rows and the cap paths are reached
-# within a few dozen steps (a lane switch costs a system call here; the unsanitized suite runs the long trajectories)
-for level, kw, steps in (("two_agent.xml", {}, 240), ("four_agent.xml", {}, 160), ("sensor_touch.xml", dict(nconmax=2, njmax=8), 60),
-                         ("two_agent_3sensors.xml", {}, 120), ("single_agent.xml", dict(lane_map=False), 120)):
+# within a few dozen steps (a lane switch costs a system call here; the unsanitized suite runs the long trajectories);
+# the last two with the solver forms of the build for batches of at most one wave per SIMD (StepArgs::few)
+for level, kw, steps, few in (("two_agent.xml", {}, 240, 0), ("four_agent.xml", {}, 160, 0),
+                              ("sensor_touch.xml", dict(nconmax=2, njmax=8), 60, 0), ("two_agent_3sensors.xml", {}, 120, 0),
+                              ("single_agent.xml", dict(lane_map=False), 120, 0), ("two_agent.xml", {}, 240, 1),
+                              ("four_agent.xml", {}, 160, 1)):
+    emu_mod.lib().emu_set_few(few)
     model = mjcf.compile_mjcf(levels.level_path(level), **kw)
     env = EmuEnv(model, blob.pack(model))
     for j in range(model.njnt):
@@ -37,6 +42,7 @@ for level, kw, steps in (("two_agent.xml", {}, 240), ("four_agent.xml", {}, 160)
         env.ctrl[:model.nu] = rng.uniform(-1, 1, model.nu)
         most = max(most, env.step().ncon)
     assert np.isfinite(env.qpos).all() and most > 0, (level, most)
+emu_mod.lib().emu_set_few(0)
 # random scenes (tests/test_fuzz_scenes.py): box-box items, rows that couple two to four trees, hinge / slide joints
 from tests.test_fuzz_scenes import random_scene
 for seed in (3, 1002, 3001, 5004):

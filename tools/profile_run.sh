@@ -3,7 +3,7 @@
 # command (python3 bench.py --gpus 1 --steps 20 --warmup 5), HBM traffic counters (separate --pmc passes, kernel-trace
 # only), and the counter calibration copy.  Usage: profile_run.sh [level]   (two_agent | four_agent)
 LEVEL=${1:-two_agent}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${ROUND}_$LEVEL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

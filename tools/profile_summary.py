@@ -8,7 +8,7 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 level = sys.argv[1] if len(sys.argv) > 1 else "two_agent"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-ROUND = os.environ.get("ROUND", "r03")
+ROUND = os.environ.get("ROUND", "r04")
 src = os.path.join(ROOT, "gpurun_out", f"prof_{ROUND}_{level}")
 dst = os.environ.get("PROFILE_OUT", os.path.join(ROOT, "profiles"))
 os.makedirs(dst, exist_ok=True)

@@ -2,7 +2,7 @@
 # Everything the round's profiles/ summaries are made from, in one gpurun call (run from the repo root on the GPU box):
 # rocprofv3 stats + HBM counters of the exact driver command (two_agent, four_agent), per-stage instruction mix, wave
 # timelines, stage cycles, the PMC passes of the step and render kernels.  Summaries: tools/profile_summary.py etc.
-export ROUND=${ROUND:-r03}
+export ROUND=${ROUND:-r04}
 O=gpurun_out
 # (raw traces are summarised here and deleted: gpurun copies back at most 64 MiB)
 export PROFILE_OUT=$PWD/$O/profiles_$ROUND
