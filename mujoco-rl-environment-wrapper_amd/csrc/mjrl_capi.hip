@@ -666,7 +666,8 @@ int mjrl_create(const void* blob, size_t nbytes, int n_env, int device_id, unsig
   if (rc) return fail(2, "mjrl_create: model blob rejected (magic/version/size), code " + std::to_string(rc));
   const DevModel& m = e->hm;
   if (m.nv < 1 || m.nv > 64 || m.nbody > 64 || m.njnt > 64 || m.ngeom > 128)
-    return fail(3, "mjrl_create: the model must fit one wavefront (1 <= nv <= 64; nbody, njnt <= 64; ngeom <= 128)");
+    return fail(3, "mjrl_create: the model must fit one wavefront (1 <= nv <= 64; nbody, njnt <= 64 after the compiler has "
+                   "folded the bodies that cannot move; ngeom <= 128): the dof- and body-indexed stages have no second pass");
   if (m.maxdofdepth + 1 > mj::MAX_DOF_DEPTH) return fail(3, "mjrl_create: kinematic chains deeper than 8 dofs are not supported");
   if (m.nconmax > 64 || m.nconmax < 1) return fail(3, "mjrl_create: nconmax must be in 1..64");
   if (m.njmax > 511 || m.njmax < 1) return fail(3, "mjrl_create: njmax must be in 1..511");
