@@ -580,6 +580,8 @@ struct mjrl_env {
   double *p_act = nullptr, *p_obs = nullptr, *p_rew = nullptr;
   unsigned char *p_term = nullptr, *p_trunc = nullptr;
   size_t p_act_n = 0, p_obs_n = 0, p_na = 0;     // elements allocated: actions, observations, rewards / flags
+  void* p_dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // their device addresses, and the host buffers
+  void* p_dev_of[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // they were looked up for
   std::string err;
 };
 
@@ -1576,12 +1578,16 @@ int mjrl_step_pinned(mjrl_env* e, int act_dim, int skip_frames) {
   if (!e->p_rew || !e->p_term || !e->p_trunc || na > e->p_na || na * std::max(act_dim, 1) > e->p_act_n ||
       na * std::max(e->obs_dim, 1) > e->p_obs_n)
     MJRL_FAIL(e, 4, "step_pinned: call mjrl_host_buffers with this act_dim (and after the gather tables are set) first");
-  void *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_term = nullptr, *d_trunc = nullptr;
-  MJRL_HIP(e, hipHostGetDevicePointer(&d_act, e->p_act, 0));
-  MJRL_HIP(e, hipHostGetDevicePointer(&d_obs, e->p_obs, 0));
-  MJRL_HIP(e, hipHostGetDevicePointer(&d_rew, e->p_rew, 0));
-  MJRL_HIP(e, hipHostGetDevicePointer(&d_term, e->p_term, 0));
-  MJRL_HIP(e, hipHostGetDevicePointer(&d_trunc, e->p_trunc, 0));
+  // (the buffers' device addresses: looked up when a buffer is new, not five runtime calls per step)
+  if (e->p_dev_of[0] != e->p_act || e->p_dev_of[1] != e->p_obs || e->p_dev_of[2] != e->p_rew || e->p_dev_of[3] != e->p_term ||
+      e->p_dev_of[4] != e->p_trunc) {
+    void* host[5] = {e->p_act, e->p_obs, e->p_rew, e->p_term, e->p_trunc};
+    for (int k = 0; k < 5; k++) {
+      MJRL_HIP(e, hipHostGetDevicePointer(&e->p_dev[k], host[k], 0));
+      e->p_dev_of[k] = host[k];
+    }
+  }
+  void *d_act = e->p_dev[0], *d_obs = e->p_dev[1], *d_rew = e->p_dev[2], *d_term = e->p_dev[3], *d_trunc = e->p_dev[4];
   int rc = launch_step(e, act_dim > 0 ? (const double*)d_act : nullptr, act_dim, skip_frames, e->d_gather ? (double*)d_obs : nullptr,
                        (double*)d_rew, (uint8_t*)d_term, (uint8_t*)d_trunc, nullptr, 0, 0);
   if (rc) return rc;
