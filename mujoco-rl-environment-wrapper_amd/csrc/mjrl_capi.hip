@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void mjrl_camera_frames_kernel(DevModel m, cons
 // calling wave into `img` (rows of row_bytes bytes), its tables staged in the wave's LDS `ldsf`.
 __device__ __forceinline__ void render_body(const DevModel& m, const double* row, int cam, int width, int height, int blk0,
                                             int blk1, int blk_step, float* ldsf, unsigned char* img, int row_bytes,
-                                            const double* rgba_tab, const float* consts) {
+                                            const double* rgba_tab, const float* consts, int loose_culls) {
   using namespace mj;
   const int L = wv::lane(), tid = L, nthr = 64;
   auto barrier = [&]() { wv::sync(); };
@@ -224,6 +224,29 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
     T[21] = m.light_castshadow[li] ? 1.0f : 0.0f;
   }
   barrier();
+  // Boxes (the arena's walls: 20 m long, bounding spheres of 10 m -- inside every block's cone) get a tighter test than
+  // the sphere's: the block's rays lie in the frustum of its four edge planes, all through the camera, with inward
+  // normals X + a Z, -X - b Z, Y + c Z, -Y - d Z (X, Y, Z the camera's axes; a, b / c, d the block's left, right /
+  // bottom, top edges per unit depth), and a box wholly behind one of them is seen by no ray of the block.  Per box and
+  // camera axis W: the centre's coordinate rel . W and the three half-extents (u_i . W) s_i -- twelve floats, here.
+  float* BX = cm + 12;
+  for (int g = tid; g < m.ngeom; g += nthr) {
+    const F3 rel = ldf3(GP + 3 * g), sz = ldf3(GS + 3 * g);
+    for (int w = 0; w < 3; w++) {
+      const F3 W = colf(cm, w);
+      BX[12 * g + 4 * w] = dotf(rel, W);
+      BX[12 * g + 4 * w + 1] = dotf(colf(GM + 9 * g, 0), W) * sz.x;
+      BX[12 * g + 4 * w + 2] = dotf(colf(GM + 9 * g, 1), W) * sz.y;
+      BX[12 * g + 4 * w + 3] = dotf(colf(GM + 9 * g, 2), W) * sz.z;
+    }
+    // (a plane keeps its normal in camera coordinates there: a block whose four edge rays all point away from the
+    // plane's front -- the half of the image above the horizon -- cannot see it)
+    if (m.geom_type[g] == GEOM_PLANE) {
+      const F3 pn = colf(GM + 9 * g, 2);
+      BX[12 * g] = dotf(pn, colf(cm, 0)); BX[12 * g + 1] = dotf(pn, colf(cm, 1)); BX[12 * g + 2] = dotf(pn, colf(cm, 2));
+    }
+  }
+  barrier();
   const F3 origin = f3(0, 0, 0);
   // (tan(fovy / 2) per camera and cos(cutoff) per light come from the host, mjrl_create: in double precision on the
   // device they were 600 of a wave's 5 k instructions)
@@ -275,12 +298,36 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
     int hit0 = -1, hit1 = -1;
     // the geoms in chunks of 64, lane g of a chunk standing for geom base + g (one chunk unless the level has more than
     // 64 geoms; the first chunk's records live in registers for the whole kernel, a later chunk's are fetched per block)
+    // the block's edges per unit depth (pixel EDGES, so that every pixel centre's ray lies inside)
+    const float e_a = (c0 * inv_w - 1.0f) * t * aspect, e_b = ((c0 + 16) * inv_w - 1.0f) * t * aspect;
+    const float e_c = (r0 * inv_h - 1.0f) * t, e_d = ((r0 + 8) * inv_h - 1.0f) * t;
     auto visit = [&](int base, bool geom_on, int type_v, float rb_v, F3 rel_v) {
       bool cand = geom_on;
       if (geom_on && type_v != GEOM_PLANE) {
         const float along = dotf(rel_v, axis), perp = fsqrt(fmaxf(dotf(rel_v, rel_v) - along * along, 0.0f));
         // (perp cos - along sin is a lower bound of the centre's distance to the cone, negative inside it)
         cand = !(along + rb_v < 0.0f) && perp * cos_t - along * sin_t <= rb_v + 1e-5f * (1.0f + perp);
+      }
+      if (cand && type_v == GEOM_PLANE && !loose_culls) {
+        // n . (lx X + ly Y - Z) is linear in (lx, ly): if it is >= 0 at the block's four corners no ray of the block
+        // travels against the plane's normal (ray_geom2: denom > -1e-15 misses)
+        const float* B = BX + 12 * (base + L);
+        const float nx = B[0], ny = B[1], nz = B[2];
+        const float d0 = nx * e_a + ny * e_c - nz, d1 = nx * e_b + ny * e_c - nz, d2 = nx * e_a + ny * e_d - nz, d3 = nx * e_b + ny * e_d - nz;
+        cand = fminf(fminf(d0, d1), fminf(d2, d3)) < 1e-6f * (fabsf(nx) + fabsf(ny) + fabsf(nz));
+      }
+      if (cand && type_v == GEOM_BOX && !loose_culls) {
+        const float* B = BX + 12 * (base + L);
+        const float cx = B[0], x1 = B[1], x2 = B[2], x3 = B[3], cy = B[4], y1 = B[5], y2 = B[6], y3 = B[7];
+        const float cz = B[8], z1 = B[9], z2 = B[10], z3 = B[11];
+        auto behind = [&](float cw, float w1, float w2, float w3, float edge, float sign) {
+          // signed distance of the box's nearest-to-inside corner from the plane sign (W + edge Z): centre + extent
+          const float centre = sign * (cw + edge * cz);
+          const float extent = fabsf(w1 + edge * z1) + fabsf(w2 + edge * z2) + fabsf(w3 + edge * z3);
+          return centre + extent < -1e-4f * (1.0f + fabsf(centre) + extent);
+        };
+        cand = !(behind(cx, x1, x2, x3, e_a, 1.0f) || behind(cx, x1, x2, x3, e_b, -1.0f) ||
+                 behind(cy, y1, y2, y3, e_c, 1.0f) || behind(cy, y1, y2, y3, e_d, -1.0f));
       }
       unsigned long long todo = wv::ballot(cand);
       while (todo) {
@@ -383,6 +430,18 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
               const F3 off = w - toward * along;
               const float lim = rb_v + br;
               cand = dotf(off, off) <= lim * lim + 1e-5f * (1.0f + dotf(w, w));
+              if (cand && type_v == GEOM_BOX && !loose_culls) {
+                // (a wall's bounding sphere reaches every hull: on each of the box's own axes the hull -- the segment
+                // from the ball's centre towards the light, fattened by the ball's radius -- must overlap the box's slab)
+                const float* gm = GM + 9 * (base + L);
+                const F3 p = mulTf(gm, bc - rel_v), dl = mulTf(gm, toward), sz = ldf3(GS + 3 * (base + L));
+                const float len = directional ? 1.0e30f : reach, pad = br + 1e-4f * (1.0f + br);
+                auto clear = [&](float pi, float di, float si) {
+                  const float qi = pi + di * len;
+                  return fminf(pi, qi) - pad > si || fmaxf(pi, qi) + pad < -si;
+                };
+                cand = !(clear(p.x, dl.x, sz.x) || clear(p.y, dl.y, sz.y) || clear(p.z, dl.z, sz.z));
+              }
             }
           }
           unsigned long long todo = wv::ballot(cand);
@@ -483,18 +542,21 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
 #define MJRL_RENDER_OCC __attribute__((amdgpu_waves_per_eu(MJRL_RENDER_WAVES, MJRL_RENDER_WAVES)))
 __global__ __launch_bounds__(64) MJRL_RENDER_OCC void mjrl_render_kernel(DevModel m, const double* scene, int n_env, int width, int height,
                                                          int tiles, unsigned char* rgb, const int* variant,
-                                                         const double* variant_rgba, const float* consts) {
+                                                         const double* variant_rgba, const float* consts, int loose_culls) {
   extern __shared__ float ldsf[];
   const int env = blockIdx.x, cam = blockIdx.y / tiles, tile = blockIdx.y % tiles;
   const int nblock = ((width + 15) / 16) * ((height + 7) / 8);          // blocks of 16 x 8 pixels: two rays per lane
   const int blk0 = (int)((long long)tile * nblock / tiles), blk1 = (int)((long long)(tile + 1) * nblock / tiles);
   const double* rgba_tab = (variant && variant_rgba) ? variant_rgba + (size_t)variant[env] * 4 * m.ngeom : nullptr;
   render_body(m, scene + (size_t)env * scene_doubles(m), cam, width, height, blk0, blk1, 1, ldsf,
-              rgb + ((size_t)env * m.ncam + cam) * width * height * 3, 3 * width, rgba_tab, consts);
+              rgb + ((size_t)env * m.ncam + cam) * width * height * 3, 3 * width, rgba_tab, consts, loose_culls);
 }
 
 // the ray kernel's LDS: geom positions, matrices and sizes
-inline size_t render_lds_bytes(const DevModel& m) { return (21 * (size_t)m.ngeom + LIGHT_FLOATS * ((size_t)m.nlight + 1) + 9) * sizeof(float); }
+inline size_t render_lds_bytes(const DevModel& m) {
+  // geom positions, matrices, sizes, material properties, colours | lights | camera matrix (padded to 12) | boxes' frustum table
+  return (21 * (size_t)m.ngeom + LIGHT_FLOATS * ((size_t)m.nlight + 1) + 12 + 12 * (size_t)m.ngeom) * sizeof(float);
+}
 
 std::string g_create_error;
 
@@ -1670,8 +1732,11 @@ int mjrl_render_device(mjrl_env* e, int width, int height, uint8_t* d_rgb) {
   if (const char* tv = getenv("MJRL_RENDER_TARGET")) target = atoi(tv) * 2048;       // (experiments)
   int tiles = (int)((target + (size_t)e->n_env * e->hm.ncam - 1) / ((size_t)e->n_env * e->hm.ncam));
   tiles = std::max(1, std::min(tiles, std::max(1, nblock / 2)));
+  // (tests: MJRL_RENDER_LOOSE=1 leaves the boxes to the bounding-sphere culls alone -- the images must not change)
+  const char* lv = getenv("MJRL_RENDER_LOOSE");
+  const int loose = lv && atoi(lv) ? 1 : 0;
   hipLaunchKernelGGL(mjrl_render_kernel, dim3(e->n_env, e->hm.ncam * tiles), dim3(64), render_lds_bytes(e->hm), e->stream, e->dm,
-                     e->scene, e->n_env, width, height, tiles, d_rgb, e->variant, e->variant_rgba, e->render_consts);
+                     e->scene, e->n_env, width, height, tiles, d_rgb, e->variant, e->variant_rgba, e->render_consts, loose);
   MJRL_HIP(e, hipGetLastError());
   return 0;
 }

@@ -440,6 +440,33 @@ def test_render_kernel_casts_the_oracles_shadows(tmp_path):
         h.close(); ora.close()
 
 
+def test_the_boxes_tight_culls_change_no_pixel(monkeypatch):
+    """The ray kernel drops a box from a block's candidates when it lies wholly behind one of the block's four frustum
+    planes, and from a block's shadow candidates when its slab on one of its own axes stays clear of the hull of the
+    block's lit points and the light.  Both are conservative: with them switched off (MJRL_RENDER_LOOSE=1: bounding
+    spheres only) every image of a stepped batch is the same, byte for byte -- at 64 x 64, at a size that is not a
+    multiple of the block, and with a camera looking along a wall."""
+    env = MuJoCoRL({"xmlPath": levels.level_path("two_agent.xml"), "agents": AGENTS, "numEnvs": 24, "agentCameras": True})
+    env.reset()
+    rng = np.random.default_rng(9)
+    for t in range(260):
+        env.step({a: rng.uniform(-1, 1, (24, 8)) for a in AGENTS})
+    # (some copies moved next to a wall, turned)
+    qpos = env._handle.get_field("qpos")
+    qpos[:6, 0] = [9.2, -9.3, 0.0, 3.0, 9.0, -9.0]; qpos[:6, 1] = [0.0, 0.0, 4.3, -4.4, 4.2, -4.2]
+    qpos[:6, 3:7] = [[1, 0, 0, 0], [0.7071, 0, 0, 0.7071], [0.7071, 0, 0, -0.7071], [0.9239, 0, 0, 0.3827], [0, 0, 0, 1], [0.3827, 0, 0, 0.9239]]
+    env._handle.set_field("qpos", qpos)
+    env._handle.set_scene_cache(False)
+    for size in ((64, 64), (72, 40)):
+        monkeypatch.delenv("MJRL_RENDER_LOOSE", raising=False)
+        tight = env._handle.render(*size)
+        monkeypatch.setenv("MJRL_RENDER_LOOSE", "1")
+        loose = env._handle.render(*size)
+        assert np.array_equal(tight, loose), size
+        assert (tight.astype(int).sum(axis=-1) > 0).mean() > 0.3
+    env.close()
+
+
 # --------------------------------------------------------------------------- levels with more bodies / geoms than lanes
 def test_arena_with_73_geoms_on_the_device(tmp_path):
     """74 bodies, 73 geoms: the compiler folds the static bodies into the world (53 bodies left), the kernels take geoms
