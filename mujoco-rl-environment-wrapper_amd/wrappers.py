@@ -55,12 +55,12 @@ class BatchedVectorEnv(_VecBase):
     truncations, infos)``.  ``actions`` is a numpy array or a torch CUDA tensor (outputs: torch tensors in HBM, the launch
     asynchronous on the current torch stream).  It is a ``gymnasium.vector.VectorEnv`` where gymnasium exists.
 
-    ``copy`` (default True, like Gymnasium's own vector envs): what ``step`` returns is the caller's to keep.  numpy:
-    fresh arrays, copied out of the handle's pinned host buffers; torch: tensors of a ring of ``ring`` preallocated
-    output sets, so a result stays valid until ``ring`` further steps have been taken (rollout code that keeps
-    ``last_obs`` across a step, a replay buffer that copies on insert) without an allocation per step.  ``copy=False``
-    is the zero-copy contract: numpy views of the pinned buffers / one set of torch tensors, overwritten in place by the
-    next step and gone after ``close()`` -- for samplers that consume a step's results before taking the next.
+    ``copy`` (default True, like Gymnasium's own vector envs): what ``step`` returns is the caller's to keep, for good.
+    numpy: fresh arrays, copied out of the handle's pinned host buffers; torch: fresh tensors every step (four
+    allocations from torch's caching allocator, no synchronisation; the kernel writes into them directly).
+    ``copy=False`` is the zero-copy contract: numpy views of the pinned buffers / one persistent set of torch tensors,
+    overwritten in place by the next step and gone after ``close()`` -- for samplers that consume a step's results
+    before taking the next.
 
     The adapter puts the handle into the one-agent I/O layout (``mjrl_set_io_layout``): the kernel reads the driven
     agent's action row straight from the caller's ``[num_envs, act_dim]`` array / tensor (no padded copy; the other
@@ -87,7 +87,7 @@ class BatchedVectorEnv(_VecBase):
     MODES = {"next_step": 1, "reset_then_step": 2, "same_step": 0}
 
     def __init__(self, environment, agent: str | None = None, autoreset: str = "next_step", copy: bool = True,
-                 ring: int = 4, obs_dtype=np.float64):
+                 obs_dtype=np.float64):
         if len(environment.agents) != 1 and agent is None:
             raise Exception("BatchedVectorEnv drives one agent; pass `agent` for a multi-agent level")
         if autoreset not in self.MODES:
@@ -120,8 +120,7 @@ class BatchedVectorEnv(_VecBase):
         environment._pinned = None                 # (views of the old layout)
         self._torch_act = None
         self._copy = bool(copy)
-        self._ring, self._ring_at = [], 0
-        self._ring_len = max(int(ring), 2) if copy else 1
+        self._outputs = None              # (copy=False: the one persistent set of torch output tensors)
         environment._handle.set_autoreset(self.MODES[autoreset])
 
     # -- helpers
@@ -166,19 +165,18 @@ class BatchedVectorEnv(_VecBase):
                     obs[done, fresh.shape[1]:] = 0.0
             return obs, reward, term, trunc, info
         import torch
-        if len(self._ring) < self._ring_len or self._ring[0][0].device != actions.device:
-            if self._ring and self._ring[0][0].device != actions.device:
-                self._ring = []
+        if self._copy or self._outputs is None or self._outputs[0].device != actions.device:
             n, na, dev = self.num_envs, self._n_agent, actions.device
-            self._ring.append((torch.empty((n, self._obs_dim), dtype=torch.float32 if self._f32 else torch.float64, device=dev),
-                               torch.empty((n, na), dtype=torch.float64, device=dev),
-                               torch.empty((n, na), dtype=torch.uint8, device=dev),
-                               torch.empty((n, na), dtype=torch.uint8, device=dev)))
-            self._ring_at = len(self._ring) - 1
+            fresh = (torch.empty((n, self._obs_dim), dtype=torch.float32 if self._f32 else torch.float64, device=dev),
+                     torch.empty((n, na), dtype=torch.float64, device=dev),
+                     torch.empty((n, na), dtype=torch.uint8, device=dev),
+                     torch.empty((n, na), dtype=torch.uint8, device=dev))
+            if not self._copy:
+                self._outputs = fresh
         else:
-            self._ring_at = (self._ring_at + 1) % self._ring_len
-        o_obs, o_rew, o_term, o_trunc = self._ring[self._ring_at]
-        # (raw addresses go to the kernel: the action tensor is checked on every call, the ring was made here)
+            fresh = self._outputs
+        o_obs, o_rew, o_term, o_trunc = fresh
+        # (raw addresses go to the kernel: the action tensor is checked on every call, the outputs were made here)
         if not (actions.is_cuda and actions.device.index == env.device_id and actions.dtype == torch.float64
                 and actions.is_contiguous() and actions.dim() == 2 and actions.shape[0] == self.num_envs
                 and actions.shape[1] == self._act_dim):
@@ -211,7 +209,7 @@ class BatchedVectorEnv(_VecBase):
         return obs, reward, term, trunc, info
 
     def close(self, **kwargs):
-        self._ring = []
+        self._outputs = None
         self._torch_act = None
         self.environment.close()
 

@@ -344,8 +344,8 @@ def test_one_agent_io_layout_gives_the_default_layouts_rows(f32, few_build):
 
 def test_vector_env_results_are_the_callers_to_keep_unless_asked_otherwise():
     """copy=True (the default, Gymnasium's own convention): what step() returned is unchanged by later steps -- fresh numpy
-    arrays, torch tensors of a ring; copy=False hands out views of the buffers the next step overwrites.  float32
-    observations are the float64 ones rounded."""
+    arrays, fresh torch tensors; copy=False hands out the buffers the next step overwrites.  float32 observations are the
+    float64 ones rounded."""
     import torch
     from mjrl_amd.wrappers import BatchedVectorEnv
     n_env = 9
@@ -370,11 +370,19 @@ def test_vector_env_results_are_the_callers_to_keep_unless_asked_otherwise():
         v.close()
     tk = make()
     tk.reset()
-    outs = [tk.step(torch.from_numpy(acts[t]).cuda())[0] for t in range(3)]
-    snap = [o.clone() for o in outs]
-    assert outs[0].dtype == torch.float64 and all(torch.equal(a, b) for a, b in zip(outs, snap))     # ring of 4: all valid
-    assert outs[0].data_ptr() != outs[1].data_ptr()
+    outs, snap = [], []
+    for t in range(6):
+        outs.append(tk.step(torch.from_numpy(acts[t]).cuda())[0])
+        snap.append(outs[-1].clone())
+    assert outs[0].dtype == torch.float64 and all(torch.equal(a, b) for a, b in zip(outs, snap))     # every one still its own
+    assert len({o.data_ptr() for o in outs}) == 6
     tk.close()
+    tv = make(copy=False)
+    tv.reset()
+    first = tv.step(torch.from_numpy(acts[0]).cuda())[0]
+    second = tv.step(torch.from_numpy(acts[1]).cuda())[0]
+    assert first.data_ptr() == second.data_ptr()
+    tv.close()
 
 
 # --------------------------------------------------------------------------- camera shading (row a14)
