@@ -105,3 +105,13 @@ def test_bench_py_typed_plainly_starts_its_own_ranks():
     env["WORLD_SIZE"] = "3"
     bad = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_config_one_cpu_leg_of_the_bench_line():
+    """BASELINE configs[0] (single_agent.xml, one copy): the CPU leg of the bench's `configs[0]` entry runs here -- one
+    thread of the oracle through the reference's loop shape -- and reports what it measured on."""
+    import bench
+    bench.entry.load_package()
+    leg = bench.config_one_cpu(seconds=0.4)
+    assert leg["cores"] == 1 and leg["kind"] in ("port", "reference") and leg["unit"] == "env-steps/s"
+    assert leg["value"] > 1000 and "single_agent.xml" in leg["sample"]
