@@ -199,9 +199,11 @@ _ORIENT = {"quat", "euler", "axisangle", "xyaxes", "zaxis"}
 # top-level sections: compiled, or read by nothing in the simulation (custom: user data; size: allocation hints,
 # the caps are config keys here; visual / statistic: rendering scale only)
 _SECTIONS = {"compiler", "option", "size", "default", "asset", "visual", "statistic", "worldbody", "actuator", "sensor",
-             "custom"}
+             "custom", "contact", "keyframe"}
+# (keyframe: mj_resetData -- the reference's reset, mujoco_parent.py:349 -- returns to qpos0 whatever keys the model holds,
+# so the section changes nothing this path computes; contact: <exclude> only, see _pair filter)
 # attribute -> accepted values (None: any value is implemented)
-_COMPILER_ATTRS = {"angle": {"degree", "radian"}, "coordinate": {"local"}, "inertiafromgeom": {"true", "auto"},
+_COMPILER_ATTRS = {"angle": {"degree", "radian"}, "coordinate": {"local"}, "inertiafromgeom": {"true", "auto", "false"},
                    "eulerseq": None, "meshdir": None, "texturedir": None, "assetdir": None, "strippath": None,
                    "autolimits": {"false"}, "fusestatic": {"false"}, "discardvisual": {"false"},
                    "balanceinertia": {"false"}, "usethread": None}
@@ -213,6 +215,7 @@ _OPTION_ATTRS = {"timestep": None, "gravity": None, "integrator": {"Euler", "RK4
 _OPTION_ZERO = {"wind", "density", "viscosity", "o_margin"}
 _ELEMENT_ATTRS = {
     "body": {"name", "pos", "childclass"} | _ORIENT,
+    "inertial": {"pos", "mass", "diaginertia", "fullinertia"} | _ORIENT,
     "geom": {"name", "class", "type", "size", "pos", "fromto", "friction", "density", "mass", "margin", "gap", "condim",
              "contype", "conaffinity", "solref", "solimp", "solmix", "rgba", "material", "group"} | _ORIENT,
     "joint": {"name", "class", "type", "pos", "axis", "limited", "range", "margin", "armature", "damping", "ref",
@@ -230,7 +233,7 @@ _ELEMENT_ATTRS = {
 _NEUTRAL = {("joint", "stiffness"): 0.0, ("joint", "frictionloss"): 0.0, ("joint", "springref"): 0.0,
             ("geom", "priority"): 0.0, ("body", "gravcomp"): 0.0, ("body", "mocap"): "false",
             ("motor", "forcelimited"): "false", ("general", "forcelimited"): "false"}
-_BODY_CHILDREN = {"body", "geom", "joint", "freejoint", "site", "camera", "light"}
+_BODY_CHILDREN = {"body", "geom", "joint", "freejoint", "site", "camera", "light", "inertial"}
 _DEFAULT_CHILDREN = {"default", "geom", "joint", "site", "camera", "light", "motor", "general", "material"}
 _ASSET_CHILDREN = {"texture", "material"}        # textures are parsed and ignored (rendering: DESIGN 4.2)
 
@@ -312,6 +315,11 @@ def check_subset(root: ET.Element):
                 body(child)
     for world in root.findall("worldbody"):
         body(world)
+    for con in root.findall("contact"):
+        for el in con:
+            # (explicit <pair>s carry their own solver parameters and dimensions: not implemented)
+            if el.tag != "exclude" or set(el.attrib) - {"name", "body1", "body2"}:
+                _refuse(f"<contact><{el.tag} {' '.join(el.attrib)}>")
     for act in root.findall("actuator"):
         for el in act:
             if el.tag not in ("motor", "general"):
@@ -335,6 +343,9 @@ class _Compiler:
         check_subset(self.root)
         comp = self.root.find("compiler")
         comp = comp.attrib if comp is not None else {}
+        # inertiafromgeom: "true" infer every body's inertia from its geoms, "false" use <inertial> only, "auto" (the
+        # default) infer where a body has no <inertial>
+        self.inertiafromgeom = comp.get("inertiafromgeom", "auto")
         self.degree = comp.get("angle", "degree") == "degree"
         self.eulerseq = comp.get("eulerseq", "xyz")
         self.defaults = _Defaults(self.root)
@@ -411,6 +422,16 @@ class _Compiler:
                 self.sites.append(dict(name=a.get("name", ""), body=body_id,
                                        pos=_vec(a.get("pos"), 3, [0, 0, 0]), quat=self.orientation(a),
                                        size=_vec(a.get("size"), 3, [0.005, 0.005, 0.005])))
+            elif child.tag == "inertial":
+                # XML reference, body/inertial: pos and mass required; diaginertia in the frame given by the orientation
+                # attributes, or fullinertia (M11 M22 M33 M12 M13 M23) in the body frame
+                a = child.attrib
+                if "pos" not in a or "mass" not in a or not ("diaginertia" in a or "fullinertia" in a):
+                    raise ValueError("<inertial> needs pos, mass and diaginertia or fullinertia")
+                self.bodies[body_id]["inertial"] = dict(
+                    pos=_vec(a["pos"]), quat=self.orientation(a), mass=float(a["mass"]),
+                    diag=_vec(a["diaginertia"]) if "diaginertia" in a else None,
+                    full=_vec(a["fullinertia"]) if "fullinertia" in a else None)
             elif child.tag == "camera":
                 a = self.defaults.apply(child, childclass)
                 self.cams.append(dict(name=a.get("name", ""), body=body_id,
@@ -596,6 +617,17 @@ def _geom_mass_inertia(g):
         inertia = inertia * (g["mass"] / mass)
         mass = g["mass"]
     return mass, inertia
+
+
+def body_subtree_massless(b, parentid, mass):
+    """No body of b's subtree has mass (a moving body may be massless itself when it carries something that is not)."""
+    for k in range(b, len(parentid)):
+        p = k
+        while p > b:
+            p = int(parentid[p])
+        if p == b and mass[k] >= MINVAL:
+            return False
+    return True
 
 
 def _geom_rbound(g):
@@ -831,7 +863,26 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     # ---- body inertial frames from geoms
     body_mass, body_ipos = np.zeros(nbody), np.zeros((nbody, 3))
     body_iquat, body_inertia = np.tile([1.0, 0, 0, 0], (nbody, 1)), np.zeros((nbody, 3))
+    def principal(tensor):
+        """Principal moments (descending) and the right-handed frame of a symmetric inertia tensor."""
+        evals, evecs = np.linalg.eigh(tensor)
+        order = np.argsort(-evals)
+        evals, evecs = evals[order], evecs[:, order]
+        if np.linalg.det(evecs) < 0:
+            evecs[:, 2] = -evecs[:, 2]
+        return evals, mat_to_quat(evecs)
     for b in range(1, nbody):
+        given = c.bodies[b].get("inertial")
+        if given is not None and c.inertiafromgeom != "true":
+            body_mass[b], body_ipos[b] = given["mass"], given["pos"]
+            if given["full"] is not None:
+                f = given["full"]
+                body_inertia[b], body_iquat[b] = principal(np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]]))
+            else:
+                body_inertia[b], body_iquat[b] = given["diag"], given["quat"]
+            continue
+        if c.inertiafromgeom == "false":
+            continue                    # (no <inertial>: massless -- refused below if the body can move)
         parts = []
         for gi in c.bodies[b]["geoms"]:
             mass, inertia = _geom_mass_inertia(c.geoms[gi])
@@ -849,12 +900,12 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
             rot = quat_to_mat(quat)
             d = pos - com
             tensor += rot @ np.diag(inertia) @ rot.T + mass * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
-        evals, evecs = np.linalg.eigh(tensor)
-        order = np.argsort(-evals)
-        evals, evecs = evals[order], evecs[:, order]
-        if np.linalg.det(evecs) < 0:
-            evecs[:, 2] = -evecs[:, 2]
-        body_mass[b], body_ipos[b], body_inertia[b], body_iquat[b] = total, com, evals, mat_to_quat(evecs)
+        evals, iquat = principal(tensor)
+        body_mass[b], body_ipos[b], body_inertia[b], body_iquat[b] = total, com, evals, iquat
+    for b in range(1, nbody):
+        # (MuJoCo's compiler refuses the same: "mass and inertia of moving bodies must be larger than mjMINVAL")
+        if body_jntnum[b] > 0 and (body_mass[b] < MINVAL or np.min(body_inertia[b]) < MINVAL) and body_subtree_massless(b, body_parentid, body_mass):
+            raise ValueError(f"body '{c.bodies[b]['name']}' moves but it and everything it carries have no mass")
     body_subtreemass = body_mass.copy()
     for b in range(nbody - 1, 0, -1):
         body_subtreemass[body_parentid[b]] += body_subtreemass[b]
@@ -945,10 +996,24 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     # ---- candidate collision pairs (static filter), ordered by (geom1, geom2) before type swap
     pairs = []
     gt, gb = A["geom_type"], A["geom_bodyid"]
+    # <contact><exclude body1 body2/>: no geom of the one body collides with a geom of the other
+    excluded = set()
+    for con in c.root.findall("contact"):
+        for el in con:
+            ids = []
+            for key in ("body1", "body2"):
+                name = el.attrib.get(key)
+                if name in folded:
+                    ids.append(0)
+                elif name in m.names["body"]:
+                    ids.append(m.names["body"].index(name))
+                else:
+                    raise KeyError(f"<exclude>: no body named '{name}'")
+            excluded.add((min(ids), max(ids)))
     for g1 in range(ngeom):
         for g2 in range(g1 + 1, ngeom):
             b1, b2 = gb[g1], gb[g2]
-            if b1 == b2:
+            if b1 == b2 or (min(int(b1), int(b2)), max(int(b1), int(b2))) in excluded:
                 continue
             g_a, g_b = c.geoms[g1], c.geoms[g2]
             if not ((g_a["contype"] & g_b["conaffinity"]) or (g_b["contype"] & g_a["conaffinity"])):

@@ -258,6 +258,48 @@ def test_the_ant_levels_total_mass_at_density_5():
     assert m.body_mass[torso] == pytest.approx(rho * 4 / 3 * math.pi * 0.25 ** 3, rel=1e-13)
 
 
+# ---------------------------------------------------------------------------------------- <inertial>, <exclude>, <keyframe>
+def test_inertial_elements_override_the_geoms_unless_the_compiler_says_otherwise():
+    body = ('<body pos="0 0 1"><freejoint/><inertial pos="0.1 0 0.2" mass="3" diaginertia="0.3 0.2 0.1" euler="0 0 90"/>'
+            '<geom type="sphere" size="0.1"/></body>')
+    m = compile_xml(body)                                               # inertiafromgeom="auto": the <inertial> wins
+    assert m.body_mass[1] == 3.0 and np.allclose(m.body_ipos[1], [0.1, 0, 0.2]) and np.allclose(m.body_inertia[1], [0.3, 0.2, 0.1])
+    assert np.allclose(m.body_iquat[1], [math.sqrt(0.5), 0, 0, math.sqrt(0.5)])
+    assert np.allclose(m.body_invweight0[1], [1 / 3.0, np.mean(1 / np.array([0.3, 0.2, 0.1]))], rtol=1e-12)
+    m = compile_xml(body, head='<compiler inertiafromgeom="true"/>')    # the levels' setting: geoms only
+    assert m.body_mass[1] == pytest.approx(1000 * 4 / 3 * math.pi * 1e-3, rel=1e-13) and np.allclose(m.body_ipos[1], 0)
+    m = compile_xml(body, head='<compiler inertiafromgeom="false"/>')
+    assert m.body_mass[1] == 3.0
+    with pytest.raises(ValueError, match="no mass"):                    # "false" and no <inertial> on a body that moves
+        compile_xml('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1"/></body>',
+                    head='<compiler inertiafromgeom="false"/>')
+
+
+def test_fullinertia_is_brought_to_its_principal_frame():
+    # the tensor of a box (principal moments 0.5, 0.3, 0.2) turned by 30 degrees about z, given in the body frame
+    cz, sz = math.cos(math.radians(30)), math.sin(math.radians(30))
+    rot = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    t = rot @ np.diag([0.5, 0.3, 0.2]) @ rot.T
+    full = f"{t[0, 0]} {t[1, 1]} {t[2, 2]} {t[0, 1]} {t[0, 2]} {t[1, 2]}"
+    m = compile_xml(f'<body pos="0 0 1"><freejoint/><inertial pos="0 0 0" mass="2" fullinertia="{full}"/>'
+                    '<geom type="sphere" size="0.1"/></body>')
+    assert np.allclose(m.body_inertia[1], [0.5, 0.3, 0.2], rtol=1e-12)
+    assert np.allclose(inertia_tensor(m, 1), t, rtol=1e-12, atol=1e-15)
+    assert np.linalg.det(mjcf.quat_to_mat(m.body_iquat[1])) == pytest.approx(1.0, abs=1e-13)
+
+
+def test_contact_exclude_removes_the_two_bodies_pairs_and_keyframes_change_nothing():
+    plain = compile_xml(TWO)
+    assert {tuple(sorted((plain.names["geom"][a], plain.names["geom"][b]))) for a, b in plain.pair_geom if a >= 0} == {("ga", "gb")}
+    m = compile_xml(TWO, tail='<contact><exclude body1="a" body2="b"/></contact>')
+    assert not [1 for a, b in m.pair_geom if a >= 0]
+    with pytest.raises(KeyError):
+        compile_xml(TWO, tail='<contact><exclude body1="a" body2="nobody"/></contact>')
+    from mjrl_amd import blob
+    keyed = compile_xml(TWO, tail='<keyframe><key qpos="0.3 0.4"/></keyframe>')      # mj_resetData goes to qpos0, not to a key
+    assert blob.pack(keyed) == blob.pack(plain) and np.array_equal(keyed.qpos0, [0, 0])
+
+
 # ---------------------------------------------------------------------------------------- the subset is loud
 BALL = '<body pos="0 0 1"><freejoint/><geom name="g" type="sphere" size="0.1"/></body>'
 TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga" type="sphere" size="0.1"/></body>'
@@ -267,8 +309,7 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
 @pytest.mark.parametrize("body, head, tail, named", [
     (TWO, "", '<equality><weld body1="a" body2="b"/></equality>', "equality"),
     (TWO, "", '<tendon><fixed><joint joint="ja" coef="1"/></fixed></tendon>', "tendon"),
-    (TWO, "", '<contact><exclude body1="a" body2="b"/></contact>', "contact"),
-    (TWO, "", '<keyframe><key qpos="0 0"/></keyframe>', "keyframe"),
+    (TWO, "", '<contact><pair geom1="ga" geom2="gb" condim="1"/></contact>', "pair"),
     (BALL, '<include file="other.xml"/>', "", "include"),
     (BALL, '<option solver="Newton"/>', "", "solver"),
     (BALL, '<option solver="CG"/>', "", "solver"),
@@ -278,12 +319,9 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
     (BALL, '<option viscosity="0.1"/>', "", "viscosity"),
     (BALL, '<option><flag contact="disable"/></option>', "", "flag"),
     (BALL, '<compiler coordinate="global"/>', "", "coordinate"),
-    (BALL, '<compiler inertiafromgeom="false"/>', "", "inertiafromgeom"),
     (BALL, '<compiler autolimits="true"/>', "", "autolimits"),
     (BALL, '<asset><mesh name="m" file="m.stl"/></asset>', "", "mesh"),
     (BALL, '<default><tendon width="0.1"/></default>', "", "tendon"),
-    ('<body pos="0 0 1"><freejoint/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
-     '<geom type="sphere" size="0.1"/></body>', "", "", "inertial"),
     ('<body pos="0 0 1"><joint type="ball"/><geom type="sphere" size="0.1"/></body>', "", "", "ball"),
     ('<body pos="0 0 1"><joint type="hinge" frictionloss="0.1"/><geom type="sphere" size="0.1"/></body>', "", "",
      "frictionloss"),
