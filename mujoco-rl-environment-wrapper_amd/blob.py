@@ -18,7 +18,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x4C524A4D  # 'MJRL'
-VERSION = 17
+VERSION = 18
 
 SIZE_FIELDS = ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ncam", "nsensor", "nsensordata",
                "npair", "nM", "ntree", "nconmax", "njmax", "integrator", "iterations", "maxdepth",
@@ -37,6 +37,7 @@ F64_FIELDS = [
     ("jnt_pos", "njnt*3"), ("jnt_axis", "njnt*3"), ("jnt_range", "njnt*2"), ("jnt_margin", "njnt"),
     ("jnt_solref", "njnt*2"), ("jnt_solimp", "njnt*5"),
     ("dof_armature", "nv"), ("dof_damping", "nv"), ("dof_invweight0", "nv"),
+    ("dof_stiffness", "nv"), ("dof_springref", "nv"),          # layout 18: joint springs
     ("geom_size", "ngeom*3"), ("geom_pos", "ngeom*3"), ("geom_quat", "ngeom*4"), ("geom_friction", "ngeom*3"),
     ("geom_margin", "ngeom"), ("geom_gap", "ngeom"), ("geom_solref", "ngeom*2"), ("geom_solimp", "ngeom*5"),
     ("geom_solmix", "ngeom"), ("geom_rbound", "ngeom"), ("geom_rgba", "ngeom*4"),
@@ -74,6 +75,7 @@ I32_FIELDS = [
     ("body_kparent", "nbody"), ("body_kdepth", "nbody"), ("chunk_info", "nchunk"), ("tp_root", "ntp*2"),
     ("light_bodyid", "nlight"), ("light_directional", "nlight"),
     ("light_castshadow", "nlight"),          # layout 17: the light's shadow is drawn (body/light castshadow, default true)
+    ("dof_qposadr", "nv"),                   # layout 18: the coordinate a hinge's / slide's dof moves (joint springs)
 ]
 
 

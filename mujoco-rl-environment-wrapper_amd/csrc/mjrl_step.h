@@ -284,6 +284,8 @@ struct LaneK {
   // lane as dof
   int d_parent, d_Madr, d_depth, d_body, d_descadr, d_descnum, d_act;
   real d_damping, d_armature;
+  real d_stiffness, d_springref;      // joint spring of the lane's dof (hinge / slide; 0: none)
+  int d_qposadr;                      // the coordinate it acts on
 };
 
 __host__ __device__ inline void load_lane_constants(const DevModel& m, int L, LaneK& k) {
@@ -299,6 +301,7 @@ __host__ __device__ inline void load_lane_constants(const DevModel& m, int L, La
   k.d_parent = m.dof_parentid[d]; k.d_Madr = m.dof_Madr[d]; k.d_depth = isd ? m.dof_depth[d] : -1;
   k.d_body = m.dof_bodyid[d]; k.d_descadr = m.dof_descadr[d]; k.d_descnum = isd ? m.dof_descnum[d] : 0;
   k.d_act = isd ? m.dof_actid[d] : -1; k.d_damping = m.dof_damping[d]; k.d_armature = m.dof_armature[d];
+  k.d_stiffness = m.dof_stiffness[d]; k.d_springref = m.dof_springref[d]; k.d_qposadr = m.dof_qposadr[d];
 }
 
 // Structure tables kept in LDS as 16-bit words (order fixed by mjcf._kernel_schedules): the row build walks them
@@ -1241,7 +1244,9 @@ __device__ inline void stage_smooth(const DevModel& m, const Lay& l, const LaneK
         act += m.act_gear[u] * c;
       }
     }
+    // (joint damping, and the joint's spring -stiffness (q - springref): mj_passive; the oracle's two statements)
     real passive = -K.d_damping * S[l.qvel + L];
+    passive -= K.d_stiffness * (S[l.qpos + K.d_qposadr] - K.d_springref);
     real sm = passive - S[l.bias + L] + act;
     S[l.smooth + L] = sm;
     S[l.qaccs + L] = sm;

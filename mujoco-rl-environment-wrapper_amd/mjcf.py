@@ -219,7 +219,7 @@ _ELEMENT_ATTRS = {
     "geom": {"name", "class", "type", "size", "pos", "fromto", "friction", "density", "mass", "margin", "gap", "condim",
              "contype", "conaffinity", "solref", "solimp", "solmix", "rgba", "material", "group"} | _ORIENT,
     "joint": {"name", "class", "type", "pos", "axis", "limited", "range", "margin", "armature", "damping", "ref",
-              "solreflimit", "solimplimit", "group"},
+              "stiffness", "springref", "solreflimit", "solimplimit", "group"},
     "freejoint": {"name", "group"},
     "site": {"name", "class", "pos", "size", "type", "rgba", "group", "material"} | _ORIENT,
     "camera": {"name", "class", "pos", "fovy", "mode"} | _ORIENT,
@@ -230,7 +230,7 @@ _ELEMENT_ATTRS = {
     "sensor": {"name", "site", "objname", "objtype", "cutoff", "noise", "user"},
 }
 # attributes that may be present as long as they leave the feature off
-_NEUTRAL = {("joint", "stiffness"): 0.0, ("joint", "frictionloss"): 0.0, ("joint", "springref"): 0.0,
+_NEUTRAL = {("joint", "frictionloss"): 0.0,
             ("geom", "priority"): 0.0, ("body", "gravcomp"): 0.0, ("body", "mocap"): "false",
             ("motor", "forcelimited"): "false", ("general", "forcelimited"): "false"}
 _BODY_CHILDREN = {"body", "geom", "joint", "freejoint", "site", "camera", "light", "inertial"}
@@ -550,9 +550,14 @@ class _Compiler:
                  axis=axis, limited=limited and jtype != JNT_FREE, range=rng,
                  margin=float(a.get("margin", 0.0)), armature=float(a.get("armature", 0.0)),
                  damping=float(a.get("damping", 0.0)), stiffness=float(a.get("stiffness", 0.0)),
-                 ref=float(a.get("ref", 0.0)),
+                 ref=float(a.get("ref", 0.0)), springref=float(a.get("springref", 0.0)),
                  solref=_vec(a.get("solreflimit"), 2, [0.02, 1.0]),
                  solimp=_vec(a.get("solimplimit"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]))
+        if jtype == JNT_FREE and j["stiffness"] != 0.0:
+            _refuse("stiffness of a free joint")
+        if jtype == JNT_HINGE and self.degree:
+            j["springref"] = math.radians(j["springref"])         # (an angle like ref and range: the compiler's unit)
+            j["ref"] = math.radians(j["ref"])
         self.bodies[body_id]["jnts"].append(len(self.joints))
         self.joints.append(j)
 
@@ -707,6 +712,9 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     qpos0 = np.zeros(nq)
     dof_bodyid, dof_jntid = np.zeros(nv, np.int32), np.zeros(nv, np.int32)
     dof_armature, dof_damping = np.zeros(nv), np.zeros(nv)
+    # joint springs (XML reference, body/joint stiffness and springref): the passive force -stiffness (q - springref) on a
+    # hinge's or a slide's coordinate
+    dof_stiffness, dof_springref, dof_qposadr = np.zeros(nv), np.zeros(nv), np.zeros(nv, np.int32)
 
     # ---- bodies
     body_parentid = np.array([b["parent"] for b in c.bodies], np.int32)
@@ -738,6 +746,9 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
                 dof_bodyid[d], dof_jntid[d] = b, j
                 dof_parentid[d] = last
                 dof_armature[d], dof_damping[d] = jn["armature"], jn["damping"]
+                dof_qposadr[d] = jnt_qposadr[j] + (k if jn["type"] != JNT_FREE else min(k, 2))
+                if jn["type"] != JNT_FREE:
+                    dof_stiffness[d], dof_springref[d] = jn["stiffness"], jn["springref"]
                 last = d
             if jn["type"] == JNT_FREE:
                 qa = jnt_qposadr[j]
@@ -766,7 +777,8 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
              body_dofadr=body_dofadr, body_geomnum=body_geomnum, body_geomadr=body_geomadr,
              body_pos=body_pos, body_quat=body_quat, body_depth=body_depth, body_lastdof=body_lastdof,
              dof_bodyid=dof_bodyid, dof_jntid=dof_jntid, dof_parentid=dof_parentid,
-             dof_armature=dof_armature, dof_damping=dof_damping, qpos0=qpos0)
+             dof_armature=dof_armature, dof_damping=dof_damping, qpos0=qpos0,
+             dof_stiffness=dof_stiffness, dof_springref=dof_springref, dof_qposadr=dof_qposadr)
 
     # kinematic trees: one per child of the world that carries (or whose subtree carries) dofs
     dof_treeid = np.zeros(nv, np.int32)

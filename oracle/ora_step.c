@@ -785,7 +785,12 @@ void ora_forward(const ora_model* m, ora_data* d) {
   ora_collision(m, d);
   ora_make_constraint(m, d);
   ora_com_vel(m, d);
-  for (int i = 0; i < nv; i++) d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
+  /* passive forces: joint damping, and the joint springs -stiffness (q - springref) of hinges and slides (mj_passive) */
+  for (int i = 0; i < nv; i++) {
+    double frc = -m->dof_damping[i] * d->qvel[i];
+    frc -= m->dof_stiffness[i] * (d->qpos[m->dof_qposadr[i]] - m->dof_springref[i]);
+    d->qfrc_passive[i] = frc;
+  }
   ora_rne(m, d, 0, d->qfrc_bias);
   memset(d->qfrc_actuator, 0, (size_t)nv * sizeof(double));
   for (int u = 0; u < m->nu; u++) {

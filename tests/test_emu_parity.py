@@ -713,3 +713,32 @@ def test_reset_without_a_step_and_the_autoreset_kept_by_the_step(emu_few):
                 assert np.allclose(obs[0], look(ora), atol=1e-9), (frames, mode, step)
                 assert bool(trunc[0]) == (t == horizon + 1) and bool(flag[0]) == bool(trunc[0])
             assert episode[0] >= 2
+
+
+SPRUNG = """<mujoco><option timestep="0.002"/>
+<default><joint armature="0.05" damping="0.3" limited="true"/><geom density="60" friction="1 0.005 0.0001"/></default>
+<worldbody><geom type="plane" size="5 5 0.1"/>
+  <body name="hopper" pos="0 0 0.6"><freejoint/><geom type="sphere" size="0.12"/>
+    <body pos="0.1 0 0"><joint type="hinge" axis="0 1 0" range="-60 60" stiffness="4" springref="25"/>
+      <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.04"/>
+      <body pos="0.3 0 0"><joint type="slide" axis="0 0 1" range="-0.2 0.2" stiffness="120" springref="-0.05"/>
+        <geom type="capsule" fromto="0 0 0 0 0 -0.3" size="0.035"/></body></body>
+    <body pos="-0.1 0 0"><joint type="hinge" axis="0 1 0" range="-60 60" stiffness="2.5" ref="10" springref="-20"/>
+      <geom type="capsule" fromto="0 0 0 -0.3 0 0" size="0.04"/></body></body>
+</worldbody></mujoco>"""
+
+
+def test_joint_springs_in_the_device_source(emu_few):
+    """Joint stiffness / springref (hinge and slide; a non-zero ref): the passive force of the smooth stage, device source
+    against oracle through flight, landing and rest -- same counts every step, same trajectory."""
+    model = mjcf.compile_mjcf_string(SPRUNG)
+    assert np.count_nonzero(model.dof_stiffness) == 3 and model.qpos0[9] == pytest.approx(np.radians(10))
+    packed = blob.pack(model)
+    ora, emu = OracleEnv(packed), EmuEnv(model, packed)
+    emu.step(forward_only=True)
+    for step in range(700):
+        img = emu.step()
+        ora.step()
+        assert (img.ncon, img.nefc, img.niter) == (ora.ncon, ora.nefc, ora.niter), step
+    assert ora.ncon > 0
+    assert np.abs(emu.qpos - ora.qpos).max() < 1e-9 and np.abs(emu.qvel - ora.qvel).max() < 1e-8

@@ -669,3 +669,23 @@ def test_agent_dropped_onto_agent_in_both_builds(few, monkeypatch):
     h.close()
     for o in oras:
         o.close()
+
+
+def test_joint_springs_through_the_c_abi(few_build):
+    """Joint stiffness / springref on the GPU (specialised and generic kernel), against the oracle: counts every step,
+    states at the end; the springs hold the limbs where -k (q - springref) balances gravity and contact."""
+    from tests.test_emu_parity import SPRUNG
+    model = mjcf.compile_mjcf_string(SPRUNG)
+    packed = blob.pack(model)
+    for specialize in (True, False):
+        h = _capi.Handle(packed, 3, specialize=specialize)
+        h.reset()
+        ora = OracleEnv(packed)
+        for step in range(700):
+            h.step_host(None, 1)
+            ora.step()
+            stats = h.get_field("solver_stats")
+            assert (stats[:, 0] == ora.ncon).all() and (stats[:, 1] == ora.nefc).all() and (stats[:, 2] == ora.niter).all(), step
+        assert ora.ncon > 0
+        assert np.abs(h.get_field("qpos") - ora.qpos).max() < 1e-9 and np.abs(h.get_field("qvel") - ora.qvel).max() < 1e-8
+        h.close(); ora.close()

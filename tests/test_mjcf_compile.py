@@ -325,7 +325,8 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
     ('<body pos="0 0 1"><joint type="ball"/><geom type="sphere" size="0.1"/></body>', "", "", "ball"),
     ('<body pos="0 0 1"><joint type="hinge" frictionloss="0.1"/><geom type="sphere" size="0.1"/></body>', "", "",
      "frictionloss"),
-    ('<body pos="0 0 1"><joint type="hinge" stiffness="2"/><geom type="sphere" size="0.1"/></body>', "", "", "stiffness"),
+    ('<body pos="0 0 1"><joint type="free" stiffness="2"/><geom type="sphere" size="0.1"/></body>', "", "", "stiffness"),
+    ('<body pos="0 0 1"><joint type="hinge" springdamper="1 1"/><geom type="sphere" size="0.1"/></body>', "", "", "springdamper"),
     ('<body pos="0 0 1"><freejoint/><geom type="ellipsoid" size="0.1 0.2 0.3"/></body>', "", "", "ellipsoid"),
     ('<body pos="0 0 1"><freejoint/><geom type="cylinder" size="0.1 0.2"/></body>', "", "", "cylinder"),
     ('<body pos="0 0 1" mocap="true"><geom type="sphere" size="0.1"/></body>', "", "", "mocap"),

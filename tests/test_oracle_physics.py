@@ -412,3 +412,58 @@ def test_a_step_is_the_semi_implicit_euler_update_of_its_own_forward_pass():
             assert np.allclose(env.qpos[qa + 3:qa + 7], q / np.linalg.norm(q), atol=1e-13)
         else:
             assert np.isclose(env.qpos[qa], q0[qa] + h * v1[da], atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------- joint springs (round 4)
+def test_a_mass_on_a_slide_spring_settles_where_the_spring_carries_it():
+    """body/joint stiffness + springref: the passive force -k (q - springref) on a slide's coordinate.  A damped mass on a
+    vertical spring comes to rest at q = springref - m g / k."""
+    k, ref = 400.0, 0.05
+    model, env = make(f"""<mujoco><option timestep="0.001"/><worldbody>
+      <body pos="0 0 1"><joint type="slide" axis="0 0 1" stiffness="{k}" springref="{ref}" damping="60"/>
+        <geom type="sphere" size="0.1" density="1000" contype="0" conaffinity="0"/></body></worldbody></mujoco>""")
+    mass = 1000 * 4 / 3 * np.pi * 1e-3
+    env.step(8000)
+    assert abs(env.qvel[0]) < 1e-9
+    assert env.qpos[0] == pytest.approx(ref - mass * 9.81 / k, rel=1e-9)
+
+
+def test_a_torsion_spring_swings_with_the_period_of_its_inertia():
+    """No gravity, no damping: I q'' = -k q.  The semi-implicit Euler map x -> (q + h v', v' = v - h w^2 q) has the exact
+    discrete frequency cos(w_d h) = 1 - (w h)^2 / 2; the zero crossings of q are half a discrete period apart."""
+    k, length, r, arm, h = 3.0, 0.4, 0.05, 0.02, 0.001
+    model, env = make(f"""<mujoco><option timestep="{h}" gravity="0 0 0"/><worldbody>
+      <body pos="0 0 1"><joint type="hinge" axis="0 1 0" stiffness="{k}" armature="{arm}"/>
+        <geom type="sphere" size="{r}" pos="0 0 {-length}" density="1000" contype="0" conaffinity="0"/></body></worldbody></mujoco>""")
+    mass = 1000 * 4 / 3 * np.pi * r ** 3
+    inertia = 0.4 * mass * r * r + mass * length * length + arm
+    w = np.sqrt(k / inertia)
+    period = 2 * np.pi / (np.arccos(1 - (w * h) ** 2 / 2) / h)
+    env.qpos[0] = 0.3
+    crossings, prev = [], env.qpos[0]
+    for step in range(1, int(3.2 * period / h)):
+        env.step()
+        q = env.qpos[0]
+        if prev > 0 >= q or prev < 0 <= q:
+            crossings.append((step - 1 + prev / (prev - q)) * h)        # linear interpolation of the crossing
+        prev = q
+    assert len(crossings) >= 6
+    half_periods = np.diff(crossings)
+    assert np.allclose(half_periods, period / 2, rtol=2e-4)
+    assert abs(period - 2 * np.pi / w) / period < 1e-3                 # (and that is the continuous period to O(h^2))
+
+
+def test_springref_and_ref_of_a_hinge_are_angles_in_the_compilers_unit():
+    xml = """<mujoco><option timestep="0.002" gravity="0 0 0"/><worldbody>
+      <body pos="0 0 1"><joint type="hinge" axis="0 1 0" stiffness="5" springref="30" ref="10" damping="0.4"/>
+        <geom type="sphere" size="0.05" pos="0 0 -0.3" density="1000" contype="0" conaffinity="0"/></body></worldbody></mujoco>"""
+    model, env = make(xml)
+    assert model.qpos0[0] == pytest.approx(np.radians(10)) and model.dof_springref[0] == pytest.approx(np.radians(30))
+    assert model.dof_stiffness[0] == 5.0 and model.dof_qposadr[0] == 0
+    env.step(5000)
+    assert env.qpos[0] == pytest.approx(np.radians(30), abs=1e-9) and abs(env.qvel[0]) < 1e-9
+    radian, _ = make(xml.replace("<option", '<compiler angle="radian"/><option').replace('springref="30" ref="10"', 'springref="0.5" ref="0.2"'))
+    assert radian.qpos0[0] == 0.2 and radian.dof_springref[0] == 0.5
+    with pytest.raises(mjcf.UnsupportedMJCF, match="free joint"):
+        make('<mujoco><worldbody><body pos="0 0 1"><joint type="free" stiffness="2"/><geom type="sphere" size="0.1"/></body>'
+             '</worldbody></mujoco>')
