@@ -230,6 +230,14 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
   // bottom, top edges per unit depth), and a box wholly behind one of them is seen by no ray of the block.  Per box and
   // camera axis W: the centre's coordinate rel . W and the three half-extents (u_i . W) s_i -- twelve floats, here.
   float* BX = cm + 12;
+  // (a geom's type and bounding radius, rounded up, as the culls read them -- from LDS per block, not from five registers
+  // per lane for the whole kernel: the pair kernel is held to 128 and spilled them)
+  float* GK = BX + 12 * m.ngeom;
+  for (int g = tid; g < m.ngeom; g += nthr) {
+    const bool seen = (rgba_tab ? rgba_tab[4 * g + 3] : (double)m.geom_rgba[4 * g + 3]) != 0;
+    GK[2 * g] = seen ? (float)m.geom_type[g] : -1.0f;
+    GK[2 * g + 1] = (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f;
+  }
   for (int g = tid; g < m.ngeom; g += nthr) {
     const F3 rel = ldf3(GP + 3 * g), sz = ldf3(GS + 3 * g);
     for (int w = 0; w < 3; w++) {
@@ -266,10 +274,6 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
     return normalized2(mul2(cm, p3((px * splat2(inv_w) - splat2(1.0f)) * splat2(t) * splat2(aspect), splat2((py * inv_h - 1.0f) * t),
                                    splat2(-1.0f))));
   };
-  const bool my_geom = L < m.ngeom && rgba_of(L < m.ngeom ? L : 0, 3) != 0;
-  const int my_type = my_geom ? m.geom_type[L] : -1;
-  const float my_rb = my_geom ? (float)m.geom_rbound[L] * (1.0f + 1e-5f) + 1e-5f : 0.0f;     // (rounded up)
-  const F3 my_rel = my_geom ? ldf3(GP + 3 * L) : origin;
   // The bounding cones of the wave's blocks -- axis through the block's centre, half-angle from its corner rays: five
   // rays per block -- are computed 64 blocks at a time, lane j the cone of the j-th block to come, and handed out
   // through scalar registers.
@@ -349,12 +353,10 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
         if (x.y >= 0 && (best.y < 0 || x.y < best.y)) { best.y = x.y; hit1 = base + g; }
       }
     };
-    visit(0, my_geom, my_type, my_rb, my_rel);
-    for (int base = 64; base < m.ngeom; base += 64) {
-      const int g = base + L;
-      const bool on = g < m.ngeom && rgba_of(g < m.ngeom ? g : 0, 3) != 0;
-      visit(base, on, on ? m.geom_type[g] : -1, on ? (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f : 0.0f,
-            on ? ldf3(GP + 3 * g) : origin);
+    for (int base = 0; base < m.ngeom; base += 64) {       // (one chunk unless the level has more than 64 geoms)
+      const int g = base + L < m.ngeom ? base + L : 0;
+      const int type_g = base + L < m.ngeom ? (int)GK[2 * g] : -1;
+      visit(base, type_g >= 0, type_g, GK[2 * g + 1], ldf3(GP + 3 * g));
     }
     unsigned packed0 = 0u, packed1 = 0u;
     // (the shading runs for the whole wave, rays without a hit computing on geom 0 and storing nothing: the shadow pass
@@ -465,12 +467,10 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
             lit = and2(lit, not2(and2(ge2(x, splat2(0.0f)), lt2(x, light_dist))));
           }
         };
-        shadow_pass(0, my_geom, my_type, my_rb, my_rel);
-        for (int base = 64; base < m.ngeom; base += 64) {
-          const int g = base + L;
-          const bool on = g < m.ngeom && rgba_of(g < m.ngeom ? g : 0, 3) != 0;
-          shadow_pass(base, on, on ? m.geom_type[g] : -1, on ? (float)m.geom_rbound[g] * (1.0f + 1e-5f) + 1e-5f : 0.0f,
-                      on ? ldf3(GP + 3 * g) : origin);
+        for (int base = 0; base < m.ngeom; base += 64) {
+          const int g = base + L < m.ngeom ? base + L : 0;
+          const int type_g = base + L < m.ngeom ? (int)GK[2 * g] : -1;
+          shadow_pass(base, type_g >= 0, type_g, GK[2 * g + 1], ldf3(GP + 3 * g));
         }
         if (was_lit.x && !lit.x) dark0 |= 1u << li;
         if (was_lit.y && !lit.y) dark1 |= 1u << li;
@@ -555,7 +555,8 @@ __global__ __launch_bounds__(64) MJRL_RENDER_OCC void mjrl_render_kernel(DevMode
 // the ray kernel's LDS: geom positions, matrices and sizes
 inline size_t render_lds_bytes(const DevModel& m) {
   // geom positions, matrices, sizes, material properties, colours | lights | camera matrix (padded to 12) | boxes' frustum table
-  return (21 * (size_t)m.ngeom + LIGHT_FLOATS * ((size_t)m.nlight + 1) + 12 + 12 * (size_t)m.ngeom) * sizeof(float);
+  // | per geom: type (-1: transparent, never a candidate) and bounding radius
+  return (21 * (size_t)m.ngeom + LIGHT_FLOATS * ((size_t)m.nlight + 1) + 12 + 12 * (size_t)m.ngeom + 2 * (size_t)m.ngeom) * sizeof(float);
 }
 
 std::string g_create_error;
