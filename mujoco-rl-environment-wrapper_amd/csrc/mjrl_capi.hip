@@ -275,25 +275,27 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
                                    splat2(-1.0f))));
   };
   // The bounding cones of the wave's blocks -- axis through the block's centre, half-angle from its corner rays: five
-  // rays per block -- are computed 64 blocks at a time, lane j the cone of the j-th block to come, and handed out
-  // through scalar registers.
-  F3 cone_axis = origin;
-  float cone_cos = 1.0f, cone_sin = 0.0f;
+  // rays per block -- are computed 64 blocks at a time, lane j the cone of the j-th block to come, and parked in LDS
+  // (five floats per block; held in registers they were five of the 128 the kernel may use, for all of it).
+  float* CN = GK + 2 * m.ngeom;
   int ahead = 0;
   auto lane_f = [&](float v, int src) { return __int_as_float(wv::lane_int(__float_as_int(v), src)); };
   for (int blk = blk0; blk < blk1; blk += blk_step, ahead++) {
     if ((ahead & 63) == 0) {
       const int mine = blk + L * blk_step, mr0 = (mine / bw) * 8, mc0 = (mine % bw) * 16;
-      cone_axis = pixel_ray(mc0 + 8.0f, mr0 + 4.0f);
+      const F3 cone_axis = pixel_ray(mc0 + 8.0f, mr0 + 4.0f);
       float cosmin = 1.0f;
       for (int k = 0; k < 4; k++)
         cosmin = fminf(cosmin, dotf(cone_axis, pixel_ray(mc0 + ((k & 1) ? 15.5f : 0.5f), mr0 + ((k & 2) ? 7.5f : 0.5f))));
-      cone_cos = cosmin * (1.0f - 1e-5f) - 1e-6f;
-      cone_sin = fsqrt(fmaxf(1.0f - cone_cos * cone_cos, 0.0f));
+      const float cone_cos = cosmin * (1.0f - 1e-5f) - 1e-6f;
+      barrier();                         // (the cones of the 64 blocks before have been read)
+      CN[5 * L] = cone_axis.x; CN[5 * L + 1] = cone_axis.y; CN[5 * L + 2] = cone_axis.z;
+      CN[5 * L + 3] = cone_cos; CN[5 * L + 4] = fsqrt(fmaxf(1.0f - cone_cos * cone_cos, 0.0f));
+      barrier();
     }
     const int r0 = (blk / bw) * 8, c0 = (blk % bw) * 16, from = ahead & 63;
-    const F3 axis = f3(lane_f(cone_axis.x, from), lane_f(cone_axis.y, from), lane_f(cone_axis.z, from));
-    const float cos_t = lane_f(cone_cos, from), sin_t = lane_f(cone_sin, from);
+    const F3 axis = ldf3(CN + 5 * from);
+    const float cos_t = CN[5 * from + 3], sin_t = CN[5 * from + 4];
     const int r = r0 + (L >> 3), c = c0 + (L & 7);
     B2 inside; inside.x = r < height && c < width; inside.y = r < height && c + 8 < width;
     const P3 vec = pixel_rays(mk2(c + 0.5f, c + 8.5f), r + 0.5f);
@@ -533,9 +535,9 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
   }
 }
 
-// Four waves per SIMD: the pair kernel wants 137 registers (three waves); held to 128 it spills seven dwords per lane in
-// the shadow pass and runs 93 us per 512 x 2 cameras against 102 uncapped (five waves / 96 registers: 126 us, the spills
-// reach the candidate loop).  tools/render_probe.sh.
+// Four waves per SIMD.  The pair kernel wanted 137 registers with the geoms' cull records and the blocks' cones held in
+// registers (held to 128 it spilled 52 B per lane); with both read from LDS per block it takes 111 and no scratch.  Five
+// waves (96 registers) spill 56 B into the candidate loop: 84 us against 79.  tools/render_probe.sh.
 #ifndef MJRL_RENDER_WAVES
 #define MJRL_RENDER_WAVES 4
 #endif
@@ -555,8 +557,8 @@ __global__ __launch_bounds__(64) MJRL_RENDER_OCC void mjrl_render_kernel(DevMode
 // the ray kernel's LDS: geom positions, matrices and sizes
 inline size_t render_lds_bytes(const DevModel& m) {
   // geom positions, matrices, sizes, material properties, colours | lights | camera matrix (padded to 12) | boxes' frustum table
-  // | per geom: type (-1: transparent, never a candidate) and bounding radius
-  return (21 * (size_t)m.ngeom + LIGHT_FLOATS * ((size_t)m.nlight + 1) + 12 + 12 * (size_t)m.ngeom + 2 * (size_t)m.ngeom) * sizeof(float);
+  // | per geom: type (-1: transparent, never a candidate) and bounding radius | the cones of 64 blocks
+  return (21 * (size_t)m.ngeom + LIGHT_FLOATS * ((size_t)m.nlight + 1) + 12 + 12 * (size_t)m.ngeom + 2 * (size_t)m.ngeom + 5 * 64) * sizeof(float);
 }
 
 std::string g_create_error;

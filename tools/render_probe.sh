@@ -1,7 +1,7 @@
 # render kernel time for several builds (MJRL_LIB) and tile targets: tools/render_probe.sh
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
-for spec in "w0 8" "w0 4" "w4 8" "w4 4" "w5 4"; do
+for spec in "w0 8" "w0 4" "w5 8" "w5 4"; do
   set -- $spec; lib=$1; tgt=$2
   unset MJRL_LIB; [ $lib != w0 ] && export MJRL_LIB=$GRAFT_REPO_ROOT/tools/ab/libs/lib_$lib.so
   export MJRL_RENDER_TARGET=$tgt
