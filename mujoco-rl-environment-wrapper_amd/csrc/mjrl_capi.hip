@@ -343,7 +343,9 @@ __device__ __forceinline__ void render_body(const DevModel& m, const double* row
         const int gt = wv::lane_int(type_v, g);
         const F3 rel = f3(lane_f(rel_v.x, g), lane_f(rel_v.y, g), lane_f(rel_v.z, g));
         B2 on = inside;
-        if (gt != GEOM_PLANE) {
+        // (a box has passed the block's frustum test: most of the block's rays do hit it, and its bounding sphere -- a
+        // wall's is 10 m -- decides nothing the slab test does not decide at the same price)
+        if (gt != GEOM_PLANE && (gt != GEOM_BOX || loose_culls)) {
           const float rb = lane_f(rb_v, g), rr = dotf(rel, rel);
           const f2 along = dot2(splat3(rel), vec), d2 = splat2(rr) - along * along;
           const float lim = rb * rb + 1e-5f * (1.0f + rr);
