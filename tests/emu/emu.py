@@ -42,6 +42,8 @@ def lib():
         L.emu_set_autoreset.restype = None
         L.emu_set_tags.argtypes = [P, P, P, ctypes.c_int]
         L.emu_set_tags.restype = None
+        L.emu_set_io_layout.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.emu_set_io_layout.restype = None
         L.emu_set_few.argtypes = [ctypes.c_int]
         L.emu_set_few.restype = None
         L.emu_set_lpt.argtypes = [P, P, ctypes.c_int]

@@ -168,6 +168,10 @@ void emu_set_tags(const int32_t* adr, const int32_t* num, const int32_t* ref, in
 static int g_few = 0;
 void emu_set_few(int few) { g_few = few; }
 
+// I/O layout of the following emu_step calls (mjrl_set_io_layout): agent + 1 (0: every agent's rows), float32 observations
+static int g_io_agent1 = 0, g_obs_f32 = 0;
+void emu_set_io_layout(int agent1, int obs_f32) { g_io_agent1 = agent1; g_obs_f32 = obs_f32; }
+
 // longest-first dispatch tables of the following emu_step calls (launch_step's lpt_count_in / lpt_list_in); null: identity
 static const int* g_lpt_count = nullptr;
 static const unsigned* g_lpt_mask = nullptr;
@@ -208,6 +212,7 @@ int emu_step(const void* blob, size_t nbytes, double* qpos, double* qvel, double
   a.lpt_count_in = g_lpt_count; a.lpt_mask_in = g_lpt_mask; a.lpt_words = g_lpt_words;
   a.tag_adr = g_tag_adr; a.tag_num = g_tag_num; a.tag_ref = g_tag_ref; a.env_base = g_env_base;
   a.max_steps = max_steps; a.n_env = 1; a.few = g_few;
+  a.io_agent1 = g_io_agent1; a.obs_f32 = g_obs_f32;
   std::vector<int32_t> lane_rec((size_t)mj::LANE_REC_INTS, 0);        // (mjrl_create builds this table once per handle)
   mj::build_lane_records(m, l, lane_rec.data());
   a.lane_rec = lane_rec.data();

@@ -742,3 +742,39 @@ def test_joint_springs_in_the_device_source(emu_few):
         assert (img.ncon, img.nefc, img.niter) == (ora.ncon, ora.nefc, ora.niter), step
     assert ora.ncon > 0
     assert np.abs(emu.qpos - ora.qpos).max() < 1e-9 and np.abs(emu.qvel - ora.qvel).max() < 1e-8
+
+
+def test_one_agent_io_layout_in_the_device_source():
+    """StepArgs::io_agent1 / obs_f32 (mjrl_set_io_layout) in the CPU emulation: with one agent's action row alone in the
+    buffer (the other acting with 0) the step writes exactly that agent's observation row of the default layout -- the
+    same doubles, or the same values as floats -- including the fused Language channel's slot."""
+    from tests.emu import emu as emu_mod
+    from tests.emu.batch import EmuBatch
+    rng = np.random.default_rng(4)
+    acts = rng.uniform(-1, 1, (25, 9)); acts[:, 8] = rng.integers(0, 3, 25) + 0.5
+    for driven in (0, 1):
+        for f32 in (0, 1):
+            full = EmuBatch(levels.level_path("two_agent.xml"), ["sender", "receiver"], 1, language=True)
+            lone = EmuBatch(levels.level_path("two_agent.xml"), ["sender", "receiver"], 1, language=True)
+            n_obs = full.obs_dim
+            for t in range(25):
+                a_full = np.zeros((1, 2, 9)); a_full[0, driven] = acts[t]
+                o_full, r = np.zeros((1, 2, n_obs)), np.zeros((1, 2))
+                term, trunc = np.zeros((1, 2), np.uint8), np.zeros((1, 2), np.uint8)
+                emu_mod.lib().emu_set_io_layout(0, 0)
+                full.step_batched(a_full, o_full, r, term, trunc)
+                # the one-agent layout: the action buffer's first act_dim doubles, the observation buffer's first obs_dim
+                a_lone = np.zeros((1, 2, 9)); a_lone.reshape(-1)[:9] = acts[t]
+                o_lone = np.zeros((1, 2, n_obs))
+                emu_mod.lib().emu_set_io_layout(driven + 1, f32)
+                try:
+                    lone.step_batched(a_lone, o_lone, np.zeros((1, 2)), np.zeros((1, 2), np.uint8), np.zeros((1, 2), np.uint8))
+                finally:
+                    emu_mod.lib().emu_set_io_layout(0, 0)
+                want = o_full[0, driven]
+                if f32:
+                    got = o_lone.reshape(-1).view(np.float32)[:n_obs]
+                    assert np.array_equal(got, want.astype(np.float32)), (driven, t)
+                else:
+                    assert np.array_equal(o_lone.reshape(-1)[:n_obs], want), (driven, t)
+                assert np.array_equal(lone.envs[0].qpos, full.envs[0].qpos)

@@ -71,6 +71,12 @@ term, trunc = np.zeros((2, 2), np.uint8), np.zeros((2, 2), np.uint8)
 for t in range(6):
     batch.set_step_reset_mask(np.array([t == 3, t == 4], np.uint8))
     batch.step_batched(rng.uniform(-1, 1, (2, 2, 9)), obs, rew, term, trunc)
+# the one-agent I/O layout (StepArgs::io_agent1 / obs_f32): one agent's action row in, its observation row out, as floats
+for agent1, f32 in ((1, 0), (2, 1)):
+    emu_mod.lib().emu_set_io_layout(agent1, f32)
+    for t in range(4):
+        batch.step_batched(rng.uniform(-1, 1, (2, 2, 9)), obs, rew, term, trunc)
+emu_mod.lib().emu_set_io_layout(0, 0)
 # a reset without a step (mask byte 2) and the autoreset kept by the step itself, two frames per step
 model = mjcf.compile_mjcf(levels.level_path("single_agent.xml"))
 env = EmuEnv(model, blob.pack(model))
