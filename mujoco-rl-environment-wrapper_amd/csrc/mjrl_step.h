@@ -1180,8 +1180,11 @@ enum { LANE_REC_INTS = REC_QUADS * 64 * 4 };
 // host: the table of a model (LANE_REC_INTS ints, zero-filled by the caller)
 inline void build_lane_records(const DevModel& m, const Lay& l, int32_t* out) {
   auto put = [&](int first, const void* rec, size_t nbytes, int L) {
-    const int32_t* w = (const int32_t*)rec;
-    for (size_t i = 0; i < nbytes / 4; i++) out[((size_t)(first + i / 4) * 64 + L) * 4 + i % 4] = w[i];
+    // (memcpy, not a read through an int pointer: the records hold doubles, and under type-based alias analysis such a
+    // read may be moved ahead of the loader's stores -- at -O3 the host compiler did, and the sensors' site size reached
+    // the GPU as 0)
+    for (size_t i = 0; i < nbytes / 4; i++)
+      __builtin_memcpy(&out[((size_t)(first + i / 4) * 64 + L) * 4 + i % 4], (const char*)rec + 4 * i, 4);
   };
   for (int L = 0; L < 64; L++) {
     // (zero-filled first: padding bytes of the structs must not differ from run to run)

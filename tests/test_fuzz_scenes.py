@@ -12,8 +12,12 @@ from oracle.oracle import OracleEnv
 from tests.emu.emu import EmuEnv
 
 
-def random_scene(rng):
+def random_scene(rng, sensors=False):
+    """``sensors``: every body also carries a site with one to three sensors of the kinds the levels use (rangefinder,
+    touch, accelerometer, frame axes) -- drawn from a second generator, so the scenes themselves stay the same."""
     n_body = int(rng.integers(1, 5))
+    srng = np.random.default_rng(int(rng.integers(0, 2 ** 31))) if sensors else None
+    sensor_xml = []
     parts = []
     slots = rng.permutation(4)
     for b in range(n_body):
@@ -41,13 +45,24 @@ def random_scene(rng):
                              f'euler="{e[0]:.2f} {e[1]:.2f} {e[2]:.2f}"/>')
         joint = '<joint type="free"/>' if rng.random() < 0.85 else \
             '<joint type="hinge" axis="0 1 0" damping="0.5" armature="0.1"/><joint type="slide" axis="0 0 1" damping="0.5"/>'
-        parts.append(f'<body pos="{x:.4f} {y:.4f} {z:.4f}" quat="{q[0]:.5f} {q[1]:.5f} {q[2]:.5f} {q[3]:.5f}">{joint}{"".join(geoms)}</body>')
+        site = ""
+        if sensors:
+            e = srng.uniform(-180, 180, 3)
+            site = f'<site name="s{b}" pos="0 0 0" size="0.15" euler="{e[0]:.1f} {e[1]:.1f} {e[2]:.1f}"/>'
+            for kind in srng.choice(["rangefinder", "touch", "accelerometer", "framexaxis", "frameyaxis", "framezaxis"],
+                                    size=int(srng.integers(1, 4)), replace=False):
+                if kind.startswith("frame"):
+                    sensor_xml.append(f'<{kind} objtype="site" objname="s{b}"/>')
+                else:
+                    sensor_xml.append(f'<{kind} site="s{b}" cutoff="{srng.choice([0, 3, 50])}"/>')
+        parts.append(f'<body pos="{x:.4f} {y:.4f} {z:.4f}" quat="{q[0]:.5f} {q[1]:.5f} {q[2]:.5f} {q[3]:.5f}">{joint}{"".join(geoms)}{site}</body>')
     wall = '<body pos="0.75 0 0.3"><geom type="box" size="0.15 0.8 0.3"/></body>' if rng.random() < 0.7 else ""
     friction = rng.choice(["1 0.005 0.0001", "0.4 0.005 0.0001"])
     return f"""
 <mujoco><option timestep="0.002"/>
 <default><geom density="300" margin="{rng.choice([0.0, 0.01])}" friction="{friction}"/></default>
-<worldbody><geom type="plane" size="5 5 0.1"/>{wall}{"".join(parts)}</worldbody></mujoco>"""
+<worldbody><geom type="plane" size="5 5 0.1"/>{wall}{"".join(parts)}</worldbody>
+{"<sensor>" + "".join(sensor_xml) + "</sensor>" if sensor_xml else ""}</mujoco>"""
 
 
 @pytest.mark.parametrize("block", range(6))
@@ -79,3 +94,27 @@ def test_random_scenes_step_like_the_oracle(block):
         assert worst < 1e-8, (seed, worst)
         assert np.isfinite(emu.qpos).all()
     assert len(paths) >= 2
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_scenes_with_sensors(block):
+    """The same scenes with a site and one to three sensors per body (rangefinder, touch, accelerometer, frame axes, with
+    and without cutoffs): the device source's sensor stage -- the sensors' records come as lane records -- against the
+    oracle's readings, every step."""
+    for k in range(6):
+        seed = 9000 + 100 * block + k
+        model = mjcf.compile_mjcf_string(random_scene(np.random.default_rng(seed), sensors=True), nconmax=24, njmax=120)
+        assert model.nsensor >= 1
+        packed = blob.pack(model)
+        ora, emu = OracleEnv(packed), EmuEnv(model, packed)
+        emu.step(forward_only=True)
+        for j in range(model.njnt):
+            if model.jnt_type[j] == mjcf.JNT_FREE:
+                qa, da = int(model.jnt_qposadr[j]), int(model.jnt_dofadr[j])
+                for env in (ora, emu):
+                    env.qvel[da:da + 2] = -2.0 * env.qpos[qa:qa + 2]
+        for step in range(220):
+            img = emu.step()
+            ora.step()
+            assert (img.ncon, img.nefc, img.niter) == (ora.ncon, ora.nefc, ora.niter), (seed, step)
+            assert np.allclose(emu.sens[:model.nsensordata], ora.sensordata, rtol=1e-8, atol=1e-8), (seed, step)

@@ -689,3 +689,36 @@ def test_joint_springs_through_the_c_abi(few_build):
         assert ora.ncon > 0
         assert np.abs(h.get_field("qpos") - ora.qpos).max() < 1e-9 and np.abs(h.get_field("qvel") - ora.qvel).max() < 1e-8
         h.close(); ora.close()
+
+
+@pytest.mark.parametrize("seed", [7003, 7020, 9001, 9104])
+def test_random_scenes_with_sensors_through_the_c_abi(seed):
+    """Random scenes with a site and one to three sensors per body (tests/test_fuzz_scenes.py): the readings of every step
+    against the oracle, generic and specialised kernel.  The sensors' constants reach the kernel as lane records built
+    on the HOST by the library (not by the emulation's build of the same source): in 7003 and 7020 a touch sensor's
+    contact lies outside its site's sphere, so the reading depends on the site's size -- which the library's table held
+    as 0 when its writer read the records through an int pointer (tools/parity_fuzz.py with sensors found it)."""
+    from tests.test_fuzz_scenes import random_scene
+    model = mjcf.compile_mjcf_string(random_scene(np.random.default_rng(seed), sensors=True), nconmax=24, njmax=120)
+    packed = blob.pack(model)
+    for specialize in (False, True):
+        h = _capi.Handle(packed, 2, specialize=specialize)
+        h.reset()
+        ora = OracleEnv(packed)
+        qvel = h.get_field("qvel")
+        for j in range(model.njnt):
+            if model.jnt_type[j] == mjcf.JNT_FREE:
+                qa, da = int(model.jnt_qposadr[j]), int(model.jnt_dofadr[j])
+                ora.qvel[da:da + 2] = -2.0 * ora.qpos[qa:qa + 2]
+                qvel[:, da:da + 2] = -2.0 * model.qpos0[qa:qa + 2]
+        h.set_field("qvel", qvel)
+        touched = 0.0
+        for step in range(260):
+            h.step_host(None, 1)
+            ora.step()
+            sd = h.get_field("sensordata")
+            assert np.allclose(sd, ora.sensordata[None, :], rtol=1e-8, atol=1e-8), (seed, specialize, step, sd[0], ora.sensordata)
+            touched = max(touched, float(np.abs(ora.sensordata[np.asarray(model.sensor_adr)[np.asarray(model.sensor_type) == mjcf.SENS_TOUCH]]).max(initial=0.0)))
+        if seed in (7003, 7020):
+            assert touched > 0
+        h.close(); ora.close()

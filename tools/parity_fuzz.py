@@ -2,7 +2,8 @@
 one to four trees of spheres / capsules / boxes, free / hinge / slide joints, a floor, mostly a wall): every step's contact,
 row and sweep counts and the final states, through the C-ABI, with the generic kernels in both forms (full-batch and
 few-copies solver forms).  The GPU test suite runs sixteen such scenes; this runs hundreds and prints a summary for
-profiles/.  Usage: parity_fuzz.py [n_scenes] [steps]"""
+profiles/.  Usage: parity_fuzz.py [n_scenes] [steps] [sensors]   (sensors: every body also carries a site with one to three
+sensors -- rangefinder, touch, accelerometer, frame axes -- and every step's sensordata is compared too)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,13 +16,15 @@ from tests.test_fuzz_scenes import random_scene
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+with_sensors = len(sys.argv) > 3 and sys.argv[3] == "sensors"
+sens_worst = 0.0
 t0 = time.time()
 worst, checked, mismatched, paths = 0.0, 0, [], {}
 for few in ("0", "1"):
     os.environ["MJRL_FEW"] = few
     for seed in range(7000, 7000 + n_scenes):
         rng = np.random.default_rng(seed)
-        model = mjcf.compile_mjcf_string(random_scene(rng), nconmax=24, njmax=120)
+        model = mjcf.compile_mjcf_string(random_scene(rng, sensors=with_sensors), nconmax=24, njmax=120)
         packed = blob.pack(model)
         h = _capi.Handle(packed, 2, specialize=False)
         h.reset()
@@ -43,6 +46,14 @@ for few in ("0", "1"):
                 mismatched.append((few, seed, step, stats[0, :3].tolist(), [ora.ncon, ora.nefc, ora.niter]))
                 ok = False
                 break
+            if with_sensors:
+                sd = h.get_field("sensordata")
+                err = float(np.abs(sd - ora.sensordata).max())
+                sens_worst = max(sens_worst, err)
+                if err > 1e-7:
+                    mismatched.append((few, seed, step, ["sensordata", err], []))
+                    ok = False
+                    break
             key = (model.ntree, int(model.rowmap), min(ora.nefc // 17, 3))
             paths[key] = paths.get(key, 0) + 1
         if ok:
@@ -52,6 +63,8 @@ for few in ("0", "1"):
         h.close(); ora.close()
 print(f"{2 * n_scenes} runs ({n_scenes} scenes x 2 kernel forms) x {steps} steps: {checked} steps compared, "
       f"{len(mismatched)} runs with a count mismatch, worst final |qpos - oracle| (relative) {worst:.2e}, {time.time() - t0:.0f} s")
+if with_sensors:
+    print(f"sensors on: worst |sensordata - oracle| over every step {sens_worst:.2e}")
 print("solver paths met (trees, lane map, rows // 17): " + ", ".join(f"{k}: {v}" for k, v in sorted(paths.items())))
 for m in mismatched[:10]:
     print("MISMATCH few=%s seed=%d step=%d kernel %s oracle %s" % m)
