@@ -1017,6 +1017,29 @@ void ora_render(const ora_model* m, ora_data* d, int cam, int width, int height,
     }
 }
 
+/* The same rays, for the test harness: per pixel the geom hit (-1: none) and the distance along the ray. */
+void ora_render_hits(const ora_model* m, ora_data* d, int cam, int width, int height, int* hit_out, double* dist_out) {
+  const double* cp = d->cam_xpos + 3 * cam;
+  const double* cm = d->cam_xmat + 9 * cam;
+  double t = tan(0.5 * m->cam_fovy[cam] * ORA_PI / 180.0), aspect = (double)width / (double)height;
+  for (int r = 0; r < height; r++)
+    for (int c = 0; c < width; c++) {
+      double lx = (2.0 * (c + 0.5) / width - 1.0) * t * aspect, ly = (2.0 * (r + 0.5) / height - 1.0) * t;
+      double loc[3] = {lx, ly, -1.0}, vec[3];
+      m3_mulv(vec, cm, loc);
+      v3_normalize(vec);
+      double best = -1.0;
+      int hit = -1;
+      for (int g = 0; g < m->ngeom; g++) {
+        if (m->geom_rgba[4 * g + 3] == 0) continue;
+        double x = ora_ray_geom(m->geom_type[g], d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, cp, vec);
+        if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
+      }
+      hit_out[(size_t)r * width + c] = hit;
+      dist_out[(size_t)r * width + c] = best;
+    }
+}
+
 /* ------------------------------------------------------------------ accessors for the test harness */
 typedef struct { const char* name; size_t offset; } field_t;
 #define F(name) {#name, offsetof(ora_data, name)}

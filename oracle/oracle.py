@@ -138,6 +138,16 @@ class OracleEnv:
         lib().ora_render(self._m, self._d, cam, width, height, out.ctypes.data_as(ctypes.c_void_p))
         return out.reshape(width, height, 3)
 
+    def render_hits(self, cam: int, width: int = 64, height: int = 64):
+        """Per pixel of ``render``'s image: the geom its ray hits (-1: none) and the distance (test harness)."""
+        hit = np.zeros((height, width), np.int32)
+        dist = np.zeros((height, width), np.float64)
+        lib().ora_render_hits.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+        lib().ora_render_hits(self._m, self._d, cam, width, height, hit.ctypes.data_as(ctypes.c_void_p),
+                              dist.ctypes.data_as(ctypes.c_void_p))
+        return hit, dist
+
     def contacts(self):
         out = []
         buf = (ctypes.c_double * 18)()

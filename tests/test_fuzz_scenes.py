@@ -12,11 +12,15 @@ from oracle.oracle import OracleEnv
 from tests.emu.emu import EmuEnv
 
 
-def random_scene(rng, sensors=False):
+def random_scene(rng, sensors=False, cameras=False):
     """``sensors``: every body also carries a site with one to three sensors of the kinds the levels use (rangefinder,
-    touch, accelerometer, frame axes) -- drawn from a second generator, so the scenes themselves stay the same."""
+    touch, accelerometer, frame axes) -- drawn from a second generator.
+    ``cameras``: every body carries a camera looking roughly at the middle of the scene, a fixed camera looks down on it,
+    the geoms are coloured and one or two lights (spot or directional, with and without shadows, one of them possibly on a
+    body) replace the default lighting -- a third generator."""
     n_body = int(rng.integers(1, 5))
     srng = np.random.default_rng(int(rng.integers(0, 2 ** 31))) if sensors else None
+    crng = np.random.default_rng(int(rng.integers(0, 2 ** 31)) + 1) if cameras else None
     sensor_xml = []
     parts = []
     slots = rng.permutation(4)
@@ -55,14 +59,105 @@ def random_scene(rng, sensors=False):
                     sensor_xml.append(f'<{kind} objtype="site" objname="s{b}"/>')
                 else:
                     sensor_xml.append(f'<{kind} site="s{b}" cutoff="{srng.choice([0, 3, 50])}"/>')
+        if cameras:
+            geoms = [g.replace("<geom ", f'<geom rgba="{c[0]:.2f} {c[1]:.2f} {c[2]:.2f} 1" ') for g, c in zip(geoms, crng.uniform(0.1, 1, (len(geoms), 3)))]
+            e = crng.uniform(-180, 180, 3)
+            site += f'<camera name="cam{b}" pos="{crng.uniform(-0.1, 0.1):.3f} {crng.uniform(-0.1, 0.1):.3f} 0.15" euler="{e[0]:.1f} {e[1]:.1f} {e[2]:.1f}" fovy="{crng.uniform(30, 100):.1f}"/>'
+            if b == 0 and crng.random() < 0.4:
+                site += f'<light pos="0 0 0.3" dir="{crng.uniform(-1, 1):.2f} {crng.uniform(-1, 1):.2f} -0.5" diffuse=".6 .6 .6" cutoff="{crng.uniform(30, 80):.0f}"/>'
         parts.append(f'<body pos="{x:.4f} {y:.4f} {z:.4f}" quat="{q[0]:.5f} {q[1]:.5f} {q[2]:.5f} {q[3]:.5f}">{joint}{"".join(geoms)}{site}</body>')
     wall = '<body pos="0.75 0 0.3"><geom type="box" size="0.15 0.8 0.3"/></body>' if rng.random() < 0.7 else ""
     friction = rng.choice(["1 0.005 0.0001", "0.4 0.005 0.0001"])
+    fixed = ""
+    if cameras:
+        wall = wall.replace("<geom ", '<geom rgba=".7 .6 .3 1" ')
+        lx, ly = crng.uniform(-1, 1, 2)
+        kind = 'directional="true"' if crng.random() < 0.3 else f'cutoff="{crng.uniform(25, 70):.0f}" exponent="{crng.choice([0, 5, 10])}"'
+        shadow = 'castshadow="false"' if crng.random() < 0.2 else ""
+        fixed = (f'<light pos="{lx:.2f} {ly:.2f} {crng.uniform(1.5, 3):.2f}" dir="{-lx * 0.3:.2f} {-ly * 0.3:.2f} -1" diffuse=".7 .7 .7" {kind} {shadow}/>'
+                 f'<camera name="top" pos="{crng.uniform(-0.3, 0.3):.2f} {crng.uniform(-0.3, 0.3):.2f} 2.2" euler="0 0 {crng.uniform(-180, 180):.0f}" fovy="60"/>'
+                 f'<camera name="side" pos="-1.6 {crng.uniform(-0.5, 0.5):.2f} 0.4" euler="90 -90 0" fovy="70"/>')
     return f"""
 <mujoco><option timestep="0.002"/>
 <default><geom density="300" margin="{rng.choice([0.0, 0.01])}" friction="{friction}"/></default>
-<worldbody><geom type="plane" size="5 5 0.1"/>{wall}{"".join(parts)}</worldbody>
+<worldbody><geom type="plane" size="5 5 0.1"{' rgba=".4 .5 .4 1"' if cameras else ""}/>{fixed}{wall}{"".join(parts)}</worldbody>
 {"<sensor>" + "".join(sensor_xml) + "</sensor>" if sensor_xml else ""}</mujoco>"""
+
+
+def random_articulated_scene(rng):
+    """One to three kinematic trees of two to seven bodies (free, hinge + slide or hinged roots; hinge and slide children up
+    to two levels below the root, in random directions), with what the levels' ants have and what they do not: joint
+    limits, damping, armature, springs with a rest angle, motors with gears and (mostly) clamped controls, limbs that
+    reach their own tree's other limbs, the floor, a wall and the other trees.  Returns (xml, nu)."""
+    n_tree = int(rng.integers(1, 4))
+    slots = rng.permutation(4)
+    motors = []
+    count = [0]
+
+    def limb(direction, length, depth, budget):
+        """A child body at `direction` x 0.09 from its parent's frame: a capsule along `direction`, one or two joints."""
+        k = count[0]
+        count[0] += 1
+        d = direction / np.linalg.norm(direction)
+        joints = []
+        for jn in range(int(rng.integers(1, 3)) if budget >= 2 else 1):
+            name = f"j{k}_{jn}"
+            if rng.random() < 0.8 or jn > 0:         # (two slides along one axis: a singular inertia matrix)
+                axis = rng.normal(size=3) if rng.random() < 0.5 else np.eye(3)[int(rng.integers(0, 3))]
+                lim = ""
+                if rng.random() < 0.6:
+                    lo, hi = -rng.uniform(5, 60), rng.uniform(5, 60)
+                    lim = f' limited="true" range="{lo:.1f} {hi:.1f}"'
+                spring = f' stiffness="{rng.uniform(1, 20):.2f}" springref="{rng.uniform(-20, 20):.1f}"' if rng.random() < 0.3 else ""
+                joints.append(f'<joint name="{name}" type="hinge" axis="{axis[0]:.4f} {axis[1]:.4f} {axis[2]:.4f}" '
+                              f'damping="{rng.uniform(0, 1):.3f}" armature="{rng.uniform(0, 0.05):.4f}"{lim}{spring}/>')
+            else:
+                joints.append(f'<joint name="{name}" type="slide" axis="{d[0]:.4f} {d[1]:.4f} {d[2]:.4f}" limited="true" '
+                              f'range="-0.03 0.05" damping="{rng.uniform(0.5, 2):.3f}"/>')
+            if rng.random() < 0.7:
+                clamp = 'ctrllimited="true" ctrlrange="-1 1"' if rng.random() < 0.8 else 'ctrllimited="false"'
+                motors.append(f'<motor joint="{name}" gear="{rng.uniform(2, 25):.2f}" {clamp}/>')
+        end = d * length
+        geom = f'<geom type="capsule" size="{rng.uniform(0.025, 0.04):.4f}" fromto="0 0 0 {end[0]:.4f} {end[1]:.4f} {end[2]:.4f}"/>'
+        child = ""
+        used = len(joints)
+        if depth < 2 and budget - used >= 1 and rng.random() < 0.7:
+            turn = d + rng.normal(size=3) * 0.5
+            child = limb(turn, rng.uniform(0.08, 0.14), depth + 1, min(budget - used, 2))
+            child = f'<body pos="{end[0]:.4f} {end[1]:.4f} {end[2]:.4f}">{child}</body>'
+        return "".join(joints) + geom + child
+
+    parts = []
+    for t in range(n_tree):
+        x, y = [(-0.35, -0.35), (0.35, -0.35), (-0.35, 0.35), (0.35, 0.35)][slots[t]] + rng.uniform(-0.03, 0.03, 2)
+        q = rng.normal(size=4) * [1, 0.3, 0.3, 0.3]
+        q /= np.linalg.norm(q)
+        kind = rng.choice(["free", "free", "free", "planar", "hinged"])
+        if kind == "free":
+            z, root = rng.uniform(0.35, 0.5), '<joint type="free"/>'
+        elif kind == "planar":
+            z, root = rng.uniform(0.3, 0.4), ('<joint type="hinge" axis="0 1 0" damping="0.2" armature="0.05"/>'
+                                               '<joint type="slide" axis="0 0 1" damping="0.5"/>')
+        else:
+            z, root = rng.uniform(0.3, 0.45), '<joint type="hinge" axis="1 0 0" damping="0.1"/>'
+        torso = f'<geom type="sphere" size="{rng.uniform(0.06, 0.09):.4f}"/>' if rng.random() < 0.6 else \
+            f'<geom type="box" size="{rng.uniform(0.05, 0.08):.4f} {rng.uniform(0.05, 0.08):.4f} {rng.uniform(0.03, 0.05):.4f}"/>'
+        limbs = []
+        # limbs leave the torso in separate directions (siblings are not parent and child: they may touch each other)
+        dirs = [np.array(v, float) for v in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1))]
+        for i in rng.permutation(5)[:int(rng.integers(1, 5))]:
+            d = dirs[i] + rng.normal(size=3) * 0.15
+            at = dirs[i] * 0.09
+            limbs.append(f'<body pos="{at[0]:.4f} {at[1]:.4f} {at[2]:.4f}">{limb(d, rng.uniform(0.1, 0.16), 1, 2)}</body>')
+        parts.append(f'<body pos="{x:.4f} {y:.4f} {z:.4f}" quat="{q[0]:.5f} {q[1]:.5f} {q[2]:.5f} {q[3]:.5f}">{root}{torso}{"".join(limbs)}</body>')
+    wall = '<body pos="0.8 0 0.3"><geom type="box" size="0.15 0.8 0.3"/></body>' if rng.random() < 0.6 else ""
+    friction = rng.choice(["1 0.005 0.0001", "0.5 0.005 0.0001"])
+    xml = f"""
+<mujoco><option timestep="0.002"/>
+<default><geom density="400" margin="{rng.choice([0.0, 0.01])}" friction="{friction}"/></default>
+<worldbody><geom type="plane" size="5 5 0.1"/>{wall}{"".join(parts)}</worldbody>
+<actuator>{"".join(motors)}</actuator></mujoco>"""
+    return xml, len(motors)
 
 
 @pytest.mark.parametrize("block", range(6))
@@ -118,3 +213,33 @@ def test_random_scenes_with_sensors(block):
             ora.step()
             assert (img.ncon, img.nefc, img.niter) == (ora.ncon, ora.nefc, ora.niter), (seed, step)
             assert np.allclose(emu.sens[:model.nsensordata], ora.sensordata, rtol=1e-8, atol=1e-8), (seed, step)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_articulated_scenes_step_like_the_oracle(block):
+    """Random trees with joint limits, springs, damping, armature and motors under random controls (beyond their clamp):
+    counts of every step and the states at the end, the device source against the oracle."""
+    shapes = set()
+    for k in range(4):
+        seed = 3000 + 100 * block + k
+        rng = np.random.default_rng(seed)
+        xml, nu = random_articulated_scene(rng)
+        model = mjcf.compile_mjcf_string(xml, nconmax=32, njmax=160)
+        assert model.nu == nu and model.nv <= 64
+        packed = blob.pack(model)
+        ora, emu = OracleEnv(packed), EmuEnv(model, packed)
+        emu.step(forward_only=True)              # (the reset's forward pass: the first step's warm start)
+        crng = np.random.default_rng(seed + 1)
+        worst = 0.0
+        for step in range(220):
+            if step % 10 == 0 and nu:
+                ctrl = crng.uniform(-1.3, 1.3, nu)
+                ora.ctrl[:nu] = ctrl
+                emu.ctrl[:nu] = ctrl
+            img = emu.step()
+            ora.step()
+            assert (img.ncon, img.nefc, img.niter) == (ora.ncon, ora.nefc, ora.niter), (seed, step)
+            worst = max(worst, np.abs(emu.qpos - ora.qpos).max(), np.abs(emu.qvel - ora.qvel).max() * 1e-1)
+        assert worst < 1e-8, (seed, worst)
+        shapes.add((model.ntree, model.rowmap, model.nv))
+    assert len(shapes) >= 2

@@ -722,3 +722,30 @@ def test_random_scenes_with_sensors_through_the_c_abi(seed):
         if seed in (7003, 7020):
             assert touched > 0
         h.close(); ora.close()
+
+
+@pytest.mark.parametrize("seed", [3000, 3007, 3010, 3104])
+def test_random_articulated_scenes_through_the_c_abi(seed, few_build):
+    """Random trees with joint limits, springs, damping, armature and motors (tests/test_fuzz_scenes.py), controls drawn
+    beyond their clamp every ten steps: counts of every step and the states at the end against the oracle, generic and
+    specialised kernel."""
+    from tests.test_fuzz_scenes import random_articulated_scene
+    xml, nu = random_articulated_scene(np.random.default_rng(seed))
+    model = mjcf.compile_mjcf_string(xml, nconmax=32, njmax=160)
+    packed = blob.pack(model)
+    for specialize in (False, True):
+        h = _capi.Handle(packed, 2, specialize=specialize)
+        h.reset()
+        ora = OracleEnv(packed)
+        crng = np.random.default_rng(seed + 1)
+        for step in range(240):
+            if step % 10 == 0 and nu:
+                ctrl = crng.uniform(-1.3, 1.3, nu)
+                ora.ctrl[:nu] = ctrl
+                h.set_field("ctrl", np.tile(ctrl, (2, 1)))
+            h.step_host(None, 1)
+            ora.step()
+            stats = h.get_field("solver_stats")
+            assert (stats[:, 0] == ora.ncon).all() and (stats[:, 1] == ora.nefc).all() and (stats[:, 2] == ora.niter).all(), (seed, step)
+        assert np.abs(h.get_field("qpos") - ora.qpos).max() < 1e-9 and np.abs(h.get_field("qvel") - ora.qvel).max() < 1e-8
+        h.close(); ora.close()

@@ -2,8 +2,11 @@
 one to four trees of spheres / capsules / boxes, free / hinge / slide joints, a floor, mostly a wall): every step's contact,
 row and sweep counts and the final states, through the C-ABI, with the generic kernels in both forms (full-batch and
 few-copies solver forms).  The GPU test suite runs sixteen such scenes; this runs hundreds and prints a summary for
-profiles/.  Usage: parity_fuzz.py [n_scenes] [steps] [sensors]   (sensors: every body also carries a site with one to three
-sensors -- rangefinder, touch, accelerometer, frame axes -- and every step's sensordata is compared too)"""
+profiles/.  Usage: parity_fuzz.py [n_scenes] [steps] [sensors | articulated]
+sensors: every body also carries a site with one to three sensors -- rangefinder, touch, accelerometer, frame axes -- and
+every step's sensordata is compared too.  articulated: random_articulated_scene instead -- trees of two to seven bodies
+with joint limits, springs, damping, armature and motors, under random controls (beyond their clamp) redrawn every ten
+steps."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,25 +15,31 @@ import __graft_entry__ as entry
 entry.load_package()
 from mjrl_amd import _capi, blob, mjcf
 from oracle.oracle import OracleEnv
-from tests.test_fuzz_scenes import random_scene
+from tests.test_fuzz_scenes import random_articulated_scene, random_scene
 
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 with_sensors = len(sys.argv) > 3 and sys.argv[3] == "sensors"
+articulated = len(sys.argv) > 3 and sys.argv[3] == "articulated"
 sens_worst = 0.0
 t0 = time.time()
-worst, checked, mismatched, paths = 0.0, 0, [], {}
+worst, checked, mismatched, paths, capped = 0.0, 0, [], {}, 0
 for few in ("0", "1"):
     os.environ["MJRL_FEW"] = few
     for seed in range(7000, 7000 + n_scenes):
         rng = np.random.default_rng(seed)
-        model = mjcf.compile_mjcf_string(random_scene(rng, sensors=with_sensors), nconmax=24, njmax=120)
+        if articulated:
+            xml, nu = random_articulated_scene(rng)
+            model = mjcf.compile_mjcf_string(xml, nconmax=32, njmax=160)
+            crng = np.random.default_rng(seed + 1)
+        else:
+            model = mjcf.compile_mjcf_string(random_scene(rng, sensors=with_sensors), nconmax=24, njmax=120)
         packed = blob.pack(model)
         h = _capi.Handle(packed, 2, specialize=False)
         h.reset()
         ora = OracleEnv(packed)
         qvel = h.get_field("qvel")
-        for j in range(model.njnt):
+        for j in range(0 if articulated else model.njnt):
             if model.jnt_type[j] == mjcf.JNT_FREE:
                 qa, da = int(model.jnt_qposadr[j]), int(model.jnt_dofadr[j])
                 ora.qvel[da:da + 2] = -2.0 * ora.qpos[qa:qa + 2]
@@ -38,6 +47,10 @@ for few in ("0", "1"):
         h.set_field("qvel", qvel)
         ok = True
         for step in range(steps):
+            if articulated and step % 10 == 0 and model.nu:
+                ctrl = crng.uniform(-1.3, 1.3, model.nu)
+                ora.ctrl[:model.nu] = ctrl
+                h.set_field("ctrl", np.tile(ctrl, (2, 1)))
             h.step_host(None, 1)
             ora.step()
             stats = h.get_field("solver_stats")
@@ -55,6 +68,8 @@ for few in ("0", "1"):
                     ok = False
                     break
             key = (model.ntree, int(model.rowmap), min(ora.nefc // 17, 3))
+            if ora.niter >= 100:
+                capped += 1
             paths[key] = paths.get(key, 0) + 1
         if ok:
             q = h.get_field("qpos")
@@ -63,6 +78,7 @@ for few in ("0", "1"):
         h.close(); ora.close()
 print(f"{2 * n_scenes} runs ({n_scenes} scenes x 2 kernel forms) x {steps} steps: {checked} steps compared, "
       f"{len(mismatched)} runs with a count mismatch, worst final |qpos - oracle| (relative) {worst:.2e}, {time.time() - t0:.0f} s")
+print(f"steps whose solve ran to the 100-sweep cap: {capped}")
 if with_sensors:
     print(f"sensors on: worst |sensordata - oracle| over every step {sens_worst:.2e}")
 print("solver paths met (trees, lane map, rows // 17): " + ", ".join(f"{k}: {v}" for k, v in sorted(paths.items())))

@@ -1,0 +1,81 @@
+"""Differential fuzz of the ray kernel against the oracle's ray caster on random scenes (tests/test_fuzz_scenes.random_scene
+with cameras: coloured spheres / capsules / boxes after they have fallen and come to rest against each other, a wall, a
+camera on every body plus two fixed ones, a spot or directional light with or without shadows, sometimes a second light
+on a body).  Per image: the share of pixels that differ by more than one level from the oracle's (fp64, every geom tested
+against every ray; the kernel: fp32, candidates culled per block), and -- exact -- the same images with the kernel's tight
+culls switched off (MJRL_RENDER_LOOSE=1) byte for byte.  Usage: render_fuzz.py [n_scenes] [first_seed]"""
+import os, re, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import __graft_entry__ as entry
+entry.load_package()
+from mjrl_amd import _capi, blob, mjcf
+from oracle.oracle import OracleEnv
+from tests.test_fuzz_scenes import random_scene
+
+def unexplained(got, ref, tol=2):
+    """Pixels of `got` with a channel outside the range of the 3 x 3 pixels around them in `ref` (+- `tol` levels): not
+    the one-pixel shift of an edge or of a steep gradient (a silhouette, a shadow's or a light cone's border, the floor's
+    horizon, a small sphere's highlight) that fp32 rays against fp64 rays make."""
+    H, W, _ = got.shape
+    pad = np.pad(ref, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    stack = np.stack([pad[dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)])
+    return ((got < stack.min(axis=0) - tol) | (got > stack.max(axis=0) + tol)).any(axis=-1)
+
+
+variant = os.environ.get("RENDER_FUZZ_VARIANT", "")
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+t0 = time.time()
+images, worst_share, worst_any, cull_diffs, bad, dumps = 0, 0.0, 0.0, 0, [], {}
+n_unexplained = 0
+for seed in range(first, first + n_scenes):
+    xml = random_scene(np.random.default_rng(seed), cameras=True)
+    if "nobodylight" in variant:
+        xml = re.sub(r'<light pos="0 0 0.3"[^>]*>', "", xml)
+    if "onlybodylight" in variant:
+        xml = re.sub(r'<light pos="(?!0 0 0.3)[^>]*>', "", xml)
+    if "noshadow" in variant:
+        xml = xml.replace(' castshadow="false"', "").replace("<light ", '<light castshadow="false" ')
+    model = mjcf.compile_mjcf_string(xml, nconmax=24, njmax=120)
+    packed = blob.pack(model)
+    h = _capi.Handle(packed, 2, specialize=False)
+    h.set_scene_cache(True)       # the frames of the step's forward pass, as MuJoCoRL sets it (what mjv_updateScene reads)
+    h.reset()
+    ora = OracleEnv(packed)
+    steps = 40 + 60 * (seed % 5)            # in the air, landing, at rest
+    for _ in range(steps):
+        h.step_host(None, 1)
+    ora.step(steps)
+    assert np.abs(h.get_field("qpos") - ora.qpos).max() < 1e-9, seed
+    for w, hh in ((64, 64), (72, 40)):
+        os.environ.pop("MJRL_RENDER_LOOSE", None)
+        got = h.render(w, hh)
+        os.environ["MJRL_RENDER_LOOSE"] = "1"
+        loose = h.render(w, hh)
+        os.environ.pop("MJRL_RENDER_LOOSE", None)
+        if not np.array_equal(got, loose):
+            cull_diffs += 1
+            bad.append((seed, w, hh, "tight culls change pixels", int((got != loose).any(axis=-1).sum())))
+        for cam in range(model.ncam):
+            ref = ora.render(cam, w, hh).reshape(hh, w, 3).astype(int)
+            differ = np.abs(got[0, cam].astype(int) - ref).max(axis=-1)
+            share, share_any = float((differ > 1).mean()), float((differ > 0).mean())
+            n_unexplained += int(unexplained(got[0, cam].astype(int), ref).sum())
+            worst_share, worst_any = max(worst_share, share), max(worst_any, share_any)
+            images += 1
+            if share > 0.01:
+                bad.append((seed, w, hh, f"camera {cam}", share))
+                if os.environ.get("RENDER_FUZZ_DUMP") and len(dumps) < 40:
+                    dumps[f"{seed}_{w}_{cam}_gpu"] = got[0, cam].copy()
+                    dumps[f"{seed}_{w}_{cam}_ref"] = ref.astype(np.uint8)
+    h.close(); ora.close()
+print(f"{n_scenes} scenes, {images} images against the oracle: worst share of pixels off by more than one level {worst_share:.4f}, "
+      f"by any amount {worst_any:.4f}; images changed by the tight culls: {cull_diffs}; {time.time() - t0:.0f} s")
+if dumps:
+    np.savez_compressed(os.environ["RENDER_FUZZ_DUMP"], **dumps)
+print(f"variant [{variant}]: pixels outside the oracle's local range: {n_unexplained}")
+for b in bad[:20]:
+    print("BAD", b)
+sys.exit(1 if bad else 0)
