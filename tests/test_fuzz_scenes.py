@@ -84,6 +84,16 @@ def random_scene(rng, sensors=False, cameras=False):
 {"<sensor>" + "".join(sensor_xml) + "</sensor>" if sensor_xml else ""}</mujoco>"""
 
 
+def unexplained(got, ref, tol=2):
+    """Pixels of `got` with a channel outside the range of the 3 x 3 pixels around them in `ref` (+- `tol` levels): not
+    the one-pixel shift of an edge or of a steep gradient (a silhouette, a shadow's or a light cone's border, the floor's
+    horizon, a small sphere's highlight) that fp32 rays against fp64 rays make."""
+    H, W, _ = got.shape
+    pad = np.pad(ref, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    stack = np.stack([pad[dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)])
+    return ((got < stack.min(axis=0) - tol) | (got > stack.max(axis=0) + tol)).any(axis=-1)
+
+
 def random_articulated_scene(rng):
     """One to three kinematic trees of two to seven bodies (free, hinge + slide or hinged roots; hinge and slide children up
     to two levels below the root, in random directions), with what the levels' ants have and what they do not: joint
