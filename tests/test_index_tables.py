@@ -93,6 +93,25 @@ def test_generated_level_compiles_like_the_reference_file(name):
     assert xmldict.find_in_nested_dict(a, parent="sensor") == xmldict.find_in_nested_dict(b, parent="sensor")
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_every_level_file_of_the_reference_tree_is_inside_the_supported_subset():
+    """All MJCF files the reference ships (benchmarking/levels, Testing/levels, Testing/sensor_levels) compile -- nothing in
+    them is refused by the loud subset check -- and fit the step kernel's limits (one wavefront: nv, bodies, joints <= 64,
+    geoms <= 128, chains of at most 8 dofs); Testing/levels/Model2..10 are the 2-agent arena in other colours (the level
+    variants of mujoco_parent.py:351-356)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REF, "**", "*.xml"), recursive=True))
+    assert len(files) >= 19
+    base = mjcf.compile_mjcf(os.path.join(REF, "Testing/levels/Model2.xml"))
+    for path in files:
+        m = mjcf.compile_mjcf(path)
+        assert 1 <= m.nv <= 64 and m.nbody <= 64 and m.njnt <= 64 and m.ngeom <= 128 and m.maxdofdepth + 1 <= 8, path
+        if "/Testing/levels/Model" in path and not path.endswith("Model1.xml"):
+            for key in m.arrays:
+                if key != "geom_rgba":
+                    assert np.array_equal(m.arrays[key], base.arrays[key]), (path, key)
+
+
 def test_blob_sections_are_aligned_to_their_element_size():
     """The float64 sections of a packed model start on 8-byte boundaries and the int32 sections on 4-byte ones (the
     header is 8 bytes + 4 bytes per size field, so the number of size fields has to be even): the device reads them with
