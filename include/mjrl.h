@@ -185,7 +185,8 @@ int mjrl_query(mjrl_env* env, const char* name, double* h_out, size_t nbytes);
 /* Agent cameras (get_camera_data, mujoco_parent.py:540-555): every fixed camera of the level, ray cast;
  * rgb [n_env][ncam][height][width][3] uint8, rows bottom-up as glReadPixels returns them (mujoco_parent.py:571, 538).
  * The image model is OpenGL's fixed-function lighting equation with the parameters MuJoCo documents (headlight, the
- * level's <light>s, materials); shadows, textures, the skybox and anti-aliasing are not drawn.
+ * level's <light>s, materials) with the lights' shadows as shadow rays (castshadow); textures, the skybox and
+ * anti-aliasing are not drawn.
  *
  * WHICH frames are drawn: the reference calls mjv_updateScene(model, data, ...) (mujoco_parent.py:533), which reads the
  * geom / camera / light frames out of MjData as the last forward pass left them -- after mj_step those are one
