@@ -73,8 +73,20 @@ __device__ __forceinline__ double sum_n(double v, int width) {
 __device__ __forceinline__ double sum(double v) { return sum_n(v, 64); }
 
 // value of lane N of the caller's row of 16 lanes, in every lane of that row (DPP row_newbcast, no LDS traffic)
+// (ONE v_mov_b64_dpp: row_newbcast is the control word the 64-bit DPP move of gfx90a and later takes, and the builtin
+// forms it from a double operand; the other controls stay two 32-bit moves.  35 against 38 cycles per row step of the
+// register solvers in isolation, tools/dpp64_probe.hip -- 6 % of the long solves the launch waits for.)
+// (In the model-specialised kernels only: with it the generic kernels of libmjrl_hip.so -- every size a run-time value --
+// run into a code generator error of this compiler, "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base".
+// The same bits either way.)
 template <int N>
-__device__ __forceinline__ double bcast16(double v) { return dpp<0x150 + N>(v); }
+__device__ __forceinline__ double bcast16(double v) {
+#if defined(MJRL_SPEC)
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xF, 0xF, true);
+#else
+  return dpp<0x150 + N>(v);
+#endif
+}
 
 template <int N>
 __device__ __forceinline__ int bcast16i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xF, 0xF, true); }
