@@ -421,7 +421,8 @@ class _Compiler:
                 a = self.defaults.apply(child, childclass)
                 self.sites.append(dict(name=a.get("name", ""), body=body_id,
                                        pos=_vec(a.get("pos"), 3, [0, 0, 0]), quat=self.orientation(a),
-                                       size=_vec(a.get("size"), 3, [0.005, 0.005, 0.005])))
+                                       size=_vec(a.get("size"), 3, [0.005, 0.005, 0.005]),
+                                       type=a.get("type", "sphere")))
             elif child.tag == "inertial":
                 # XML reference, body/inertial: pos and mass required; diaginertia in the frame given by the orientation
                 # attributes, or fullinertia (M11 M22 M33 M12 M13 M23) in the body frame
@@ -991,6 +992,10 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
             site_name = el.attrib.get("site", el.attrib.get("objname"))
             if el.tag.startswith("frame") and el.attrib.get("objtype", "site") != "site":
                 raise ValueError("frame sensors are supported on sites only")
+            # (a touch sensor's active zone is its site's SHAPE -- the kernels test a sphere of radius size[0]; a frame or a
+            # rangefinder reads the site's frame only, whatever its shape)
+            if el.tag == "touch" and c.sites[m.names["site"].index(site_name)]["type"] != "sphere":
+                _refuse(f'a touch sensor on a site of type "{c.sites[m.names["site"].index(site_name)]["type"]}" (sphere sites only)')
             s_type.append(stype)
             s_objid.append(m.names["site"].index(site_name))
             s_dim.append(dim)

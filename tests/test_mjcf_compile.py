@@ -337,6 +337,8 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
     (TWO, "", '<actuator><motor joint="ja" forcelimited="true" forcerange="-1 1"/></actuator>', "forcelimited"),
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1"/><site name="s"/></body>', "",
      '<sensor><gyro site="s"/></sensor>', "gyro"),
+    ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1"/><site name="s" type="box" size="0.1 0.1 0.1"/></body>', "",
+     '<sensor><touch site="s"/></sensor>', "touch sensor on a site of type"),
 ])
 def test_features_outside_the_subset_are_refused_by_name(body, head, tail, named):
     with pytest.raises(mjcf.UnsupportedMJCF) as err:
