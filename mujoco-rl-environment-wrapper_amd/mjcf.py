@@ -444,6 +444,8 @@ class _Compiler:
                 a = self.defaults.apply(child, childclass)
                 if a.get("active", "true") == "false":
                     continue
+                if a.get("mode", "fixed") != "fixed":       # (track / trackcom / targetbody...: the light would move or turn)
+                    _refuse(f'light mode "{a.get("mode")}"')
                 d = _vec(a.get("dir"), 3, [0, 0, -1])
                 n = np.linalg.norm(d)
                 self.lights.append(dict(name=a.get("name", ""), body=body_id, pos=_vec(a.get("pos"), 3, [0, 0, 0]),

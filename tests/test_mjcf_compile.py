@@ -339,6 +339,8 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
      '<sensor><gyro site="s"/></sensor>', "gyro"),
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1"/><site name="s" type="box" size="0.1 0.1 0.1"/></body>', "",
      '<sensor><touch site="s"/></sensor>', "touch sensor on a site of type"),
+    ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1"/><light mode="trackcom" pos="0 0 2"/></body>', "", "",
+     "light mode"),
 ])
 def test_features_outside_the_subset_are_refused_by_name(body, head, tail, named):
     with pytest.raises(mjcf.UnsupportedMJCF) as err:
