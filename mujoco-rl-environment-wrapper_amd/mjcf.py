@@ -588,7 +588,7 @@ class _Compiler:
                  solimp=_vec(a.get("solimp"), 5, [0.9, 0.95, 0.001, 0.5, 2.0]),
                  solmix=float(a.get("solmix", 1.0)),
                  rgba=_vec(a.get("rgba"), 4, [0.5, 0.5, 0.5, 1.0]),
-                 mass=float(a["mass"]) if "mass" in a else None)
+                 mass=float(a["mass"]) if "mass" in a else None, group=int(a.get("group", 0)))
         # visual material (XML reference, geom/material and geom/rgba): without a material the renderer's defaults
         # (specular 0.5, shininess 0.5, no emission); with one, its properties -- and its colour unless the geom sets rgba
         mat = self.materials.get(a.get("material", ""))
@@ -692,6 +692,10 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
 
     nbody, njnt, ngeom = len(c.bodies), len(c.joints), len(c.geoms)
     m.nbody, m.njnt, m.ngeom, m.nsite, m.ncam = nbody, njnt, ngeom, len(c.sites), len(c.cams)
+    # (geom groups 3..5 are hidden under the default visual options the reference renders with, mujoco_parent.py:533; the
+    # ray caster draws every opaque geom -- a level that relies on hidden groups would get other camera images)
+    if c.cams and any(g["group"] >= 3 for g in c.geoms):
+        _refuse("a geom in group 3 or higher (hidden by the renderer's default options) in a level with cameras")
 
     # ---- joints / dofs
     jnt_qposadr, jnt_dofadr = np.zeros(njnt, np.int32), np.zeros(njnt, np.int32)

@@ -341,6 +341,7 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
      '<sensor><touch site="s"/></sensor>', "touch sensor on a site of type"),
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1"/><light mode="trackcom" pos="0 0 2"/></body>', "", "",
      "light mode"),
+    ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" group="3"/><camera name="c"/></body>', "", "", "group 3"),
 ])
 def test_features_outside_the_subset_are_refused_by_name(body, head, tail, named):
     with pytest.raises(mjcf.UnsupportedMJCF) as err:
