@@ -1091,6 +1091,11 @@ def compile_mjcf_string(text: str, xml_path: str = "", nconmax=None, njmax=None,
     m.njmax = int(njmax) if njmax is not None else n_limited + 4 * m.nconmax
 
     _set_const(m)
+    # <statistic meaninertia="..."/> overrides the computed value (it scales the solver's stop test); the section's other
+    # attributes -- extent, center, meansize, meanmass -- scale the visualisation only
+    stat = c.root.find("statistic")
+    if stat is not None and "meaninertia" in stat.attrib:
+        m.meaninertia = float(stat.attrib["meaninertia"])
     _kernel_schedules(m, lane_map)
     return m
 

@@ -364,6 +364,16 @@ def test_what_is_implemented_or_inert_still_compiles(head):
     assert compile_xml(body, head=head).nv == 1
 
 
+def test_statistic_meaninertia_overrides_the_computed_value():
+    """<statistic meaninertia> replaces the mean diagonal of M(qpos0) in the model (the scale of the solver's stop test);
+    the section's other attributes are the visualiser's."""
+    body = '<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" density="1000"/></body>'
+    computed = compile_xml(body).meaninertia
+    assert abs(computed - np.mean([4.18879, 4.18879, 4.18879, 0.0167552, 0.0167552, 0.0167552])) < 1e-4
+    assert compile_xml(body, head='<statistic meaninertia="2.5" extent="3"/>').meaninertia == 2.5
+    assert compile_xml(body, head='<statistic extent="3"/>').meaninertia == computed
+
+
 def test_every_shipped_level_is_inside_the_subset():
     from mjrl_amd import levels
     for name in sorted(levels.LEVELS):
