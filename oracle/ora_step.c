@@ -1040,6 +1040,51 @@ void ora_render_hits(const ora_model* m, ora_data* d, int cam, int width, int he
     }
 }
 
+/* One pixel's shadow rays, for the test harness: out[4 * li + 0..3] = n.L at the pixel's surface point for light li, the
+ * first occluding geom found (-1: none), its distance along the shadow ray, the light's distance (0: directional). */
+void ora_shadow_probe(const ora_model* m, ora_data* d, int cam, int width, int height, int r, int c, double* out) {
+  const double* cp = d->cam_xpos + 3 * cam;
+  const double* cm = d->cam_xmat + 9 * cam;
+  double t = tan(0.5 * m->cam_fovy[cam] * ORA_PI / 180.0), aspect = (double)width / (double)height;
+  double lx = (2.0 * (c + 0.5) / width - 1.0) * t * aspect, ly = (2.0 * (r + 0.5) / height - 1.0) * t;
+  double loc[3] = {lx, ly, -1.0}, vec[3];
+  m3_mulv(vec, cm, loc);
+  v3_normalize(vec);
+  double best = -1.0;
+  int hit = -1;
+  for (int g = 0; g < m->ngeom; g++) {
+    if (m->geom_rgba[4 * g + 3] == 0) continue;
+    double x = ora_ray_geom(m->geom_type[g], d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, cp, vec);
+    if (x >= 0 && (best < 0 || x < best)) { best = x; hit = g; }
+  }
+  for (int li = 0; li < m->nlight; li++) { out[4 * li] = 0; out[4 * li + 1] = -1; out[4 * li + 2] = 0; out[4 * li + 3] = 0; }
+  if (hit < 0) return;
+  double p[3], n[3];
+  v3_addscl(p, cp, vec, best);
+  ora_geom_normal(m->geom_type[hit], d->geom_xpos + 3 * hit, d->geom_xmat + 9 * hit, m->geom_size + 3 * hit, p, n);
+  for (int li = 0; li < m->nlight; li++) {
+    const int b = m->light_bodyid[li];
+    double pos[3], dir[3], L[3], light_dist = 0;
+    m3_mulv(pos, d->xmat + 9 * b, m->light_pos + 3 * li);
+    v3_add(pos, pos, d->xpos + 3 * b);
+    m3_mulv(dir, d->xmat + 9 * b, m->light_dir + 3 * li);
+    if (m->light_directional[li]) { L[0] = -dir[0]; L[1] = -dir[1]; L[2] = -dir[2]; }
+    else {
+      v3_sub(L, pos, p);
+      light_dist = sqrt(v3_dot(L, L));
+      if (light_dist < ORA_MINVAL) continue;
+      L[0] /= light_dist; L[1] /= light_dist; L[2] /= light_dist;
+    }
+    out[4 * li] = v3_dot(n, L);
+    out[4 * li + 3] = light_dist;
+    for (int g = 0; g < m->ngeom; g++) {
+      if (g == hit || m->geom_rgba[4 * g + 3] == 0) continue;
+      double x = ora_ray_geom(m->geom_type[g], d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, p, L);
+      if (x >= 0 && (m->light_directional[li] || x < light_dist)) { out[4 * li + 1] = g; out[4 * li + 2] = x; break; }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ accessors for the test harness */
 typedef struct { const char* name; size_t offset; } field_t;
 #define F(name) {#name, offsetof(ora_data, name)}
