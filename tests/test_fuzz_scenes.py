@@ -253,3 +253,49 @@ def test_random_articulated_scenes_step_like_the_oracle(block):
         assert worst < 1e-8, (seed, worst)
         shapes.add((model.ntree, model.rowmap, model.nv))
     assert len(shapes) >= 2
+
+
+def many_sensors_scene():
+    """Two free bodies with twelve sites and 84 sensors between them -- more than a wavefront has lanes: sensors 64.. take the
+    sensor stage's second pass, which reads their records from the model instead of the lane records."""
+    rng = np.random.default_rng(77)
+    bodies, sensors = [], []
+    for b in range(2):
+        sites = []
+        for k in range(6):
+            e = rng.uniform(-180, 180, 3)
+            p = rng.uniform(-0.1, 0.1, 3)
+            name = f"s{b}_{k}"
+            sites.append(f'<site name="{name}" pos="{p[0]:.3f} {p[1]:.3f} {p[2]:.3f}" size="{rng.uniform(0.1, 0.25):.3f}" '
+                         f'euler="{e[0]:.1f} {e[1]:.1f} {e[2]:.1f}"/>')
+            for kind in ("rangefinder", "touch", "accelerometer", "framexaxis", "frameyaxis", "framezaxis", "rangefinder"):
+                if kind.startswith("frame"):
+                    sensors.append(f'<{kind} objtype="site" objname="{name}"/>')
+                else:
+                    sensors.append(f'<{kind} site="{name}" cutoff="{rng.choice([0, 2, 40])}"/>')
+        geom = ('<geom type="box" size="0.12 0.09 0.07"/><geom type="sphere" size="0.08" pos="0.1 0.05 0.06"/>' if b == 0 else
+                '<geom type="capsule" size="0.06" fromto="0 0 0 0.15 0.05 0.1"/>')
+        bodies.append(f'<body pos="{0.25 * b - 0.1:.2f} 0.05 {0.5 + 0.3 * b:.2f}" euler="20 {30 + 50 * b} 10"><joint type="free"/>{geom}{"".join(sites)}</body>')
+    return f"""
+<mujoco><option timestep="0.002"/>
+<default><geom density="300" friction="0.6 0.005 0.0001"/></default>
+<worldbody><geom type="plane" size="5 5 0.1"/><body pos="0.6 0 0.3"><geom type="box" size="0.15 0.8 0.3"/></body>{"".join(bodies)}</worldbody>
+<sensor>{"".join(sensors)}</sensor></mujoco>"""
+
+
+def test_more_sensors_than_lanes():
+    """84 sensors: the second pass of the sensor stage (records read from the model) against the oracle, every step."""
+    model = mjcf.compile_mjcf_string(many_sensors_scene(), nconmax=24, njmax=120)
+    assert model.nsensor == 84 and model.nsensordata == 2 * 6 * (1 + 1 + 3 + 9 + 1)
+    packed = blob.pack(model)
+    ora, emu = OracleEnv(packed), EmuEnv(model, packed)
+    emu.step(forward_only=True)
+    touched = 0.0
+    for step in range(300):
+        img = emu.step()
+        ora.step()
+        assert (img.ncon, img.nefc, img.niter) == (ora.ncon, ora.nefc, ora.niter), step
+        assert np.allclose(emu.sens[:model.nsensordata], ora.sensordata, rtol=1e-8, atol=1e-8), step
+        late = np.asarray(model.sensor_adr)[(np.asarray(model.sensor_type) == mjcf.SENS_TOUCH) & (np.arange(model.nsensor) >= 64)]
+        touched = max(touched, float(ora.sensordata[late].max()))
+    assert touched > 0            # a touch sensor of the second pass did read a force

@@ -784,3 +784,24 @@ def test_ray_kernel_on_random_scenes_against_the_oracle(monkeypatch):
                 images += 1
         h.close(); ora.close()
     assert images > 100
+
+
+def test_more_sensors_than_lanes_through_the_c_abi(few_build):
+    """84 sensors on two free bodies (tests/test_fuzz_scenes.many_sensors_scene): sensors 0..63 come from the lane records the
+    library builds on the host, sensors 64.. from the model in the sensor stage's second pass -- every reading of every step
+    against the oracle, generic and specialised kernel."""
+    from tests.test_fuzz_scenes import many_sensors_scene
+    model = mjcf.compile_mjcf_string(many_sensors_scene(), nconmax=24, njmax=120)
+    packed = blob.pack(model)
+    for specialize in (False, True):
+        h = _capi.Handle(packed, 2, specialize=specialize)
+        h.reset()
+        ora = OracleEnv(packed)
+        assert np.allclose(h.get_field("sensordata"), ora.sensordata[None, :], rtol=1e-8, atol=1e-8)
+        for step in range(300):
+            h.step_host(None, 1)
+            ora.step()
+            sd = h.get_field("sensordata")
+            assert np.allclose(sd, ora.sensordata[None, :], rtol=1e-8, atol=1e-8), (specialize, step)
+        assert np.abs(h.get_field("qpos") - ora.qpos).max() < 1e-9
+        h.close(); ora.close()
