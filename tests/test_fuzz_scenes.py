@@ -299,3 +299,36 @@ def test_more_sensors_than_lanes():
         late = np.asarray(model.sensor_adr)[(np.asarray(model.sensor_type) == mjcf.SENS_TOUCH) & (np.arange(model.nsensor) >= 64)]
         touched = max(touched, float(ora.sensordata[late].max()))
     assert touched > 0            # a touch sensor of the second pass did read a force
+
+
+TWO_MOTORS_ONE_JOINT = """
+<mujoco><option timestep="0.002"/>
+<worldbody><geom type="plane" size="5 5 0.1"/>
+<body pos="0 0 0.6"><joint name="root" type="hinge" axis="0 1 0" damping="0.2"/><geom type="capsule" size="0.04" fromto="0 0 0 0.3 0 0"/>
+  <body pos="0.3 0 0"><joint name="elbow" type="hinge" axis="0 1 0" damping="0.1" limited="true" range="-60 60"/>
+    <geom type="capsule" size="0.03" fromto="0 0 0 0.25 0 0"/></body></body>
+<body pos="0 0.5 0.3"><joint type="free"/><geom type="sphere" size="0.1"/></body></worldbody>
+<actuator><motor joint="root" gear="3" ctrllimited="true" ctrlrange="-1 1"/><motor joint="elbow" gear="2"/>
+<motor joint="root" gear="-1.5" ctrllimited="true" ctrlrange="-0.5 0.5"/></actuator></mujoco>"""
+
+
+def test_two_motors_on_one_joint():
+    """A dof driven by two motors (the stage that sums the actuator forces then scans the actuator list instead of reading
+    the dof's one actuator from its lane record): their clamped, geared controls add up -- against the oracle, and against
+    the closed form at the first step."""
+    model = mjcf.compile_mjcf_string(TWO_MOTORS_ONE_JOINT)
+    assert model.nu == 3 and list(model.arrays["dof_actid"][:2]) == [-2, 1]
+    packed = blob.pack(model)
+    ora, emu = OracleEnv(packed), EmuEnv(model, packed)
+    emu.step(forward_only=True)
+    rng = np.random.default_rng(3)
+    for step in range(200):
+        if step % 8 == 0:
+            ctrl = rng.uniform(-1.5, 1.5, 3)
+            ora.ctrl[:3] = ctrl
+            emu.ctrl[:3] = ctrl
+        img = emu.step()
+        ora.step()
+        assert (img.ncon, img.nefc, img.niter) == (ora.ncon, ora.nefc, ora.niter), step
+        assert np.allclose(ora.qfrc_actuator[0], 3 * np.clip(ora.ctrl[0], -1, 1) - 1.5 * np.clip(ora.ctrl[2], -0.5, 0.5), atol=1e-14)
+        assert np.abs(emu.qpos - ora.qpos).max() < 1e-9 and np.abs(emu.qvel - ora.qvel).max() < 1e-8, step

@@ -805,3 +805,26 @@ def test_more_sensors_than_lanes_through_the_c_abi(few_build):
             assert np.allclose(sd, ora.sensordata[None, :], rtol=1e-8, atol=1e-8), (specialize, step)
         assert np.abs(h.get_field("qpos") - ora.qpos).max() < 1e-9
         h.close(); ora.close()
+
+
+def test_two_motors_on_one_joint_through_the_c_abi(few_build):
+    """A dof with two motors (dof_actid -2: the smooth stage scans the actuator list), controls beyond their clamps: states
+    against the oracle, generic and specialised kernel."""
+    from tests.test_fuzz_scenes import TWO_MOTORS_ONE_JOINT
+    model = mjcf.compile_mjcf_string(TWO_MOTORS_ONE_JOINT)
+    packed = blob.pack(model)
+    for specialize in (False, True):
+        h = _capi.Handle(packed, 2, specialize=specialize)
+        h.reset()
+        ora = OracleEnv(packed)
+        rng = np.random.default_rng(3)
+        for step in range(200):
+            if step % 8 == 0:
+                ctrl = rng.uniform(-1.5, 1.5, 3)
+                ora.ctrl[:3] = ctrl
+                h.set_field("ctrl", np.tile(ctrl, (2, 1)))
+            h.step_host(None, 1)
+            ora.step()
+        assert np.abs(h.get_field("qpos") - ora.qpos).max() < 1e-9 and np.abs(h.get_field("qvel") - ora.qvel).max() < 1e-8
+        assert np.abs(ora.qvel[:2]).max() > 0.1          # the arm did move
+        h.close(); ora.close()
