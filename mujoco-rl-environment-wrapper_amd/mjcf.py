@@ -579,6 +579,9 @@ class _Compiler:
             pos = 0.5 * (ft[:3] + ft[3:])
             quat = z_to_quat(vec / length)
             size = np.array([size[0], 0.5 * length, 0.0])
+        # (condim 4 / 6 add torsional / rolling friction rows; the row builder makes the normal row or the 4-edge pyramid)
+        if int(a.get("condim", 3)) not in (1, 3):
+            _refuse(f'geom condim {a.get("condim")} (1 and 3 only: torsional and rolling friction are not implemented)')
         g = dict(name=a.get("name", ""), type=gtype, body=body_id, size=size, pos=pos, quat=quat,
                  friction=_vec(a.get("friction"), 3, [1.0, 0.005, 0.0001]),
                  density=float(a.get("density", 1000.0)), margin=float(a.get("margin", 0.0)),

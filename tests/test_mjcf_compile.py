@@ -342,6 +342,8 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1"/><light mode="trackcom" pos="0 0 2"/></body>', "", "",
      "light mode"),
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" group="3"/><camera name="c"/></body>', "", "", "group 3"),
+    ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" condim="4"/></body>', "", "", "condim 4"),
+    ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" condim="6"/></body>', "", "", "condim 6"),
 ])
 def test_features_outside_the_subset_are_refused_by_name(body, head, tail, named):
     with pytest.raises(mjcf.UnsupportedMJCF) as err:
