@@ -549,6 +549,8 @@ class _Compiler:
         axis = _vec(a.get("axis"), 3, [0, 0, 1])
         n = np.linalg.norm(axis)
         axis = axis / n if n > MINVAL else np.array([0.0, 0, 1])
+        if "solreflimit" in a and min(_vec(a["solreflimit"])) <= 0:
+            _refuse(f'joint solreflimit "{a["solreflimit"]}" (the direct stiffness / damping form; positive timeconst and dampratio only)')
         j = dict(name=a.get("name", ""), type=jtype, body=body_id, pos=_vec(a.get("pos"), 3, [0, 0, 0]),
                  axis=axis, limited=limited and jtype != JNT_FREE, range=rng,
                  margin=float(a.get("margin", 0.0)), armature=float(a.get("armature", 0.0)),
@@ -579,6 +581,9 @@ class _Compiler:
             pos = 0.5 * (ft[:3] + ft[3:])
             quat = z_to_quat(vec / length)
             size = np.array([size[0], 0.5 * length, 0.0])
+        # (solref <= 0 is MuJoCo's direct form, (-stiffness, -damping); the row builder implements (timeconst, dampratio))
+        if "solref" in a and min(_vec(a["solref"])) <= 0:
+            _refuse(f'geom solref "{a["solref"]}" (the direct stiffness / damping form; positive timeconst and dampratio only)')
         # (condim 4 / 6 add torsional / rolling friction rows; the row builder makes the normal row or the 4-edge pyramid)
         if int(a.get("condim", 3)) not in (1, 3):
             _refuse(f'geom condim {a.get("condim")} (1 and 3 only: torsional and rolling friction are not implemented)')

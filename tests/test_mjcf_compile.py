@@ -344,6 +344,9 @@ TWO = ('<body name="a" pos="0 0 1"><joint name="ja" type="hinge"/><geom name="ga
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" group="3"/><camera name="c"/></body>', "", "", "group 3"),
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" condim="4"/></body>', "", "", "condim 4"),
     ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" condim="6"/></body>', "", "", "condim 6"),
+    ('<body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" solref="-1000 -10"/></body>', "", "", "solref"),
+    ('<body pos="0 0 1"><joint type="hinge" limited="true" range="-1 1" solreflimit="-100 -1"/><geom type="sphere" size="0.1"/></body>',
+     "", "", "solreflimit"),
 ])
 def test_features_outside_the_subset_are_refused_by_name(body, head, tail, named):
     with pytest.raises(mjcf.UnsupportedMJCF) as err:
